@@ -1,0 +1,113 @@
+/* ractip_hot.h -- C ABI of the MI355X-native probability-matrix engine for RactIP.
+ *
+ * This is the drop-in boundary of SURVEY.md section 8(b): plain C, no C++ types,
+ * no exceptions, caller-owned output buffers, one context per host thread / GPU.
+ * Every entry point names the reference interface it replaces (paths relative
+ * to /root/reference).  The C++ adapters that rebuild the reference's
+ * VF/VI/VVF containers on top of this ABI live in ractip_amd/host/.
+ *
+ * Status codes: 0 = ok, negative = error (see rh_last_error).
+ * Layouts (identical to the reference):
+ *   bp  : T(n) = (n+1)(n+2)/2 doubles, element (i,j), 1 <= i < j <= n, at
+ *         offset[i]+j with offset[i] = i*(2(n+1)-i-1)/2   (src/ractip.cpp:254-257,
+ *         src/contrafold/InferenceEngine.ipp:316); all other entries 0.
+ *   up  : n*max_w doubles row-major, up[i*max_w+w] = P(i..i+w unpaired), 0-based i
+ *         (src/ractip.cpp:213-222 for max_w=1; src/ractip.cpp:370-375).
+ *   hp  : (n1+1)*(n2+1) doubles row-major, 1-based, row 0 / column 0 zero
+ *         (src/ractip.cpp:393-397, 236-244).
+ */
+#ifndef RACTIP_HOT_H
+#define RACTIP_HOT_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rh_ctx rh_ctx;
+
+/* scoring model selector */
+#define RH_MODEL_CONTRAFOLD 0 /* --contrafold path: src/ractip.cpp:195-246 */
+#define RH_MODEL_VIENNA_BL 1  /* default / --duplex path; parity unpinned; not built yet */
+
+#define RH_OK 0
+#define RH_ERR_ARG (-1)
+#define RH_ERR_HIP (-2)
+#define RH_ERR_OOM (-3)
+#define RH_ERR_PARAM (-4)
+#define RH_ERR_UNSUPPORTED (-5)
+
+/* Create a context bound to HIP device `device`.  `param_file` = NULL loads the
+ * bundled default weights (ractip_amd/data/contrafold_complementary.params, the
+ * values of GetDefaultComplementaryValues, src/contrafold/Defaults.ipp:7-723).
+ * Replaces the per-call engine construction of src/ractip.cpp:199-206, 229-234.
+ * Returns NULL on failure; rh_last_error(NULL) then describes why. */
+rh_ctx* rh_create(int device, int model, const char* param_file);
+void rh_destroy(rh_ctx* ctx);
+const char* rh_last_error(const rh_ctx* ctx);
+
+/* Base-pairing probabilities of one sequence.  Replaces the body of
+ * RactIP::contrafold up to GetPosterior (src/ractip.cpp:199-211:
+ * ComputeInside/ComputeOutside/ComputePosterior/GetPosterior(0,...)) and, for
+ * RH_MODEL_VIENNA_BL, pf_fold + export_bppm of RactIP::rnafold
+ * (src/ractip.cpp:288-304, 351-367).  `constraint` must be NULL for now. */
+int rh_bpp(rh_ctx* ctx, const char* seq, int n, const char* constraint,
+           double* bp_tri, double* logZ);
+
+/* Accessibility.  max_w == 1 replaces src/ractip.cpp:213-222
+ * (up[i] = max(0, 1 - sum_j bp(i,j))); max_w > 1 (pf_unstru, src/ractip.cpp:370-375)
+ * is RH_ERR_UNSUPPORTED until the Vienna model exists. */
+int rh_unpaired(rh_ctx* ctx, const char* seq, int n, int max_w, double* up);
+
+/* Hybridization probabilities of a pair.  Replaces RactIP::contraduplex
+ * (src/ractip.cpp:225-245: DuplexEngine ComputeInside/Outside/Posterior) and, for
+ * RH_MODEL_VIENNA_BL, pf_duplex + pr_duplex of RactIP::rnaduplex (src/ractip.cpp:390-398). */
+int rh_duplex(rh_ctx* ctx, const char* s1, int n1, const char* s2, int n2,
+              double* hp, double* logZ);
+
+/* ---- batched, device-resident form (z-score loop src/ractip.cpp:1638-1657 and bench) ----
+ * A batch is `npairs` independent (s1,s2) pairs; for each the engine computes
+ * bp(s1), bp(s2), up(s1), up(s2) and hp(s1,s2) -- everything RactIP::solve needs
+ * before the ILP (src/ractip.cpp:536-548).
+ *   rh_batch_upload   : encode + copy the sequences to HBM, (re)allocate tables
+ *   rh_batch_compute  : run all DP kernels (inputs already resident); blocks until done
+ *   rh_batch_results  : copy dense results of pair `p` to caller buffers (any may be NULL)
+ *   rh_batch_candidates: thresholded sparse results of pair `p` -- the scans of
+ *                       src/ractip.cpp:557-568, 578-589, 598-608, 621-627 done on device.
+ */
+int rh_batch_upload(rh_ctx* ctx, int npairs,
+                    const char* const* s1, const int* n1,
+                    const char* const* s2, const int* n2);
+int rh_batch_compute(rh_ctx* ctx);
+int rh_batch_results(rh_ctx* ctx, int p,
+                     double* bp1_tri, double* bp2_tri, double* up1, double* up2,
+                     double* hp, double* logZ3 /* logZ(s1), logZ(s2), logZ(duplex) */);
+
+typedef struct rh_cand {
+    int i, j; /* 1-based letters; for `up`: i = 0-based position, j = width index */
+    float p;  /* probability narrowed to float exactly as the reference does (src/ractip.cpp:82-83) */
+} rh_cand;
+/* which: 0 = bp1 (p > th), 1 = bp2, 2 = hp, 3 = up1, 4 = up2.  Writes at most `cap`
+ * entries in row-major scan order and returns the total number found (>= 0) or an error. */
+int rh_batch_candidates(rh_ctx* ctx, int p, int which, float threshold, rh_cand* out, int cap);
+
+/* Device time (ms, HIP events on the context's streams) spent by the last
+ * rh_batch_compute in: [0] McCaskill inside sweep, [1] McCaskill outside sweep
+ * (+posterior), [2] duplex sweeps, [3] whole compute.  Launch counts in n_launch[0..2]. */
+int rh_batch_timings(rh_ctx* ctx, double ms[4], int n_launch[3]);
+
+/* Device pointers of the last batch (for callers that keep results on the GPU):
+ * bp tables [2*npairs][tri_stride] (sequence 2p = s1 of pair p, 2p+1 = s2),
+ * hp tables [npairs][hp_stride]. */
+int rh_batch_device_views(rh_ctx* ctx, const double** bp, size_t* tri_stride,
+                          const double** hp, size_t* hp_stride, int* hp_ld);
+
+/* ---- source-compatible pf_duplex surface (src/pf_duplex.h:25-28) ----
+ * double pf_duplex(const char*, const char*); extern double** pr_duplex; void free_pf_duplex();
+ * are provided by libractip_pfduplex (ractip_amd/csrc/pf_duplex_shim.cpp) on top of rh_duplex. */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RACTIP_HOT_H */

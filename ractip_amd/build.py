@@ -1,0 +1,57 @@
+"""Build the in-tree native libraries (hipcc, gfx950 only).
+
+  python -m ractip_amd.build            # libractip_hot.so (+ host adapters)
+
+hipcc cross-compiles without a GPU; the built .so files stay in-tree (git-ignored)
+so that they travel with the repository snapshot to the GPU box.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+HOT_SOURCES = ["rh_api.hip", "mccaskill.hip", "duplex.hip", "param_loader.cpp"]
+HOT_LIB = os.path.join(PKG, "libractip_hot.so")
+
+
+def _hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the ROCm toolchain is required to build ractip_amd")
+    return exe
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_hot(force=False, verbose=True):
+    srcs = [os.path.join(CSRC, s) for s in HOT_SOURCES]
+    deps = srcs + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
+    deps.append(os.path.join(ROOT, "include", "ractip_hot.h"))
+    if not force and not _stale(HOT_LIB, deps):
+        return HOT_LIB
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
+           "-Wno-unused-function", "-o", HOT_LIB] + srcs + ["-ldl"]
+    if verbose:
+        print("[ractip_amd.build]", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return HOT_LIB
+
+
+def build_all(force=False, verbose=True):
+    out = [build_hot(force, verbose)]
+    host = os.path.join(PKG, "host", "Makefile")
+    if os.path.exists(host):
+        subprocess.check_call(["make", "-s", "-C", os.path.dirname(host)])
+    return out
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)

@@ -1,0 +1,71 @@
+// batch.h -- HBM layout of one batch of independent DP problems.
+//
+// McCaskill side: NS sequences (2 per pair).  Every DP table is a square
+// ld x ld array of doubles per sequence (ld = nmax+2, gap indices 0..n on both
+// axes, element [r*ld+c]); tables that are read along a column by some
+// recurrence are ALSO stored transposed so that every inner loop of every kernel
+// streams two contiguous rows.  Only interior cells 1 <= i <= j <= n-1 are ever
+// read, and each is fully (re)written by the sweep, so tables need no clearing
+// between batches.
+//
+// Duplex side: NP pairs, tables (n1max+2) x ldd, 1-based letters.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+namespace rh {
+
+// ---- McCaskill tables (gap-indexed cell (i,j): letters i+1..j inside; FC assumes
+//      letters (i, j+1) paired -- InferenceEngine.ipp:3556-3567)
+enum McTable {
+    T_FC = 0,   // FCi[i][j]
+    T_FCX,      // FCi + ScoreBasePair(i,j+1) + ScoreJunctionB(j+1,i-1): operand of single-branch loops
+    T_FCA,      // FCi + ScoreBasePair(i,j+1) + ScoreJunctionA(j+1,i-1): operand of FM1 / F5
+    T_FCAT,     // transpose of T_FCA  ([j][i])
+    T_FM1,      // FM1i[i][j]
+    T_FM1T,     // [j][i]
+    T_FM,       // FMi[i][j]
+    T_FMT,      // [j][i]
+    T_FCO,      // FCo[i][j]
+    T_FCOX,     // FCo + ScoreJunctionB(i,j): operand of the outside single-branch gather
+    T_FM2O,     // FM2o[i][j]
+    T_FM2OT,    // [j][i]
+    T_FMO,      // FMo[i][j]
+    T_FM1O,     // FM1o[i][j]
+    T_COUNT
+};
+
+struct McBatch {
+    const uint8_t* seq;  // [NS][lds] nucleotide codes, seq[0] = seq[n+1] = 4
+    const int* n;        // [NS]
+    double* tab;         // [NS][T_COUNT][ld*ld]
+    double* f5i;         // [NS][ld]  F5i[0..n]
+    double* f5o;         // [NS][ld]  F5o[0..n]
+    double* bp;          // [NS][tri_stride] posterior, reference triangular layout
+    double* up;          // [NS][ld]  width-1 unpaired probability, 0-based
+    int ns, nmax, ld, lds;
+    size_t tab_stride;   // doubles per table  (ld*ld)
+    size_t seq_stride;   // doubles per sequence (T_COUNT*ld*ld)
+    size_t tri_stride;   // doubles per bp table
+};
+
+enum DxTable {
+    D_IN = 0,  // inside[i][j]
+    D_INX,     // inside + terminal_mismatch[s1[i]][s2[j]][s1[i+1]][s2[j-1]]: as upstream pair of a loop
+    D_OUT,     // outside[i][j]
+    D_OUTX,    // outside + terminal_mismatch[s2[j]][s1[i]][s2[j+1]][s1[i-1]] + base_pair[s1[i]][s2[j]]
+    D_COUNT
+};
+
+struct DxBatch {
+    const uint8_t* seq;  // the McCaskill sequence buffer: pair p = sequences 2p (s1) and 2p+1 (s2)
+    const int* n;        // [2*NP]
+    double* tab;         // [NP][D_COUNT][rows*ldd]
+    double* hp;          // [NP][rows*ldd]  posterior, 1-based, row/col 0 zero
+    double* logz;        // [NP]
+    int np, n1max, n2max, ldd, lds;
+    size_t tab_stride;   // rows*ldd
+    size_t pair_stride;  // D_COUNT*rows*ldd
+};
+
+}  // namespace rh

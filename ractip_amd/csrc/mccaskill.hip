@@ -1,0 +1,330 @@
+// mccaskill.hip -- McCaskill inside / outside / posterior sweeps for gfx950.
+//
+// What the reference computes (CONTRAfold model, /root/reference/src/contrafold):
+//   ComputeInside    InferenceEngine.ipp:3356-3722   (FM2 3384-3411, FC 3567-3627,
+//                                                     FM1 3641-3657, FM 3669-3688, F5 3692-3717)
+//   ComputeOutside   InferenceEngine.ipp:3731-4080   (push form, read-modify-write)
+//   ComputePosterior InferenceEngine.ipp:4498-4828
+//
+// How it is organised here (not a translation):
+//   * span wavefront: one launch per diagonal d = j-i; every cell of a diagonal for
+//     every sequence of the batch is independent, one 64-lane wavefront per cell;
+//   * outside is rewritten in PULL form on decreasing spans -- every target gathers
+//     from already-final sources, so there are no atomics or RMW races:
+//       FMo [i,j] = FMo[i,j+1]+b  (+)  (+)_{i'<i} FM2o[i',j] + FM1i[i',i]
+//       FM1o[i,j] = FMo[i,j] (+) FM1o[i-1,j]+b (+) (+)_{j'>j} FM2o[i,j'] + FMi[j,j']
+//       FCo [i,j] = exterior (+) multi (+) stack (+) (+)_{enclosing loops} FCo[i',j'] + score
+//       FM2o[i,j] = FMo[i,j] (+) FCo[i,j] + ScoreJunctionA(i,j) + a + c
+//   * every inner loop streams two contiguous rows (transposed mirrors are written
+//     by the producing cell), so lanes read 512 B coalesced segments;
+//   * the posterior needs no third sweep: the reference's sum over parent contexts
+//     of exp(context + FCi - Z) (ipp:4689-4817) is exp(FCo + FCi - Z) by definition
+//     of FCo, so it is emitted by the outside cell as soon as FCo is final.
+#include <hip/hip_runtime.h>
+
+#include "batch.h"
+#include "lse.h"
+#include "score_model.h"
+
+namespace rh {
+
+namespace {
+
+// AU, CG, GU both ways (InferenceEngine.ipp:391-396); code 4 (unknown letter) never pairs
+constexpr uint32_t kPairMask = (1u << (0 * 5 + 3)) | (1u << (3 * 5 + 0)) | (1u << (1 * 5 + 2)) |
+                               (1u << (2 * 5 + 1)) | (1u << (2 * 5 + 3)) | (1u << (3 * 5 + 2));
+__device__ __forceinline__ bool complementary(int a, int b) { return (kPairMask >> (a * 5 + b)) & 1u; }
+
+__device__ __forceinline__ double tm4(const ScoreModel* M, int a, int b, int c, int d)
+{
+    return M->terminal_mismatch[((a * 5 + b) * 5 + c) * 5 + d];
+}
+__device__ __forceinline__ double hs4(const ScoreModel* M, int a, int b, int c, int d)
+{
+    return M->helix_stacking[((a * 5 + b) * 5 + c) * 5 + d];
+}
+// ScoreJunctionB(i,j) (ipp:2004-2029): letters s[i], s[j+1], s[i+1], s[j]
+__device__ __forceinline__ double junction_b(const ScoreModel* M, int si, int sj1, int si1, int sj)
+{
+    return M->helix_closing[si * 5 + sj1] + tm4(M, si, sj1, si1, sj);
+}
+// ScoreJunctionA(i,j) (ipp:1927-1956); sentinel code 4 zeroes the edge dangles
+__device__ __forceinline__ double junction_a(const ScoreModel* M, int si, int sj1, int si1, int sj)
+{
+    return M->helix_closing[si * 5 + sj1] + M->dangle_left[si * 25 + sj1 * 5 + si1] +
+           M->dangle_right[si * 25 + sj1 * 5 + sj];
+}
+// ScoreSingleNucleotides (ipp:2290-2360) for the three shapes with a nucleotide term,
+// enclosing pair (i,j) [gap indices], shape (l1,l2)
+__device__ __forceinline__ double single_nucs(const ScoreModel* M, int l1, int l2, int s_ip1, int s_j)
+{
+    double v = 0.0;
+    if (l1 == 0 && l2 == 1) v = M->bulge_0x1[s_j];
+    if (l1 == 1 && l2 == 0) v = M->bulge_1x0[s_ip1];
+    if (l1 == 1 && l2 == 1) v = M->internal_1x1[s_ip1 * 5 + s_j];
+    return v;
+}
+
+__device__ __forceinline__ size_t tri_offset(int n, int i) { return (size_t)i * (size_t)(2 * (n + 1) - i - 1) / 2; }
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------
+// one-off per batch: F5i[0] = 0, F5o[n] = 0 (ipp:3690, 3750)
+__global__ void mc_init(McBatch B)
+{
+    const int sq = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sq >= B.ns) return;
+    const int n = B.n[sq];
+    B.f5i[(size_t)sq * B.ld] = 0.0;
+    B.f5o[(size_t)sq * B.ld + n] = 0.0;
+}
+
+// ---------------------------------------------------------------------------------
+// inside, diagonal d: cells (i, i+d), 1 <= i <= n-1-d, one wavefront each; the wave
+// after the last cell computes F5i[d+1].
+__global__ __launch_bounds__(256) void mc_inside_diag(McBatch B, const ScoreModel* __restrict__ M, int d)
+{
+    const int sq = blockIdx.y;
+    const int n = B.n[sq];
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int ncell = n - 1 - d > 0 ? n - 1 - d : 0;
+    if (d > n - 1 || wave > ncell) return;
+
+    const int ld = B.ld;
+    const uint8_t* __restrict__ s = B.seq + (size_t)sq * B.lds;
+    double* __restrict__ tab = B.tab + (size_t)sq * B.seq_stride;
+    double* __restrict__ f5i = B.f5i + (size_t)sq * ld;
+    const size_t ts = B.tab_stride;
+
+    if (wave == ncell) {
+        // F5i[jj] = F5i[jj-1]+ext_unpaired (+) (+)_{k<=jj-2} F5i[k] + ext_paired + FCA[k+1][jj-1]   (ipp:3692-3717)
+        const int jj = d + 1;
+        const double* __restrict__ fcat = tab + T_FCAT * ts + (size_t)(jj - 1) * ld;
+        Lse acc = lse_empty();
+        for (int k = lane; k <= jj - 2; k += 64) lse_add(acc, f5i[k] + M->external_paired + fcat[k + 1]);
+        if (lane == 0) lse_add(acc, f5i[jj - 1] + M->external_unpaired);
+        const double v = lse_wave_finish(acc);
+        if (lane == 0) f5i[jj] = v;
+        return;
+    }
+
+    const int i = wave + 1, j = i + d;
+    const int s_im1 = s[i - 1], s_i = s[i], s_ip1 = s[i + 1], s_j = s[j], s_jp1 = s[j + 1], s_jp2 = s[j + 2];
+
+    // ---- FM2[i,j] = (+)_{i<k<j} FM1[i,k] + FM[k,j]        (ipp:3384-3411)
+    double fm2 = kNeg;
+    if (d >= 2) {
+        const double* __restrict__ r1 = tab + T_FM1 * ts + (size_t)i * ld;
+        const double* __restrict__ r2 = tab + T_FMT * ts + (size_t)j * ld;
+        Lse acc = lse_empty();
+        for (int k = i + 1 + lane; k < j; k += 64) lse_add(acc, r1[k] + r2[k]);
+        fm2 = lse_wave_finish(acc);
+    }
+
+    // ---- FC[i,j]                                            (ipp:3567-3627)
+    double fc = kNeg;
+    const bool pairable = complementary(s_i, s_jp1);
+    if (pairable) {
+        Lse acc = lse_empty();
+        const double jb = junction_b(M, s_i, s_jp1, s_ip1, s_j);
+        if (d >= 2) {
+            const int tmax = d - 2 < kMaxSingle ? d - 2 : kMaxSingle;
+            const int cnt = (tmax + 1) * (tmax + 2) / 2;
+            const double* __restrict__ fcx = tab + T_FCX * ts;
+            for (int c = lane; c < cnt; c += 64) {
+                const int len = M->mc_combo_len[c];
+                const int l1 = len & 0xff, l2 = len >> 8;
+                double x;
+                if (c == 0) {  // stacking pair: FC[i+1,j-1] + ScoreBasePair(i+1,j) + ScoreHelixStacking(i,j+1)
+                    x = tab[T_FC * ts + (size_t)(i + 1) * ld + (j - 1)] + M->base_pair[s_ip1 * 5 + s_j] +
+                        hs4(M, s_i, s_jp1, s_ip1, s_j);
+                } else {
+                    x = fcx[(size_t)(i + 1 + l1) * ld + (j - 1 - l2)] + M->mc_combo_score[c] + jb;
+                    if (c < 5) x += single_nucs(M, l1, l2, s_ip1, s_j);
+                }
+                lse_add(acc, x);
+            }
+        }
+        if (lane == 0) {
+            if (d >= kMinHairpin) lse_add(acc, jb + M->hairpin_len[d < 30 ? d : 30]);  // ScoreHairpin, ipp:2123-2152
+            lse_add(acc, fm2 + junction_a(M, s_i, s_jp1, s_ip1, s_j) + M->multi_paired + M->multi_base);
+        }
+        fc = lse_wave_finish(acc);
+    }
+
+    // ---- FM1[i,j], FM[i,j]                                  (ipp:3641-3688)
+    double fm1 = kNeg, fm = kNeg;
+    if (d >= 2) {
+        const double a = tab[T_FCA * ts + (size_t)(i + 1) * ld + (j - 1)] + M->multi_paired;
+        const double b = tab[T_FM1 * ts + (size_t)(i + 1) * ld + j] + M->multi_unpaired;
+        fm1 = lse2(a, b);
+        const double c = tab[T_FM * ts + (size_t)i * ld + (j - 1)] + M->multi_unpaired;
+        fm = lse3(fm2, c, fm1);
+    }
+
+    if (lane == 0) {
+        const size_t ij = (size_t)i * ld + j, ji = (size_t)j * ld + i;
+        const double bp = M->base_pair[s_i * 5 + s_jp1];
+        // as the inner pair (p+1,q) = (i,j+1) of an enclosing loop: ScoreJunctionB(q,p) = JB(j+1,i-1)
+        const double dec_x = bp + junction_b(M, s_jp1, s_i, s_jp2, s_im1);
+        // as a branch of a multi/exterior loop: ScoreJunctionA(j+1,i-1)
+        const double dec_a = bp + junction_a(M, s_jp1, s_i, s_jp2, s_im1);
+        tab[T_FC * ts + ij] = fc;
+        tab[T_FCX * ts + ij] = pairable ? fc + dec_x : kNeg;
+        const double fca = pairable ? fc + dec_a : kNeg;
+        tab[T_FCA * ts + ij] = fca;
+        tab[T_FCAT * ts + ji] = fca;
+        tab[T_FM1 * ts + ij] = fm1;
+        tab[T_FM1T * ts + ji] = fm1;
+        tab[T_FM * ts + ij] = fm;
+        tab[T_FMT * ts + ji] = fm;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// outside (pull form) + posterior, diagonal d: cells (i, i+d), 1 <= i <= n-1-d; the
+// wave after the last cell computes F5o[d+1].
+__global__ __launch_bounds__(256) void mc_outside_diag(McBatch B, const ScoreModel* __restrict__ M, int d)
+{
+    const int sq = blockIdx.y;
+    const int n = B.n[sq];
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int ncell = n - 1 - d;
+    if (ncell < 1 || wave > ncell) return;
+
+    const int ld = B.ld;
+    const uint8_t* __restrict__ s = B.seq + (size_t)sq * B.lds;
+    double* __restrict__ tab = B.tab + (size_t)sq * B.seq_stride;
+    const double* __restrict__ f5i = B.f5i + (size_t)sq * ld;
+    double* __restrict__ f5o = B.f5o + (size_t)sq * ld;
+    const size_t ts = B.tab_stride;
+
+    if (wave == ncell) {
+        // F5o[k] = F5o[k+1]+ext_unpaired (+) (+)_{jj>=k+2} F5o[jj] + ext_paired + FCA[k+1][jj-1]   (ipp:3751-3780, pulled)
+        const int k = d + 1;
+        const double* __restrict__ fca = tab + T_FCA * ts + (size_t)(k + 1) * ld;
+        Lse acc = lse_empty();
+        for (int jj = k + 2 + lane; jj <= n; jj += 64) lse_add(acc, f5o[jj] + M->external_paired + fca[jj - 1]);
+        if (lane == 0) lse_add(acc, f5o[k + 1] + M->external_unpaired);
+        const double v = lse_wave_finish(acc);
+        if (lane == 0) f5o[k] = v;
+        return;
+    }
+
+    const int i = wave + 1, j = i + d;
+    const int s_im1 = s[i - 1], s_i = s[i], s_ip1 = s[i + 1], s_j = s[j], s_jp1 = s[j + 1], s_jp2 = s[j + 2];
+    const bool guard_m = d >= 2;
+
+    // ---- FMo[i,j], FM1o[i,j]
+    double fmo = kNeg, fm1o = kNeg;
+    if (guard_m) {
+        {   // column gather: FM2o[i',j] + FM1i[i',i], i' = 1..i-1   (ipp:4046-4064, second update, pulled)
+            const double* __restrict__ r1 = tab + T_FM2OT * ts + (size_t)j * ld;
+            const double* __restrict__ r2 = tab + T_FM1T * ts + (size_t)i * ld;
+            Lse acc = lse_empty();
+            for (int k = 1 + lane; k < i; k += 64) lse_add(acc, r1[k] + r2[k]);
+            if (lane == 0 && j + 1 <= n - 1)  // FMo[i,j+1] + multi_unpaired (ipp:3806)
+                lse_add(acc, tab[T_FMO * ts + (size_t)i * ld + (j + 1)] + M->multi_unpaired);
+            fmo = lse_wave_finish(acc);
+        }
+        {   // row gather: FM2o[i,j'] + FMi[j,j'], j' = j+1..n-1      (ipp:4046-4064, first update, pulled)
+            const double* __restrict__ r1 = tab + T_FM2O * ts + (size_t)i * ld;
+            const double* __restrict__ r2 = tab + T_FM * ts + (size_t)j * ld;
+            Lse acc = lse_empty();
+            for (int k = j + 1 + lane; k <= n - 1; k += 64) lse_add(acc, r1[k] + r2[k]);
+            if (lane == 0) {
+                lse_add(acc, fmo);                                    // ipp:3809
+                if (i - 1 >= 1)                                       // FM1o[i-1,j] + multi_unpaired (ipp:3833)
+                    lse_add(acc, tab[T_FM1O * ts + (size_t)(i - 1) * ld + j] + M->multi_unpaired);
+            }
+            fm1o = lse_wave_finish(acc);
+        }
+    }
+
+    // ---- FCo[i,j]
+    double fco = kNeg;
+    const bool pairable = complementary(s_i, s_jp1);
+    if (pairable) {
+        const double bp = M->base_pair[s_i * 5 + s_jp1];
+        const double ja_in = junction_a(M, s_jp1, s_i, s_jp2, s_im1);  // ScoreJunctionA(j+1,i-1)
+        Lse acc = lse_empty();
+        if (lane == 0) {
+            // exterior loop (ipp:3768-3776): F5o[j+1] + ext_paired + BP + JA(j+1,i-1) + F5i[i-1]
+            lse_add(acc, f5o[j + 1] + M->external_paired + bp + ja_in + f5i[i - 1]);
+            // branch of a multiloop via FM1 (ipp:3828): FM1o[i-1,j+1] + JA + multi_paired + BP
+            if (i - 1 >= 1 && j + 1 <= n - 1 && d >= 0)
+                lse_add(acc, tab[T_FM1O * ts + (size_t)(i - 1) * ld + (j + 1)] + ja_in + M->multi_paired + bp);
+        }
+        // enclosing single-branch loops (ipp:4004-4024 pulled): source (i',j') = (i-1-l1, j+1+l2)
+        const double dec = bp + junction_b(M, s_jp1, s_i, s_jp2, s_im1);  // BP(p+1,q) + JB(q,p)
+        const int room = (i - 2) + (n - 2 - j);  // max l1 + max l2
+        if (room >= 0) {
+            const int tmax = room < kMaxSingle ? room : kMaxSingle;
+            const int cnt = (tmax + 1) * (tmax + 2) / 2;
+            const double* __restrict__ fcox = tab + T_FCOX * ts;
+            for (int c = lane; c < cnt; c += 64) {
+                const int len = M->mc_combo_len[c];
+                const int l1 = len & 0xff, l2 = len >> 8;
+                const int ii = i - 1 - l1, jj = j + 1 + l2;
+                if (ii < 1 || jj > n - 1) continue;
+                double x;
+                if (c == 0) {  // stacked on (i-1,j+1): FCo + ScoreBasePair(i,j+1) + ScoreHelixStacking(i-1,j+2)
+                    x = tab[T_FCO * ts + (size_t)ii * ld + jj] + bp + hs4(M, s_im1, s_jp2, s_i, s_jp1);
+                } else {
+                    x = fcox[(size_t)ii * ld + jj] + M->mc_combo_score[c] + dec;
+                    if (c < 5) x += single_nucs(M, l1, l2, s[ii + 1], s[jj]);
+                }
+                lse_add(acc, x);
+            }
+        }
+        fco = lse_wave_finish(acc);
+    }
+
+    // ---- FM2o[i,j] = FMo[i,j] (+) FCo[i,j] + ScoreJunctionA(i,j) + a + c   (ipp:3803, 4027)
+    const double viafc = pairable ? fco + junction_a(M, s_i, s_jp1, s_ip1, s_j) + M->multi_paired + M->multi_base : kNeg;
+    const double fm2o = lse2(fmo, viafc);
+
+    if (lane == 0) {
+        const size_t ij = (size_t)i * ld + j, ji = (size_t)j * ld + i;
+        tab[T_FCO * ts + ij] = fco;
+        tab[T_FCOX * ts + ij] = pairable ? fco + junction_b(M, s_i, s_jp1, s_ip1, s_j) : kNeg;
+        tab[T_FMO * ts + ij] = fmo;
+        tab[T_FM1O * ts + ij] = fm1o;
+        tab[T_FM2O * ts + ij] = fm2o;
+        tab[T_FM2OT * ts + ji] = fm2o;
+        // posterior of pair (i, j+1): exp(FCo + FCi - Z), clipped to [0,1] (ipp:4689-4827)
+        const double Z = f5i[n];
+        const double e = fco + tab[T_FC * ts + ij] - Z;
+        double p = e > kNeg / 2 ? exp(e) : 0.0;
+        p = p > 1.0 ? 1.0 : p;
+        B.bp[(size_t)sq * B.tri_stride + tri_offset(n, i) + (j + 1)] = pairable ? p : 0.0;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// width-1 accessibility, /root/reference/src/ractip.cpp:213-222:
+//   up[i] = max(0, 1 - sum_{j<i} bp(j,i) - sum_{j>i} bp(i,j)),  letters 1-based
+// one wavefront per letter.
+__global__ __launch_bounds__(256) void mc_unpaired(McBatch B)
+{
+    const int sq = blockIdx.y;
+    const int n = B.n[sq];
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (wave >= n) return;
+    const int a = wave + 1;
+    const double* __restrict__ bp = B.bp + (size_t)sq * B.tri_stride;
+    double acc = 0.0;
+    for (int b = 1 + lane; b <= n; b += 64) {
+        if (b == a) continue;
+        const int lo = b < a ? b : a, hi = b < a ? a : b;
+        acc += bp[tri_offset(n, lo) + hi];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) B.up[(size_t)sq * B.ld + wave] = fmax(0.0, 1.0 - acc);
+}
+
+}  // namespace rh

@@ -1,0 +1,461 @@
+// rh_api.hip -- context, batch management and the C ABI of include/ractip_hot.h.
+//
+// Host side of the drop-in boundary.  One rh_ctx owns one
+// GPU's streams, the score model in HBM and the DP tables of the current batch;
+// tables are kept and reused across batches of equal or smaller shape (the z-score
+// loop, /root/reference/src/ractip.cpp:1638-1657, shuffles preserve lengths).
+#include <hip/hip_runtime.h>
+
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ractip_hot.h"
+#include "batch.h"
+#include "score_model.h"
+
+namespace rh {
+__global__ void mc_init(McBatch B);
+__global__ void mc_inside_diag(McBatch B, const ScoreModel* __restrict__ M, int d);
+__global__ void mc_outside_diag(McBatch B, const ScoreModel* __restrict__ M, int d);
+__global__ void mc_unpaired(McBatch B);
+__global__ void dx_sweep_diag(DxBatch B, const ScoreModel* __restrict__ M, int t);
+__global__ void dx_logz(DxBatch B, const ScoreModel* __restrict__ M);
+__global__ void dx_posterior(DxBatch B);
+}  // namespace rh
+
+using namespace rh;
+
+static thread_local std::string g_create_error;
+
+struct rh_ctx {
+    int device = 0;
+    int model = 0;
+    std::string err;
+    hipStream_t s_mc = nullptr, s_dx = nullptr;
+    hipEvent_t ev[6] = {};  // mc: start, after inside, after outside ; dx: start, end ; all: end
+    ScoreModel* d_model = nullptr;
+
+    // current batch (host mirror)
+    int np = 0, ns = 0;
+    bool has_mc = false, has_dx = false, computed = false;
+    std::vector<int> n;  // [ns]
+    McBatch mc = {};
+    DxBatch dx = {};
+    // owned device buffers + capacities (bytes)
+    void* d_seq = nullptr;   size_t cap_seq = 0;
+    void* d_n = nullptr;     size_t cap_n = 0;
+    void* d_mctab = nullptr; size_t cap_mctab = 0;
+    void* d_f5 = nullptr;    size_t cap_f5 = 0;
+    void* d_bp = nullptr;    size_t cap_bp = 0;
+    void* d_up = nullptr;    size_t cap_up = 0;
+    void* d_dxtab = nullptr; size_t cap_dxtab = 0;
+    void* d_hp = nullptr;    size_t cap_hp = 0;
+    void* d_logz = nullptr;  size_t cap_logz = 0;
+    double ms[4] = {0, 0, 0, 0};
+    int n_launch[3] = {0, 0, 0};
+};
+
+namespace {
+
+int fail(rh_ctx* c, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(c, call)                                                                         \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail(c, e_ == hipErrorOutOfMemory ? RH_ERR_OOM : RH_ERR_HIP, "%s failed: %s", \
+                        #call, hipGetErrorString(e_));                                           \
+    } while (0)
+
+// grow-only device buffer
+int ensure(rh_ctx* c, void** p, size_t* cap, size_t bytes, bool zero)
+{
+    if (bytes <= *cap && *p) return RH_OK;
+    if (*p) { HIP_TRY(c, hipFree(*p)); *p = nullptr; *cap = 0; }
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(c, hipMemGetInfo(&free_b, &total_b));
+    if (bytes > free_b) return fail(c, RH_ERR_OOM, "batch needs %zu MiB of HBM, %zu MiB free", bytes >> 20, free_b >> 20);
+    HIP_TRY(c, hipMalloc(p, bytes));
+    *cap = bytes;
+    if (zero) HIP_TRY(c, hipMemset(*p, 0, bytes));
+    return RH_OK;
+}
+
+uint8_t nuc_code(char ch)
+{  // InferenceEngine.ipp:379-384: case-insensitive ACGU, anything else (incl. T, N) is code 4
+    switch (ch) {
+        case 'A': case 'a': return 0;
+        case 'C': case 'c': return 1;
+        case 'G': case 'g': return 2;
+        case 'U': case 'u': return 3;
+        default: return 4;
+    }
+}
+
+std::string default_param_path()
+{
+    Dl_info info;
+    if (dladdr((void*)&default_param_path, &info) && info.dli_fname) {
+        std::string p(info.dli_fname);
+        size_t k = p.find_last_of('/');
+        p = (k == std::string::npos) ? std::string(".") : p.substr(0, k);
+        return p + "/data/contrafold_complementary.params";
+    }
+    return "ractip_amd/data/contrafold_complementary.params";
+}
+
+inline size_t tri_size(int n) { return (size_t)(n + 1) * (n + 2) / 2; }
+inline size_t tri_offset(int n, int i) { return (size_t)i * (size_t)(2 * (n + 1) - i - 1) / 2; }
+
+// Stage `ns` sequences; pairs are (2p, 2p+1) when with_dx.  Allocates what is needed.
+int stage(rh_ctx* c, int ns, const char* const* seqs, const int* lens, bool with_mc, bool with_dx)
+{
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (ns <= 0) return fail(c, RH_ERR_ARG, "empty batch");
+    int nmax = 0, n1max = 0, n2max = 0;
+    for (int k = 0; k < ns; k++) {
+        if (lens[k] < 1) return fail(c, RH_ERR_ARG, "sequence %d has length %d (must be >= 1)", k, lens[k]);
+        if (!seqs[k]) return fail(c, RH_ERR_ARG, "sequence %d is NULL", k);
+        nmax = std::max(nmax, lens[k]);
+        if (with_dx) { if (k & 1) n2max = std::max(n2max, lens[k]); else n1max = std::max(n1max, lens[k]); }
+    }
+    if (with_dx && (ns & 1)) return fail(c, RH_ERR_ARG, "duplex batch needs an even number of sequences");
+    c->ns = ns; c->np = with_dx ? ns / 2 : 0;
+    c->has_mc = with_mc; c->has_dx = with_dx; c->computed = false;
+    c->n.assign(lens, lens + ns);
+
+    const int lds = (nmax + 3 + 15) & ~15;  // codes 0..n+2 readable
+    std::vector<uint8_t> codes((size_t)ns * lds, 4);
+    for (int k = 0; k < ns; k++)
+        for (int i = 0; i < lens[k]; i++) codes[(size_t)k * lds + 1 + i] = nuc_code(seqs[k][i]);
+    int rc;
+    if ((rc = ensure(c, &c->d_seq, &c->cap_seq, codes.size(), false))) return rc;
+    if ((rc = ensure(c, &c->d_n, &c->cap_n, sizeof(int) * ns, false))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->d_seq, codes.data(), codes.size(), hipMemcpyHostToDevice, c->s_mc));
+    HIP_TRY(c, hipMemcpyAsync(c->d_n, lens, sizeof(int) * ns, hipMemcpyHostToDevice, c->s_mc));
+    HIP_TRY(c, hipStreamSynchronize(c->s_mc));  // host staging buffers die with this scope
+
+    if (with_mc) {
+        McBatch& B = c->mc;
+        B.ns = ns; B.nmax = nmax; B.lds = lds;
+        B.ld = (nmax + 2 + 1) & ~1;
+        B.tab_stride = (size_t)B.ld * B.ld;
+        B.seq_stride = B.tab_stride * T_COUNT;
+        B.tri_stride = (tri_size(nmax) + 1) & ~(size_t)1;
+        if ((rc = ensure(c, &c->d_mctab, &c->cap_mctab, sizeof(double) * B.seq_stride * ns, false))) return rc;
+        if ((rc = ensure(c, &c->d_f5, &c->cap_f5, sizeof(double) * 2 * B.ld * ns, false))) return rc;
+        if ((rc = ensure(c, &c->d_up, &c->cap_up, sizeof(double) * B.ld * ns, false))) return rc;
+        // bp entries outside 1<=i<j<=n are never written by the sweep: keep them zero
+        const size_t bp_bytes = sizeof(double) * B.tri_stride * ns;
+        if ((rc = ensure(c, &c->d_bp, &c->cap_bp, bp_bytes, false))) return rc;
+        HIP_TRY(c, hipMemsetAsync(c->d_bp, 0, bp_bytes, c->s_mc));
+        B.seq = (const uint8_t*)c->d_seq; B.n = (const int*)c->d_n;
+        B.tab = (double*)c->d_mctab;
+        B.f5i = (double*)c->d_f5; B.f5o = (double*)c->d_f5 + (size_t)B.ld * ns;
+        B.bp = (double*)c->d_bp; B.up = (double*)c->d_up;
+    }
+    if (with_dx) {
+        DxBatch& D = c->dx;
+        D.np = ns / 2; D.n1max = n1max; D.n2max = n2max; D.lds = lds;
+        D.ldd = (n2max + 2 + 1) & ~1;
+        D.tab_stride = (size_t)(n1max + 2) * D.ldd;
+        D.pair_stride = D.tab_stride * D_COUNT;
+        if ((rc = ensure(c, &c->d_dxtab, &c->cap_dxtab, sizeof(double) * D.pair_stride * D.np, false))) return rc;
+        if ((rc = ensure(c, &c->d_logz, &c->cap_logz, sizeof(double) * D.np, false))) return rc;
+        const size_t hp_bytes = sizeof(double) * D.tab_stride * D.np;
+        if ((rc = ensure(c, &c->d_hp, &c->cap_hp, hp_bytes, false))) return rc;
+        HIP_TRY(c, hipMemsetAsync(c->d_hp, 0, hp_bytes, c->s_dx));  // row 0 / column 0 stay zero
+        D.seq = (const uint8_t*)c->d_seq; D.n = (const int*)c->d_n;
+        D.tab = (double*)c->d_dxtab; D.hp = (double*)c->d_hp; D.logz = (double*)c->d_logz;
+    }
+    return RH_OK;
+}
+
+int compute(rh_ctx* c)
+{
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->n_launch[0] = c->n_launch[1] = c->n_launch[2] = 0;
+    HIP_TRY(c, hipEventRecord(c->ev[0], c->s_mc));
+    if (c->has_mc) {
+        const McBatch& B = c->mc;
+        hipLaunchKernelGGL(mc_init, dim3((B.ns + 63) / 64), dim3(64), 0, c->s_mc, B);
+        for (int d = 0; d <= B.nmax - 1; d++) {
+            const int waves = std::max(B.nmax - 1 - d, 0) + 1;
+            hipLaunchKernelGGL(mc_inside_diag, dim3((waves + 3) / 4, B.ns), dim3(256), 0, c->s_mc, B, c->d_model, d);
+            c->n_launch[0]++;
+        }
+    }
+    HIP_TRY(c, hipEventRecord(c->ev[1], c->s_mc));
+    if (c->has_mc) {
+        const McBatch& B = c->mc;
+        for (int d = B.nmax - 2; d >= 0; d--) {
+            const int waves = (B.nmax - 1 - d) + 1;
+            hipLaunchKernelGGL(mc_outside_diag, dim3((waves + 3) / 4, B.ns), dim3(256), 0, c->s_mc, B, c->d_model, d);
+            c->n_launch[1]++;
+        }
+        hipLaunchKernelGGL(mc_unpaired, dim3((B.nmax + 3) / 4, B.ns), dim3(256), 0, c->s_mc, B);
+    }
+    HIP_TRY(c, hipEventRecord(c->ev[2], c->s_mc));
+    HIP_TRY(c, hipEventRecord(c->ev[3], c->s_dx));
+    if (c->has_dx) {
+        const DxBatch& D = c->dx;
+        const int smax = D.n1max + D.n2max;
+        const int steps = smax / 2;
+        const int waves = 2 * std::min(D.n1max, D.n2max);
+        for (int t = 0; t < steps; t++) {
+            hipLaunchKernelGGL(dx_sweep_diag, dim3((waves + 3) / 4, D.np, 2), dim3(256), 0, c->s_dx, D, c->d_model, t);
+            c->n_launch[2]++;
+        }
+        hipLaunchKernelGGL(dx_logz, dim3(D.np), dim3(1024), 0, c->s_dx, D, c->d_model);
+        const int cells = D.n1max * D.n2max;
+        hipLaunchKernelGGL(dx_posterior, dim3((cells + 255) / 256, D.np), dim3(256), 0, c->s_dx, D);
+    }
+    HIP_TRY(c, hipEventRecord(c->ev[4], c->s_dx));
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->s_mc));
+    HIP_TRY(c, hipStreamSynchronize(c->s_dx));
+    float t01 = 0, t12 = 0, t34 = 0, t02 = 0;
+    HIP_TRY(c, hipEventElapsedTime(&t01, c->ev[0], c->ev[1]));
+    HIP_TRY(c, hipEventElapsedTime(&t12, c->ev[1], c->ev[2]));
+    HIP_TRY(c, hipEventElapsedTime(&t02, c->ev[0], c->ev[2]));
+    HIP_TRY(c, hipEventElapsedTime(&t34, c->ev[3], c->ev[4]));
+    c->ms[0] = t01; c->ms[1] = t12; c->ms[2] = t34; c->ms[3] = std::max(t02, t34);
+    c->computed = true;
+    return RH_OK;
+}
+
+// copy one sequence's posterior out of the (nmax-strided) device buffer
+int fetch_bp(rh_ctx* c, int sq, double* out)
+{
+    const int n = c->n[sq];
+    HIP_TRY(c, hipMemcpy(out, (const double*)c->d_bp + (size_t)sq * c->mc.tri_stride, sizeof(double) * tri_size(n),
+                         hipMemcpyDeviceToHost));
+    return RH_OK;
+}
+int fetch_up(rh_ctx* c, int sq, double* out)
+{
+    HIP_TRY(c, hipMemcpy(out, (const double*)c->d_up + (size_t)sq * c->mc.ld, sizeof(double) * c->n[sq], hipMemcpyDeviceToHost));
+    return RH_OK;
+}
+int fetch_logz(rh_ctx* c, int sq, double* out)
+{
+    HIP_TRY(c, hipMemcpy(out, c->mc.f5i + (size_t)sq * c->mc.ld + c->n[sq], sizeof(double), hipMemcpyDeviceToHost));
+    return RH_OK;
+}
+int fetch_hp(rh_ctx* c, int p, double* out, double* logz)
+{
+    const int n1 = c->n[2 * p], n2 = c->n[2 * p + 1];
+    if (out)
+        HIP_TRY(c, hipMemcpy2D(out, sizeof(double) * (n2 + 1), (const double*)c->d_hp + (size_t)p * c->dx.tab_stride,
+                               sizeof(double) * c->dx.ldd, sizeof(double) * (n2 + 1), n1 + 1, hipMemcpyDeviceToHost));
+    if (logz) HIP_TRY(c, hipMemcpy(logz, (const double*)c->d_logz + p, sizeof(double), hipMemcpyDeviceToHost));
+    return RH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+rh_ctx* rh_create(int device, int model, const char* param_file)
+{
+    if (model != RH_MODEL_CONTRAFOLD) {
+        fail(nullptr, RH_ERR_UNSUPPORTED, "model %d is not built yet (only RH_MODEL_CONTRAFOLD)", model);
+        return nullptr;
+    }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        fail(nullptr, RH_ERR_HIP, "no HIP device available (%s): this library has no CPU fallback",
+             e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+        return nullptr;
+    }
+    if (device < 0 || device >= ndev) {
+        fail(nullptr, RH_ERR_ARG, "device %d out of range (have %d)", device, ndev);
+        return nullptr;
+    }
+    ScoreModel host_model;
+    char err[256];
+    const std::string path = param_file ? std::string(param_file) : default_param_path();
+    if (!load_score_model(path.c_str(), &host_model, err, sizeof err)) {
+        fail(nullptr, RH_ERR_PARAM, "%s", err);
+        return nullptr;
+    }
+    rh_ctx* c = new rh_ctx;
+    c->device = device; c->model = model;
+    bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&c->s_mc, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&c->s_dx, hipStreamNonBlocking) == hipSuccess &&
+              hipMalloc((void**)&c->d_model, sizeof(ScoreModel)) == hipSuccess &&
+              hipMemcpy(c->d_model, &host_model, sizeof(ScoreModel), hipMemcpyHostToDevice) == hipSuccess;
+    for (int k = 0; ok && k < 6; k++) ok = hipEventCreate(&c->ev[k]) == hipSuccess;
+    if (!ok) {
+        fail(nullptr, RH_ERR_HIP, "context setup failed: %s", hipGetErrorString(hipGetLastError()));
+        rh_destroy(c);
+        return nullptr;
+    }
+    return c;
+}
+
+void rh_destroy(rh_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    void* bufs[] = {c->d_seq, c->d_n, c->d_mctab, c->d_f5, c->d_bp, c->d_up, c->d_dxtab, c->d_hp, c->d_logz, c->d_model};
+    for (void* b : bufs) if (b) (void)hipFree(b);
+    for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    if (c->s_mc) (void)hipStreamDestroy(c->s_mc);
+    if (c->s_dx) (void)hipStreamDestroy(c->s_dx);
+    delete c;
+}
+
+const char* rh_last_error(const rh_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int rh_bpp(rh_ctx* c, const char* seq, int n, const char* constraint, double* bp_tri, double* logZ)
+{
+    if (!c) return RH_ERR_ARG;
+    if (constraint) return fail(c, RH_ERR_UNSUPPORTED, "structure constraints are not supported yet");
+    if (!seq || n < 0) return fail(c, RH_ERR_ARG, "bad sequence");
+    if (n == 0) { if (bp_tri) bp_tri[0] = 0.0; if (logZ) *logZ = 0.0; return RH_OK; }
+    int rc;
+    if ((rc = stage(c, 1, &seq, &n, true, false))) return rc;
+    if ((rc = compute(c))) return rc;
+    if (bp_tri && (rc = fetch_bp(c, 0, bp_tri))) return rc;
+    if (logZ && (rc = fetch_logz(c, 0, logZ))) return rc;
+    return RH_OK;
+}
+
+int rh_unpaired(rh_ctx* c, const char* seq, int n, int max_w, double* up)
+{
+    if (!c) return RH_ERR_ARG;
+    if (max_w != 1) return fail(c, RH_ERR_UNSUPPORTED, "max_w=%d: only width-1 accessibility (CONTRAfold path) is built", max_w);
+    if (!seq || n < 0 || !up) return fail(c, RH_ERR_ARG, "bad argument");
+    if (n == 0) return RH_OK;
+    int rc;
+    if ((rc = stage(c, 1, &seq, &n, true, false))) return rc;
+    if ((rc = compute(c))) return rc;
+    return fetch_up(c, 0, up);
+}
+
+int rh_duplex(rh_ctx* c, const char* s1, int n1, const char* s2, int n2, double* hp, double* logZ)
+{
+    if (!c) return RH_ERR_ARG;
+    if (!s1 || !s2 || n1 < 1 || n2 < 1) return fail(c, RH_ERR_ARG, "bad sequence");
+    const char* seqs[2] = {s1, s2};
+    const int lens[2] = {n1, n2};
+    int rc;
+    if ((rc = stage(c, 2, seqs, lens, false, true))) return rc;
+    if ((rc = compute(c))) return rc;
+    return fetch_hp(c, 0, hp, logZ);
+}
+
+int rh_batch_upload(rh_ctx* c, int npairs, const char* const* s1, const int* n1, const char* const* s2, const int* n2)
+{
+    if (!c) return RH_ERR_ARG;
+    if (npairs < 1 || !s1 || !s2 || !n1 || !n2) return fail(c, RH_ERR_ARG, "bad batch");
+    std::vector<const char*> seqs(2 * (size_t)npairs);
+    std::vector<int> lens(2 * (size_t)npairs);
+    for (int p = 0; p < npairs; p++) {
+        seqs[2 * p] = s1[p]; seqs[2 * p + 1] = s2[p];
+        lens[2 * p] = n1[p]; lens[2 * p + 1] = n2[p];
+    }
+    return stage(c, 2 * npairs, seqs.data(), lens.data(), true, true);
+}
+
+int rh_batch_compute(rh_ctx* c)
+{
+    if (!c) return RH_ERR_ARG;
+    if (c->ns == 0) return fail(c, RH_ERR_ARG, "no batch uploaded");
+    return compute(c);
+}
+
+int rh_batch_results(rh_ctx* c, int p, double* bp1, double* bp2, double* up1, double* up2, double* hp, double* logZ3)
+{
+    if (!c) return RH_ERR_ARG;
+    if (!c->computed || !c->has_mc || !c->has_dx) return fail(c, RH_ERR_ARG, "no computed pair batch");
+    if (p < 0 || p >= c->np) return fail(c, RH_ERR_ARG, "pair %d out of range", p);
+    int rc;
+    if (bp1 && (rc = fetch_bp(c, 2 * p, bp1))) return rc;
+    if (bp2 && (rc = fetch_bp(c, 2 * p + 1, bp2))) return rc;
+    if (up1 && (rc = fetch_up(c, 2 * p, up1))) return rc;
+    if (up2 && (rc = fetch_up(c, 2 * p + 1, up2))) return rc;
+    if ((hp || logZ3) && (rc = fetch_hp(c, p, hp, logZ3 ? logZ3 + 2 : nullptr))) return rc;
+    if (logZ3) {
+        if ((rc = fetch_logz(c, 2 * p, logZ3))) return rc;
+        if ((rc = fetch_logz(c, 2 * p + 1, logZ3 + 1))) return rc;
+    }
+    return RH_OK;
+}
+
+int rh_batch_candidates(rh_ctx* c, int p, int which, float threshold, rh_cand* out, int cap)
+{
+    if (!c) return RH_ERR_ARG;
+    if (!c->computed) return fail(c, RH_ERR_ARG, "no computed batch");
+    if (p < 0 || p >= c->np || which < 0 || which > 4) return fail(c, RH_ERR_ARG, "bad pair/which");
+    // dense fetch + host scan in the reference's order; the on-device compaction replaces this next
+    int found = 0, rc;
+    if (which <= 1) {
+        const int sq = 2 * p + which, n = c->n[sq];
+        std::vector<double> bp(tri_size(n));
+        if ((rc = fetch_bp(c, sq, bp.data()))) return rc;
+        for (int i = 1; i <= n; i++)          // src/ractip.cpp:557-568: j outer? no: i<j row-major over the triangle
+            for (int j = i + 1; j <= n; j++) {
+                const float pf = (float)bp[tri_offset(n, i) + j];
+                if (pf > threshold) { if (out && found < cap) out[found] = rh_cand{i, j, pf}; found++; }
+            }
+    } else if (which == 2) {
+        const int n1 = c->n[2 * p], n2 = c->n[2 * p + 1];
+        std::vector<double> hp((size_t)(n1 + 1) * (n2 + 1));
+        if ((rc = fetch_hp(c, p, hp.data(), nullptr))) return rc;
+        for (int i = 1; i <= n1; i++)
+            for (int j = 1; j <= n2; j++) {
+                const float pf = (float)hp[(size_t)i * (n2 + 1) + j];
+                if (pf > threshold) { if (out && found < cap) out[found] = rh_cand{i, j, pf}; found++; }
+            }
+    } else {
+        const int sq = 2 * p + (which - 3), n = c->n[sq];
+        std::vector<double> up(n);
+        if ((rc = fetch_up(c, sq, up.data()))) return rc;
+        for (int i = 0; i < n; i++) {
+            const float pf = (float)up[i];
+            if (pf > threshold) { if (out && found < cap) out[found] = rh_cand{i, 0, pf}; found++; }
+        }
+    }
+    return found;
+}
+
+int rh_batch_timings(rh_ctx* c, double ms[4], int n_launch[3])
+{
+    if (!c) return RH_ERR_ARG;
+    if (!c->computed) return fail(c, RH_ERR_ARG, "no computed batch");
+    if (ms) for (int k = 0; k < 4; k++) ms[k] = c->ms[k];
+    if (n_launch) for (int k = 0; k < 3; k++) n_launch[k] = c->n_launch[k];
+    return RH_OK;
+}
+
+int rh_batch_device_views(rh_ctx* c, const double** bp, size_t* tri_stride, const double** hp, size_t* hp_stride, int* hp_ld)
+{
+    if (!c) return RH_ERR_ARG;
+    if (!c->computed) return fail(c, RH_ERR_ARG, "no computed batch");
+    if (bp) *bp = (const double*)c->d_bp;
+    if (tri_stride) *tri_stride = c->mc.tri_stride;
+    if (hp) *hp = (const double*)c->d_hp;
+    if (hp_stride) *hp_stride = c->dx.tab_stride;
+    if (hp_ld) *hp_ld = c->dx.ldd;
+    return RH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,153 @@
+"""ctypes binding of include/ractip_hot.h (the C ABI of libractip_hot.so).
+
+Thin by design: every method is one C call.  There is NO fallback: if the HIP
+library is missing or no GPU is present, creation raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "libractip_hot.so")
+
+RH_MODEL_CONTRAFOLD = 0
+RH_MODEL_VIENNA_BL = 1
+
+EXPORTS = [
+    "rh_create", "rh_destroy", "rh_last_error", "rh_bpp", "rh_unpaired", "rh_duplex",
+    "rh_batch_upload", "rh_batch_compute", "rh_batch_results", "rh_batch_candidates",
+    "rh_batch_timings", "rh_batch_device_views",
+]
+
+
+class RhError(RuntimeError):
+    pass
+
+
+class Cand(ctypes.Structure):
+    _fields_ = [("i", ctypes.c_int), ("j", ctypes.c_int), ("p", ctypes.c_float)]
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen libractip_hot.so and declare the prototypes (no GPU needed for this)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RhError("%s is missing: run `python -m ractip_amd.build` (or __graft_entry__.build()) first; "
+                      "there is no CPU fallback" % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    vp, cp, ci, dp = ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double)
+    L.rh_create.restype = vp
+    L.rh_create.argtypes = [ci, ci, cp]
+    L.rh_destroy.restype = None
+    L.rh_destroy.argtypes = [vp]
+    L.rh_last_error.restype = cp
+    L.rh_last_error.argtypes = [vp]
+    L.rh_bpp.argtypes = [vp, cp, ci, cp, vp, vp]
+    L.rh_unpaired.argtypes = [vp, cp, ci, ci, vp]
+    L.rh_duplex.argtypes = [vp, cp, ci, cp, ci, vp, vp]
+    L.rh_batch_upload.argtypes = [vp, ci, ctypes.POINTER(cp), ctypes.POINTER(ci), ctypes.POINTER(cp), ctypes.POINTER(ci)]
+    L.rh_batch_compute.argtypes = [vp]
+    L.rh_batch_results.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp]
+    L.rh_batch_candidates.argtypes = [vp, ci, ci, ctypes.c_float, vp, ci]
+    L.rh_batch_timings.argtypes = [vp, vp, vp]
+    L.rh_batch_device_views.argtypes = [vp, vp, vp, vp, vp, vp]
+    for f in ("rh_bpp", "rh_unpaired", "rh_duplex", "rh_batch_upload", "rh_batch_compute", "rh_batch_results",
+              "rh_batch_candidates", "rh_batch_timings", "rh_batch_device_views"):
+        getattr(L, f).restype = ci
+    _lib = L
+    return L
+
+
+def tri_size(n):
+    return (n + 1) * (n + 2) // 2
+
+
+def tri_offset(n, i):
+    return i * (2 * (n + 1) - i - 1) // 2
+
+
+class Context:
+    """One rh_ctx: one GPU, one host thread."""
+
+    def __init__(self, device=0, model=RH_MODEL_CONTRAFOLD, param_file=None):
+        self.L = load_library()
+        self.h = self.L.rh_create(device, model, param_file.encode() if param_file else None)
+        if not self.h:
+            raise RhError("rh_create failed: %s" % self.L.rh_last_error(None).decode())
+        self._pairs = []
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.rh_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc < 0:
+            raise RhError("ractip_hot error %d: %s" % (rc, self.L.rh_last_error(self.h).decode()))
+        return rc
+
+    # ---- single-problem calls
+    def bpp(self, seq):
+        n = len(seq)
+        bp = np.zeros(tri_size(n))
+        z = ctypes.c_double()
+        self._check(self.L.rh_bpp(self.h, seq.encode(), n, None, bp.ctypes.data, ctypes.addressof(z)))
+        return bp, z.value
+
+    def unpaired(self, seq, max_w=1):
+        n = len(seq)
+        up = np.zeros(n * max_w)
+        self._check(self.L.rh_unpaired(self.h, seq.encode(), n, max_w, up.ctypes.data))
+        return up.reshape(n, max_w)
+
+    def duplex(self, s1, s2):
+        hp = np.zeros((len(s1) + 1, len(s2) + 1))
+        z = ctypes.c_double()
+        self._check(self.L.rh_duplex(self.h, s1.encode(), len(s1), s2.encode(), len(s2), hp.ctypes.data, ctypes.addressof(z)))
+        return hp, z.value
+
+    # ---- batched calls
+    def batch_upload(self, pairs):
+        np_ = len(pairs)
+        a = (ctypes.c_char_p * np_)(*[p[0].encode() for p in pairs])
+        b = (ctypes.c_char_p * np_)(*[p[1].encode() for p in pairs])
+        na = (ctypes.c_int * np_)(*[len(p[0]) for p in pairs])
+        nb = (ctypes.c_int * np_)(*[len(p[1]) for p in pairs])
+        self._check(self.L.rh_batch_upload(self.h, np_, a, na, b, nb))
+        self._pairs = [(len(p[0]), len(p[1])) for p in pairs]
+
+    def batch_compute(self):
+        self._check(self.L.rh_batch_compute(self.h))
+
+    def batch_results(self, p):
+        n1, n2 = self._pairs[p]
+        bp1, bp2 = np.zeros(tri_size(n1)), np.zeros(tri_size(n2))
+        up1, up2 = np.zeros(n1), np.zeros(n2)
+        hp = np.zeros((n1 + 1, n2 + 1))
+        z3 = np.zeros(3)
+        self._check(self.L.rh_batch_results(self.h, p, bp1.ctypes.data, bp2.ctypes.data, up1.ctypes.data,
+                                            up2.ctypes.data, hp.ctypes.data, z3.ctypes.data))
+        return dict(bp1=bp1, bp2=bp2, up1=up1, up2=up2, hp=hp, logZ=z3)
+
+    def batch_candidates(self, p, which, threshold, cap=1 << 20):
+        buf = (Cand * cap)()
+        k = self._check(self.L.rh_batch_candidates(self.h, p, which, ctypes.c_float(threshold), buf, cap))
+        return [(buf[t].i, buf[t].j, buf[t].p) for t in range(min(k, cap))]
+
+    def batch_timings(self):
+        ms = (ctypes.c_double * 4)()
+        nl = (ctypes.c_int * 3)()
+        self._check(self.L.rh_batch_timings(self.h, ms, nl))
+        return list(ms), list(nl)

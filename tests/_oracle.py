@@ -1,0 +1,133 @@
+"""ctypes access to the TEST-ONLY oracle (oracle/libcf_oracle.so) and, when it has
+been built in this tree, the reference engines (oracle/_ref/libref_contrafold.so)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+PARAMS = os.path.join(ROOT, "ractip_amd", "data", "contrafold_complementary.params")
+NEG = -2e20
+
+
+def tri_size(n):
+    return (n + 1) * (n + 2) // 2
+
+
+def tri_offset(n, i):
+    return i * (2 * (n + 1) - i - 1) // 2
+
+
+class Oracle:
+    def __init__(self):
+        so = os.path.join(ORACLE_DIR, "libcf_oracle.so")
+        src = os.path.join(ORACLE_DIR, "cf_oracle.c")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "oracle"])
+        L = ctypes.CDLL(so)
+        vp, cp, ci = ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int
+        L.cfo_load_params.restype = vp
+        L.cfo_load_params.argtypes = [cp]
+        L.cfo_inference.restype = ctypes.c_double
+        L.cfo_inference.argtypes = [vp, cp, ci, vp, vp, vp]
+        L.cfo_duplex.restype = None
+        L.cfo_duplex.argtypes = [vp, cp, ci, cp, ci, vp, vp, vp, vp]
+        L.cfo_up_float.restype = None
+        L.cfo_up_float.argtypes = [ci, vp, vp]
+        L.cfo_count_enable.argtypes = [ci]
+        L.cfo_count_loads.restype = ctypes.c_ulonglong
+        L.cfo_count_stores.restype = ctypes.c_ulonglong
+        self.L = L
+        self.m = L.cfo_load_params(PARAMS.encode())
+        assert self.m, "oracle could not load " + PARAMS
+
+    def inference(self, seq, tables=False):
+        n = len(seq)
+        T = tri_size(n)
+        post = np.zeros(T)
+        f5 = np.zeros(2 * (n + 1))
+        tabs = np.zeros(6 * T) if tables else None
+        z = self.L.cfo_inference(self.m, seq.encode(), n, post.ctypes.data,
+                                 tabs.ctypes.data if tables else None, f5.ctypes.data)
+        out = dict(logZ=z, post=post, f5=f5)
+        if tables:
+            out["tables"] = tabs
+        return out
+
+    def duplex(self, s1, s2):
+        S = (len(s1) + 1) * (len(s2) + 1)
+        post, ins, outs, z2 = np.zeros(S), np.zeros(S), np.zeros(S), np.zeros(2)
+        self.L.cfo_duplex(self.m, s1.encode(), len(s1), s2.encode(), len(s2), post.ctypes.data,
+                          ins.ctypes.data, outs.ctypes.data, z2.ctypes.data)
+        shape = (len(s1) + 1, len(s2) + 1)
+        return dict(logZ2=z2, post=post.reshape(shape), inside=ins.reshape(shape), outside=outs.reshape(shape))
+
+    def up_float(self, n, bp_float32):
+        up = np.zeros(n, dtype=np.float32)
+        bp = np.ascontiguousarray(bp_float32, dtype=np.float32)
+        self.L.cfo_up_float(n, bp.ctypes.data, up.ctypes.data)
+        return up
+
+    def count(self, fn, *args):
+        """Algorithmic table loads/stores of one oracle call."""
+        self.L.cfo_count_reset()
+        self.L.cfo_count_enable(1)
+        try:
+            fn(*args)
+        finally:
+            self.L.cfo_count_enable(0)
+        return self.L.cfo_count_loads(), self.L.cfo_count_stores()
+
+
+class Reference:
+    """The reference's own engines; only available where oracle/_ref was built."""
+
+    def __init__(self):
+        so = os.path.join(ORACLE_DIR, "_ref", "libref_contrafold.so")
+        if not os.path.exists(so):
+            raise FileNotFoundError(so)
+        L = ctypes.CDLL(so)
+        L.ref_inference.restype = ctypes.c_double
+        L.ref_inference.argtypes = [ctypes.c_char_p, ctypes.c_int] + [ctypes.c_void_p] * 3
+        L.ref_duplex.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int] + [ctypes.c_void_p] * 4
+        self.L = L
+
+    def inference(self, seq, use_float=False):
+        n = len(seq)
+        post = np.zeros(tri_size(n))
+        z = self.L.ref_inference(seq.encode(), int(use_float), post.ctypes.data, None, None)
+        return dict(logZ=z, post=post)
+
+    def duplex(self, s1, s2, use_float=False):
+        S = (len(s1) + 1) * (len(s2) + 1)
+        post, z2 = np.zeros(S), np.zeros(2)
+        self.L.ref_duplex(s1.encode(), s2.encode(), int(use_float), post.ctypes.data, None, None, z2.ctypes.data)
+        return dict(logZ2=z2, post=post.reshape(len(s1) + 1, len(s2) + 1))
+
+
+def assert_prob_close(got, ref, rel=1e-6, abs_floor=1e-12, what=""):
+    """rel. err <= 1e-6 where |ref| > 1e-12, else abs. err <= 1e-12."""
+    got = np.asarray(got, dtype=np.float64).ravel()
+    ref = np.asarray(ref, dtype=np.float64).ravel()
+    assert got.shape == ref.shape, what
+    big = np.abs(ref) > abs_floor
+    if big.any():
+        r = np.abs(got[big] - ref[big]) / np.abs(ref[big])
+        assert r.max() <= rel, "%s: max rel err %.3e at %d (got %r ref %r)" % (
+            what, r.max(), np.flatnonzero(big)[r.argmax()], got[big][r.argmax()], ref[big][r.argmax()])
+    if (~big).any():
+        a = np.abs(got[~big] - ref[~big])
+        assert a.max() <= abs_floor, "%s: max abs err %.3e below the floor" % (what, a.max())
+
+
+def assert_log_close(got, ref, tol=1e-9, what=""):
+    """log-space tables: same -inf pattern, finite entries within tol (absolute, log units)."""
+    got = np.asarray(got, dtype=np.float64).ravel()
+    ref = np.asarray(ref, dtype=np.float64).ravel()
+    gi, ri = got < NEG / 2, ref < NEG / 2
+    assert (gi == ri).all(), "%s: -inf pattern differs at %s" % (what, np.flatnonzero(gi != ri)[:8])
+    if (~ri).any():
+        d = np.abs(got[~ri] - ref[~ri])
+        assert d.max() <= tol, "%s: max |dlog| %.3e" % (what, d.max())

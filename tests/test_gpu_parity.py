@@ -1,0 +1,158 @@
+"""GPU suite (-m gpu): the HIP path, called through the C ABI, against
+  (1) the committed golden vectors from the reference's own engines,
+  (2) the CPU oracle on seeded random inputs,
+  (3) size-independent properties at BASELINE.json's full sizes.
+Tolerances (BASELINE.json north_star): bp/hp/up within 1e-6 relative (double);
+log-partition values within 1e-9 absolute (log units)."""
+import numpy as np
+import pytest
+
+from _oracle import NEG, assert_log_close, assert_prob_close, tri_offset, tri_size
+from ractip_amd.seqgen import random_pair, random_pairs
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-6
+
+
+def rnd(rng, n):
+    return "".join(rng.choice(list("ACGU"), n))
+
+
+def test_bpp_vs_golden_all_bundled_and_edge_sequences(ctx, golden):
+    for nm in golden["mc_names"]:
+        seq = str(golden["mc/%s/seq" % nm])
+        bp, z = ctx.bpp(seq)
+        assert abs(z - float(golden["mc/%s/logZ" % nm])) < 1e-9, nm
+        assert_prob_close(bp, golden["mc/%s/post" % nm], rel=REL, what="bp " + nm)
+
+
+def test_duplex_vs_golden(ctx, golden):
+    for key in golden["dx_names"]:
+        a, b = key.split("+")
+        s1, s2 = str(golden["mc/%s/seq" % a]), str(golden["mc/%s/seq" % b])
+        hp, z = ctx.duplex(s1, s2)
+        assert_log_close([z], golden["dx/%s/logZ2" % key][:1], tol=1e-9, what="logZ " + key)
+        assert_prob_close(hp, golden["dx/%s/post" % key], rel=REL, what="hp " + key)
+
+
+def test_config2_copa_copt_all_matrices(ctx, golden, oracle):
+    """BASELINE.json config 2: CopA vs CopT, bp/hp/up checked to 1e-6 vs the CPU path."""
+    s1, s2 = str(golden["mc/CopA/seq"]), str(golden["mc/CopT/seq"])
+    ctx.batch_upload([(s1, s2)])
+    ctx.batch_compute()
+    r = ctx.batch_results(0)
+    assert_prob_close(r["bp1"], golden["mc/CopA/post"], rel=REL, what="bp1")
+    assert_prob_close(r["bp2"], golden["mc/CopT/post"], rel=REL, what="bp2")
+    assert_prob_close(r["hp"], golden["dx/CopA+CopT/post"], rel=REL, what="hp")
+    for s, up, bp in ((s1, r["up1"], r["bp1"]), (s2, r["up2"], r["bp2"])):
+        ref = oracle.up_float(len(s), bp.astype(np.float32))  # ractip.cpp:213-222 in float
+        assert np.abs(up.astype(np.float32) - ref).max() < 2e-6
+    assert abs(r["logZ"][0] - float(golden["mc/CopA/logZ"])) < 1e-9
+    assert abs(r["logZ"][1] - float(golden["mc/CopT/logZ"])) < 1e-9
+    assert abs(r["logZ"][2] - golden["dx/CopA+CopT/logZ2"][0]) < 1e-9
+
+
+def test_n500_vs_golden(ctx, golden):
+    """BASELINE.json config 3 inputs (mt19937(12345) pair, n=500)."""
+    s1, s2 = random_pair(500)
+    assert s1 == str(golden["mc500/mt500a/seq"]) and s2 == str(golden["mc500/mt500b/seq"])
+    ctx.batch_upload([(s1, s2)])
+    ctx.batch_compute()
+    r = ctx.batch_results(0)
+    for tag, bp, z in (("mt500a", r["bp1"], r["logZ"][0]), ("mt500b", r["bp2"], r["logZ"][1])):
+        assert abs(z - float(golden["mc500/%s/logZ" % tag])) < 1e-8
+        assert abs(bp.sum() - float(golden["mc500/%s/post_sum" % tag])) < 1e-6
+        assert_prob_close(bp[golden["mc500/%s/idx" % tag]], golden["mc500/%s/val" % tag], rel=REL, what=tag)
+    assert abs(r["logZ"][2] - golden["dx500/logZ2"][0]) < 1e-8
+    hp = r["hp"].ravel()
+    assert abs(hp.sum() - float(golden["dx500/post_sum"])) < 1e-6
+    assert_prob_close(hp[golden["dx500/idx"]], golden["dx500/val"], rel=REL, what="hp n=500")
+
+
+def test_random_vs_oracle_ragged_batch(ctx, oracle):
+    """Seeded random pairs of unequal lengths in ONE batch (ragged), every matrix vs the oracle."""
+    rng = np.random.RandomState(4242)
+    lens = [(1, 1), (2, 5), (3, 3), (7, 4), (12, 33), (33, 12), (64, 65), (90, 31), (150, 97), (31, 200)]
+    pairs = [(rnd(rng, a), rnd(rng, b)) for a, b in lens]
+    ctx.batch_upload(pairs)
+    ctx.batch_compute()
+    for p, (s1, s2) in enumerate(pairs):
+        r = ctx.batch_results(p)
+        o1, o2, od = oracle.inference(s1), oracle.inference(s2), oracle.duplex(s1, s2)
+        what = "pair %d (%d,%d)" % (p, len(s1), len(s2))
+        assert abs(r["logZ"][0] - o1["logZ"]) < 1e-9 and abs(r["logZ"][1] - o2["logZ"]) < 1e-9, what
+        assert_log_close([r["logZ"][2]], [od["logZ2"][0]], tol=1e-9, what=what)
+        assert_prob_close(r["bp1"], o1["post"], rel=REL, what="bp1 " + what)
+        assert_prob_close(r["bp2"], o2["post"], rel=REL, what="bp2 " + what)
+        assert_prob_close(r["hp"], od["post"], rel=REL, what="hp " + what)
+
+
+def test_unknown_letters_and_unpairable_inputs(ctx, oracle):
+    for seq in ("AAAAAAAAAA", "GGGGTTTTNNNNCCCC", "acguACGUnnnnGGGAAACCC", "G", "GC"):
+        bp, z = ctx.bpp(seq)
+        o = oracle.inference(seq)
+        assert abs(z - o["logZ"]) < 1e-10
+        assert_prob_close(bp, o["post"], rel=REL, what=seq)
+    hp, z = ctx.duplex("AAAA", "AAAAAA")
+    assert z < NEG / 2 and hp.max() == 0.0
+
+
+def test_batch_composition_does_not_change_results(ctx):
+    """Results of a problem are bit-identical whether it runs alone or inside a ragged batch."""
+    rng = np.random.RandomState(99)
+    a, b = rnd(rng, 73), rnd(rng, 58)
+    bp_alone, z_alone = ctx.bpp(a)
+    hp_alone, zd_alone = ctx.duplex(a, b)
+    ctx.batch_upload([(rnd(rng, 120), rnd(rng, 40)), (a, b), (rnd(rng, 9), rnd(rng, 130))])
+    ctx.batch_compute()
+    r = ctx.batch_results(1)
+    assert np.array_equal(r["bp1"], bp_alone) and r["logZ"][0] == z_alone
+    assert np.array_equal(r["hp"], hp_alone) and r["logZ"][2] == zd_alone
+
+
+def test_properties_full_size(ctx):
+    """n=500 batch and one n=2000 pair (BASELINE.json configs 3 and 4): size-independent checks --
+    probabilities in [0,1], every letter pairs with total probability <= 1, up = 1 - row sums,
+    hp row/column sums <= 1, nothing lands on non-complementary letters."""
+    def check(s1, s2, r):
+        for s, bp, up in ((s1, r["bp1"], r["up1"]), (s2, r["bp2"], r["up2"])):
+            n = len(s)
+            assert np.isfinite(bp).all() and bp.min() >= 0.0 and bp.max() <= 1.0
+            P = np.zeros((n + 1, n + 1))
+            iu = np.triu_indices(n + 1, 0)
+            P[iu] = bp  # reference triangular layout == row-major upper triangle incl. diagonal
+            assert P[0].max() == 0.0 and np.diag(P).max() == 0.0
+            rows = (P + P.T).sum(axis=1)[1:]
+            assert rows.max() <= 1.0 + 1e-9
+            assert np.abs(up - np.maximum(0.0, 1.0 - rows)).max() < 1e-12
+            codes = np.array(["ACGU".index(c) for c in s])
+            ok = np.zeros((4, 4), bool)
+            for x, y in ((0, 3), (3, 0), (1, 2), (2, 1), (2, 3), (3, 2)):
+                ok[x, y] = True
+            bad = ~ok[codes[:, None], codes[None, :]]
+            assert P[1:, 1:][bad & (P[1:, 1:] > 0)].size == 0
+        hp = r["hp"]
+        assert np.isfinite(hp).all() and hp.min() >= 0 and hp.max() <= 1
+        assert hp[0].max() == 0 and hp[:, 0].max() == 0
+        assert hp.sum(axis=1).max() <= 1 + 1e-9 and hp.sum(axis=0).max() <= 1 + 1e-9
+
+    pairs = random_pairs(4, 500)
+    ctx.batch_upload(pairs)
+    ctx.batch_compute()
+    for p, (s1, s2) in enumerate(pairs):
+        check(s1, s2, ctx.batch_results(p))
+    s1, s2 = random_pair(2000)
+    ctx.batch_upload([(s1, s2)])
+    ctx.batch_compute()
+    r = ctx.batch_results(0)
+    check(s1, s2, r)
+    assert abs(r["logZ"][0] - 258.796119) < 1e-5  # SURVEY 8c known answer, InferenceEngine<double>, n=2000
+
+
+def test_errors_are_reported_not_swallowed(ctx):
+    import ractip_amd
+    with pytest.raises(ractip_amd.RhError):
+        ctx.unpaired("ACGU", max_w=5)
+    with pytest.raises(ractip_amd.RhError):
+        ctx.batch_upload([("ACGU", "")])
