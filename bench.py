@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""bench.py -- sequence-pairs/s of the RactIP probability-matrix hot path on MI355X.
+
+Metric (BASELINE.json): sequence-pairs/sec incl. bp+hp+ap DP at n=500, with the
+achieved algorithmic HBM GB/s against the roofline.  One "step" = one pass of the
+hot path (2x McCaskill inside/outside/posterior + up + duplex fw/bk/posterior)
+over one batch of synthetic pairs (mt19937(12345) stream),
+inputs already resident in HBM when the timed region starts.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--n 500] [--batch B]
+
+N > 1: one process per GPU (launched by torch.distributed.run); independent pairs
+are sharded across ranks (weak scaling, the z-score shard of ractip.cpp:1638-1657)
+and the per-pair scalars are gathered over RCCL, the path's only exchange step.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(pairs, budget_s=20.0):
+    """Time the CPU path on a bounded sample of the same workload (rank 0, N=1 only).
+
+    kind "reference": the reference's own InferenceEngine<double>/DuplexEngine<double>
+    (oracle/_ref, built from /root/reference in the build container); kind "port": our
+    CPU restatement (oracle/libcf_oracle.so).  Single-threaded, like the reference
+    (src/ractip.cpp:1494)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _oracle import Oracle, Reference
+    try:
+        eng, kind = Reference(), "reference"
+    except (FileNotFoundError, OSError):
+        eng, kind = Oracle(), "port"
+    done, t0 = 0, time.perf_counter()
+    for s1, s2 in pairs:
+        eng.inference(s1)
+        eng.inference(s2)
+        eng.duplex(s1, s2)
+        done += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "pairs/s", "cores": 1, "kind": kind,
+            "sample": "%d pair(s) of n=%d/%d, %.1f s, InferenceEngine/DuplexEngine double, 1 thread" % (
+                done, len(pairs[0][0]), len(pairs[0][1]), dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", type=int, default=500, help="sequence length (BASELINE config 3: 500; config 4: 2000)")
+    ap.add_argument("--batch", type=int, default=0, help="pairs per GPU per step (0 = auto)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import ractip_amd
+    from ractip_amd import balg
+    from ractip_amd.seqgen import random_pairs
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d bench.py --gpus %d ..."
+                         % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback to measure)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    n = args.n
+    batch = args.batch or (32 if n <= 600 else (8 if n <= 1200 else 2))
+    # every rank draws from ONE stream and keeps its own slice: distinct pairs per rank (weak scaling)
+    all_pairs = random_pairs(batch * world, n, seed=12345)
+    pairs = all_pairs[rank * batch:(rank + 1) * batch]
+
+    ctx = ractip_amd.Context(device=local_rank)
+    ctx.batch_upload(pairs)  # sequences -> HBM, tables allocated: outside the timed region
+
+    def step():
+        ctx.batch_compute()  # all DP kernels, blocks until the device is done
+        if dist is not None:  # z-score gather: 3 doubles per pair (ractip.cpp:1655-1663 needs 2 floats)
+            z = torch.from_numpy(ctx.batch_logz().ravel()).cuda()
+            out = [torch.empty_like(z) for _ in range(world)]
+            dist.all_gather(out, z)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ms_acc = np.zeros(4)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        ms, nl = ctx.batch_timings()
+        ms_acc += np.array(ms)
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        total_pairs = batch * world * args.steps
+        # algorithmic bytes of rank 0's batch, split by kernel (ractip_amd/balg.py)
+        b = {"mc_inside": 0, "mc_outside": 0, "duplex": 0, "total": 0}
+        for s1, s2 in pairs:
+            pb = balg.pair_bytes(s1, s2)
+            for k in b:
+                b[k] += pb[k]
+        ms_mean = ms_acc / args.steps  # HIP-event ms per step: inside sweep, outside sweep, duplex, whole
+        phases = {}
+        for key, bytes_, ms_k, launches in (("mc_inside_diag", b["mc_inside"], ms_mean[0], nl[0]),
+                                            ("mc_outside_diag", b["mc_outside"], ms_mean[1], nl[1]),
+                                            ("dx_sweep_diag", b["duplex"], ms_mean[2], nl[2])):
+            phases[key] = {"alg_GB_per_step": bytes_ / 1e9, "ms_per_step": float(ms_k), "launches": int(launches),
+                           "avg_launch_us": float(ms_k) * 1e3 / max(1, launches),
+                           "achieved_GBs": bytes_ / 1e9 / (ms_k / 1e3) if ms_k > 0 else None}
+        dom = max(("mc_inside_diag", "mc_outside_diag"), key=lambda k: phases[k]["ms_per_step"])
+        ach = phases[dom]["achieved_GBs"]
+        line = {
+            "metric": "sequence-pairs/sec (incl. bp+hp+ap DP) at n=%d" % n,
+            "value": total_pairs / dt,
+            "unit": "pairs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "synthetic random pairs n=%d/%d, std::mt19937(12345) stream (BASELINE config %s)"
+                                   % (n, n, "3" if n == 500 else ("4" if n == 2000 else "-")),
+                       "pairs_per_gpu_per_step": batch, "model": None, "scoring": "CONTRAfold complementary (708 weights)"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS if ach else None, "traffic": None,
+                         "alg_bytes_per_launch": phases[dom]["alg_GB_per_step"] * 1e9 / max(1, phases[dom]["launches"]),
+                         "avg_launch_us": phases[dom]["avg_launch_us"],
+                         "whole_path": {"alg_GB_per_pair": b["total"] / 1e9 / batch,
+                                        "achieved_GBs": b["total"] / 1e9 / (ms_mean[3] / 1e3),
+                                        "frac": b["total"] / 1e9 / (ms_mean[3] / 1e3) / HBM_PEAK_GBS},
+                         "phases": phases},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(all_pairs, budget_s=12.0 if n <= 600 else 1.0)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -84,6 +84,10 @@ int rh_batch_results(rh_ctx* ctx, int p,
                      double* bp1_tri, double* bp2_tri, double* up1, double* up2,
                      double* hp, double* logZ3 /* logZ(s1), logZ(s2), logZ(duplex) */);
 
+/* Per-pair scalars of the whole batch in one copy: out[3p..3p+2] = logZ(s1), logZ(s2),
+ * logZ(duplex) -- what a z-score shard gathers across GPUs (src/ractip.cpp:1655-1663). */
+int rh_batch_logz(rh_ctx* ctx, double* out);
+
 typedef struct rh_cand {
     int i, j; /* 1-based letters; for `up`: i = 0-based position, j = width index */
     float p;  /* probability narrowed to float exactly as the reference does (src/ractip.cpp:82-83) */

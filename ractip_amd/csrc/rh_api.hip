@@ -31,6 +31,16 @@ __global__ void dx_posterior(DxBatch B);
 
 using namespace rh;
 
+// out[3p..3p+2] = F5i[n] of sequences 2p, 2p+1 and the duplex logZ of pair p
+__global__ void collect_logz(McBatch B, DxBatch D, double* __restrict__ out)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= D.np) return;
+    out[3 * p + 0] = B.f5i[(size_t)(2 * p) * B.ld + B.n[2 * p]];
+    out[3 * p + 1] = B.f5i[(size_t)(2 * p + 1) * B.ld + B.n[2 * p + 1]];
+    out[3 * p + 2] = D.logz[p];
+}
+
 static thread_local std::string g_create_error;
 
 struct rh_ctx {
@@ -57,6 +67,7 @@ struct rh_ctx {
     void* d_dxtab = nullptr; size_t cap_dxtab = 0;
     void* d_hp = nullptr;    size_t cap_hp = 0;
     void* d_logz = nullptr;  size_t cap_logz = 0;
+    void* d_scal = nullptr;  size_t cap_scal = 0;
     double ms[4] = {0, 0, 0, 0};
     int n_launch[3] = {0, 0, 0};
 };
@@ -314,7 +325,7 @@ void rh_destroy(rh_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    void* bufs[] = {c->d_seq, c->d_n, c->d_mctab, c->d_f5, c->d_bp, c->d_up, c->d_dxtab, c->d_hp, c->d_logz, c->d_model};
+    void* bufs[] = {c->d_seq, c->d_n, c->d_mctab, c->d_f5, c->d_bp, c->d_up, c->d_dxtab, c->d_hp, c->d_logz, c->d_scal, c->d_model};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->s_mc) (void)hipStreamDestroy(c->s_mc);
@@ -397,6 +408,18 @@ int rh_batch_results(rh_ctx* c, int p, double* bp1, double* bp2, double* up1, do
         if ((rc = fetch_logz(c, 2 * p, logZ3))) return rc;
         if ((rc = fetch_logz(c, 2 * p + 1, logZ3 + 1))) return rc;
     }
+    return RH_OK;
+}
+
+int rh_batch_logz(rh_ctx* c, double* out)
+{
+    if (!c) return RH_ERR_ARG;
+    if (!c->computed || !c->has_mc || !c->has_dx || !out) return fail(c, RH_ERR_ARG, "no computed pair batch");
+    int rc;
+    if ((rc = ensure(c, &c->d_scal, &c->cap_scal, sizeof(double) * 3 * c->np, false))) return rc;
+    hipLaunchKernelGGL(collect_logz, dim3((c->np + 63) / 64), dim3(64), 0, c->s_mc, c->mc, c->dx, (double*)c->d_scal);
+    HIP_TRY(c, hipMemcpyAsync(out, c->d_scal, sizeof(double) * 3 * c->np, hipMemcpyDeviceToHost, c->s_mc));
+    HIP_TRY(c, hipStreamSynchronize(c->s_mc));
     return RH_OK;
 }
 

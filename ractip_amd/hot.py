@@ -17,7 +17,7 @@ RH_MODEL_VIENNA_BL = 1
 EXPORTS = [
     "rh_create", "rh_destroy", "rh_last_error", "rh_bpp", "rh_unpaired", "rh_duplex",
     "rh_batch_upload", "rh_batch_compute", "rh_batch_results", "rh_batch_candidates",
-    "rh_batch_timings", "rh_batch_device_views",
+    "rh_batch_timings", "rh_batch_device_views", "rh_batch_logz",
 ]
 
 
@@ -56,9 +56,10 @@ def load_library():
     L.rh_batch_results.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp]
     L.rh_batch_candidates.argtypes = [vp, ci, ci, ctypes.c_float, vp, ci]
     L.rh_batch_timings.argtypes = [vp, vp, vp]
+    L.rh_batch_logz.argtypes = [vp, vp]
     L.rh_batch_device_views.argtypes = [vp, vp, vp, vp, vp, vp]
     for f in ("rh_bpp", "rh_unpaired", "rh_duplex", "rh_batch_upload", "rh_batch_compute", "rh_batch_results",
-              "rh_batch_candidates", "rh_batch_timings", "rh_batch_device_views"):
+              "rh_batch_candidates", "rh_batch_timings", "rh_batch_device_views", "rh_batch_logz"):
         getattr(L, f).restype = ci
     _lib = L
     return L
@@ -140,6 +141,11 @@ class Context:
         self._check(self.L.rh_batch_results(self.h, p, bp1.ctypes.data, bp2.ctypes.data, up1.ctypes.data,
                                             up2.ctypes.data, hp.ctypes.data, z3.ctypes.data))
         return dict(bp1=bp1, bp2=bp2, up1=up1, up2=up2, hp=hp, logZ=z3)
+
+    def batch_logz(self):
+        out = np.zeros((len(self._pairs), 3))
+        self._check(self.L.rh_batch_logz(self.h, out.ctypes.data))
+        return out
 
     def batch_candidates(self, p, which, threshold, cap=1 << 20):
         buf = (Cand * cap)()
