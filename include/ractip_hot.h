@@ -60,6 +60,10 @@ int rh_bpp(rh_ctx* ctx, const char* seq, int n, const char* constraint,
  * is RH_ERR_UNSUPPORTED until the Vienna model exists. */
 int rh_unpaired(rh_ctx* ctx, const char* seq, int n, int max_w, double* up);
 
+/* Both of the above from ONE inside/outside pass -- the whole of RactIP::contrafold
+ * (src/ractip.cpp:199-222).  bp_tri, up (n doubles, width 1) or logZ may be NULL. */
+int rh_fold(rh_ctx* ctx, const char* seq, int n, double* bp_tri, double* up, double* logZ);
+
 /* Hybridization probabilities of a pair.  Replaces RactIP::contraduplex
  * (src/ractip.cpp:225-245: DuplexEngine ComputeInside/Outside/Posterior) and, for
  * RH_MODEL_VIENNA_BL, pf_duplex + pr_duplex of RactIP::rnaduplex (src/ractip.cpp:390-398). */

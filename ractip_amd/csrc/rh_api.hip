@@ -361,6 +361,20 @@ int rh_unpaired(rh_ctx* c, const char* seq, int n, int max_w, double* up)
     return fetch_up(c, 0, up);
 }
 
+int rh_fold(rh_ctx* c, const char* seq, int n, double* bp_tri, double* up, double* logZ)
+{
+    if (!c) return RH_ERR_ARG;
+    if (!seq || n < 0) return fail(c, RH_ERR_ARG, "bad sequence");
+    if (n == 0) { if (bp_tri) bp_tri[0] = 0.0; if (logZ) *logZ = 0.0; return RH_OK; }
+    int rc;
+    if ((rc = stage(c, 1, &seq, &n, true, false))) return rc;
+    if ((rc = compute(c))) return rc;
+    if (bp_tri && (rc = fetch_bp(c, 0, bp_tri))) return rc;
+    if (up && (rc = fetch_up(c, 0, up))) return rc;
+    if (logZ && (rc = fetch_logz(c, 0, logZ))) return rc;
+    return RH_OK;
+}
+
 int rh_duplex(rh_ctx* c, const char* s1, int n1, const char* s2, int n2, double* hp, double* logZ)
 {
     if (!c) return RH_ERR_ARG;

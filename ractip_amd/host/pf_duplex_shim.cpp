@@ -1,0 +1,63 @@
+// pf_duplex_shim.cpp -- source-compatible stand-in for /root/reference/src/pf_duplex.h:25-28
+//
+//   extern double **pr_duplex;
+//   double pf_duplex(const char *s1, const char *s2);
+//   void free_pf_duplex();
+//
+// so that RactIP::rnaduplex's --duplex branch (/root/reference/src/ractip.cpp:390-398)
+// links unchanged against libractip_pfduplex.so.  Same ownership as the original:
+// pf_duplex allocates pr_duplex (rows 1..n1, each n2+1 doubles, row 0 NULL;
+// pf_duplex.c:94-95) and returns log Z; free_pf_duplex releases it (:119-126).
+//
+// Scoring: the original evaluates ViennaRNA loop energies (E_IntLoop/E_ExtLoop), which
+// are third-party and absent (parity unpinned).  Until the ViennaBL model
+// row (8f-1) exists this shim runs the same forward/backward sweeps with the CONTRAfold
+// duplex scores -- i.e. it returns what RactIP::contraduplex would.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/ractip_hot.h"
+
+extern "C" {
+
+double** pr_duplex = nullptr;
+static int g_n1 = 0;
+static rh_ctx* g_ctx = nullptr;
+
+double pf_duplex(const char* s1, const char* s2)
+{
+    const int n1 = (int)std::strlen(s1), n2 = (int)std::strlen(s2);
+    if (!g_ctx) {
+        const char* dev = std::getenv("RACTIP_AMD_DEVICE");
+        g_ctx = rh_create(dev ? std::atoi(dev) : 0, RH_MODEL_CONTRAFOLD, nullptr);
+        if (!g_ctx) {  // the original aborts inside ViennaRNA's space() on failure; do the same, loudly
+            std::fprintf(stderr, "pf_duplex (ractip_amd): %s\n", rh_last_error(nullptr));
+            std::abort();
+        }
+    }
+    std::vector<double> hp((size_t)(n1 + 1) * (n2 + 1), 0.0);
+    double logz = 0.0;
+    if (n1 > 0 && n2 > 0 && rh_duplex(g_ctx, s1, n1, s2, n2, hp.data(), &logz) != RH_OK) {
+        std::fprintf(stderr, "pf_duplex (ractip_amd): %s\n", rh_last_error(g_ctx));
+        std::abort();
+    }
+    pr_duplex = (double**)std::calloc((size_t)n1 + 1, sizeof(double*));
+    for (int i = 1; i <= n1; i++) {
+        pr_duplex[i] = (double*)std::malloc(sizeof(double) * ((size_t)n2 + 1));
+        std::memcpy(pr_duplex[i], hp.data() + (size_t)i * (n2 + 1), sizeof(double) * ((size_t)n2 + 1));
+    }
+    g_n1 = n1;
+    return logz;
+}
+
+void free_pf_duplex()
+{
+    if (!pr_duplex) return;
+    for (int i = 1; i <= g_n1; i++) std::free(pr_duplex[i]);
+    std::free(pr_duplex);
+    pr_duplex = nullptr;
+}
+
+}  // extern "C"

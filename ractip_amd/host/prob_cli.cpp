@@ -1,0 +1,74 @@
+// prob_cli.cpp -- drives the C++ adapters exactly as RactIP::solve does
+// (/root/reference/src/ractip.cpp:536-548) and prints the float matrices it would
+// hand to the ILP, one value per line, for tests/test_gpu_host_adapter.py.
+//   prob_cli contrafold SEQ | contraduplex S1 S2 TH | rnaduplex S1 S2 | pfduplex S1 S2 | solve S1 S2 [S1 S2 ...]
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "ractip_prob.hpp"
+
+extern "C" {
+extern double** pr_duplex;
+double pf_duplex(const char*, const char*);
+void free_pf_duplex();
+}
+
+using namespace ractip_amd;
+
+static void dump_bp(const VF& bp, const VI& off, const VVF& up)
+{
+    std::printf("offset %zu\n", off.size());
+    for (int o : off) std::printf("%d\n", o);
+    std::printf("bp %zu\n", bp.size());
+    for (float v : bp) std::printf("%.9g\n", v);
+    std::printf("up %zu\n", up.size());
+    for (const VF& r : up) std::printf("%.9g\n", r[0]);
+}
+static void dump_hp(const VVF& hp)
+{
+    std::printf("hp %zu %zu\n", hp.size(), hp.empty() ? (size_t)0 : hp[0].size());
+    for (const VF& r : hp)
+        for (float v : r) std::printf("%.9g\n", v);
+}
+
+int main(int argc, char** argv)
+{
+    try {
+        if (argc < 3) throw std::logic_error("usage");
+        const std::string mode = argv[1];
+        if (mode == "pfduplex") {
+            const double z = pf_duplex(argv[2], argv[3]);
+            const size_t n1 = std::strlen(argv[2]), n2 = std::strlen(argv[3]);
+            std::printf("logZ %.17g\nhp %zu %zu\n", z, n1 + 1, n2 + 1);
+            for (size_t j = 0; j <= n2; j++) std::printf("0\n");
+            for (size_t i = 1; i <= n1; i++)
+                for (size_t j = 0; j <= n2; j++) std::printf("%.17g\n", j ? pr_duplex[i][j] : 0.0);
+            free_pf_duplex();
+            return 0;
+        }
+        ProbabilityEngine en(0, mode == "contraduplex" ? (float)std::atof(argv[4]) : 0.1f);
+        if (mode == "contrafold") {
+            VF bp; VI off; VVF up;
+            en.contrafold(argv[2], bp, off, up);
+            dump_bp(bp, off, up);
+        } else if (mode == "contraduplex") {
+            VVF hp; en.contraduplex(argv[2], argv[3], hp); dump_hp(hp);
+        } else if (mode == "rnaduplex") {
+            VVF hp; en.rnaduplex(argv[2], argv[3], hp); dump_hp(hp);
+        } else if (mode == "solve") {
+            std::vector<std::pair<std::string, std::string>> pairs;
+            for (int k = 2; k + 1 < argc; k += 2) pairs.emplace_back(argv[k], argv[k + 1]);
+            for (const PairProbabilities& r : en.solve_probabilities(pairs)) {
+                std::printf("pair %.17g %.17g %.17g\n", r.logZ1, r.logZ2, r.logZd);
+                dump_bp(r.bp1, r.offset1, r.up1);
+                dump_bp(r.bp2, r.offset2, r.up2);
+                dump_hp(r.hp);
+            }
+        } else throw std::logic_error("unknown mode");
+    } catch (const std::logic_error& e) {  // RactIP's main() handler, src/ractip.cpp:1684-1687
+        std::fprintf(stderr, "%s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

@@ -1,0 +1,61 @@
+// ractip_prob.hpp -- C++17 mirror of RactIP's probability-layer members on top of the
+// C ABI (include/ractip_hot.h).  Same names, argument meaning, container layouts and
+// error behaviour as the reference's private members (/root/reference/src/ractip.cpp):
+//
+//   void contrafold(const std::string& seq, VF& bp, VI& offset, VVF& up) const;   // :195-223
+//   void contraduplex(const std::string& s1, const std::string& s2, VVF& hp) const; // :225-245
+//   void rnaduplex(const std::string& s1, const std::string& s2, VVF& hp) const;  // :384-399 (--duplex branch)
+//
+// so that RactIP::solve (:536-548) can call them unchanged; see INTEGRATION.md for the
+// two-line patch.  Failures surface as std::logic_error, which RactIP's main() already
+// catches (:1684-1691).
+#pragma once
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+struct rh_ctx;
+
+namespace ractip_amd {
+
+typedef unsigned int uint;
+typedef std::vector<float> VF;   // src/ractip.cpp:82
+typedef std::vector<VF> VVF;     // src/ractip.cpp:83
+typedef std::vector<int> VI;
+
+struct PairProbabilities {  // everything RactIP::solve consumes for one (s1,s2) pair
+    VF bp1, bp2;
+    VI offset1, offset2;
+    VVF up1, up2, hp;
+    double logZ1 = 0, logZ2 = 0, logZd = 0;
+};
+
+class ProbabilityEngine {
+public:
+    // th_hy: RactIP's hybridization threshold th_hy_ (contraduplex keeps hp >= th_hy, :237)
+    explicit ProbabilityEngine(int device = 0, float th_hy = 0.1f, const char* param_file = nullptr);
+    ~ProbabilityEngine();
+    ProbabilityEngine(const ProbabilityEngine&) = delete;
+    ProbabilityEngine& operator=(const ProbabilityEngine&) = delete;
+
+    void contrafold(const std::string& seq, VF& bp, VI& offset, VVF& up) const;
+    void contraduplex(const std::string& seq1, const std::string& seq2, VVF& hp) const;
+    // the --duplex branch of RactIP::rnaduplex: pf_duplex() + pr_duplex copy (:390-398)
+    void rnaduplex(const std::string& seq1, const std::string& seq2, VVF& hp) const;
+
+    // batched form for the z-score loop (:1638-1657): all DPs of all pairs in one device pass
+    std::vector<PairProbabilities> solve_probabilities(const std::vector<std::pair<std::string, std::string>>& pairs) const;
+
+    rh_ctx* raw() const { return ctx_; }
+
+private:
+    [[noreturn]] void raise(const char* where) const;
+    rh_ctx* ctx_;
+    float th_hy_;
+};
+
+// offset[i] = i*(2(L+1)-i-1)/2, size L+1  (src/ractip.cpp:254-257; InferenceEngine.ipp:316)
+VI make_offsets(uint L);
+
+}  // namespace ractip_amd

@@ -15,7 +15,7 @@ RH_MODEL_CONTRAFOLD = 0
 RH_MODEL_VIENNA_BL = 1
 
 EXPORTS = [
-    "rh_create", "rh_destroy", "rh_last_error", "rh_bpp", "rh_unpaired", "rh_duplex",
+    "rh_create", "rh_destroy", "rh_last_error", "rh_bpp", "rh_unpaired", "rh_fold", "rh_duplex",
     "rh_batch_upload", "rh_batch_compute", "rh_batch_results", "rh_batch_candidates",
     "rh_batch_timings", "rh_batch_device_views", "rh_batch_logz",
 ]
@@ -50,6 +50,7 @@ def load_library():
     L.rh_last_error.argtypes = [vp]
     L.rh_bpp.argtypes = [vp, cp, ci, cp, vp, vp]
     L.rh_unpaired.argtypes = [vp, cp, ci, ci, vp]
+    L.rh_fold.argtypes = [vp, cp, ci, vp, vp, vp]
     L.rh_duplex.argtypes = [vp, cp, ci, cp, ci, vp, vp]
     L.rh_batch_upload.argtypes = [vp, ci, ctypes.POINTER(cp), ctypes.POINTER(ci), ctypes.POINTER(cp), ctypes.POINTER(ci)]
     L.rh_batch_compute.argtypes = [vp]
@@ -58,7 +59,7 @@ def load_library():
     L.rh_batch_timings.argtypes = [vp, vp, vp]
     L.rh_batch_logz.argtypes = [vp, vp]
     L.rh_batch_device_views.argtypes = [vp, vp, vp, vp, vp, vp]
-    for f in ("rh_bpp", "rh_unpaired", "rh_duplex", "rh_batch_upload", "rh_batch_compute", "rh_batch_results",
+    for f in ("rh_bpp", "rh_unpaired", "rh_fold", "rh_duplex", "rh_batch_upload", "rh_batch_compute", "rh_batch_results",
               "rh_batch_candidates", "rh_batch_timings", "rh_batch_device_views", "rh_batch_logz"):
         getattr(L, f).restype = ci
     _lib = L
@@ -112,6 +113,12 @@ class Context:
         up = np.zeros(n * max_w)
         self._check(self.L.rh_unpaired(self.h, seq.encode(), n, max_w, up.ctypes.data))
         return up.reshape(n, max_w)
+
+    def fold(self, seq):
+        n = len(seq)
+        bp, up, z = np.zeros(tri_size(n)), np.zeros(n), ctypes.c_double()
+        self._check(self.L.rh_fold(self.h, seq.encode(), n, bp.ctypes.data, up.ctypes.data, ctypes.addressof(z)))
+        return bp, up, z.value
 
     def duplex(self, s1, s2):
         hp = np.zeros((len(s1) + 1, len(s2) + 1))

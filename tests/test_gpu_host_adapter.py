@@ -1,0 +1,105 @@
+"""GPU suite: the C++ mirror of RactIP's probability-layer members (ractip_amd/host)
+and the pf_duplex shim, driven the way RactIP::solve drives them, against the oracle
+narrowed to float as the reference's VF/VVF containers do (src/ractip.cpp:82-83)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from _oracle import tri_size
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "ractip_amd", "host", "prob_cli")
+
+
+@pytest.fixture(scope="module")
+def cli(hotlib):
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "ractip_amd", "host")])
+    return CLI
+
+
+def run(cli, *args):
+    out = subprocess.run([cli] + list(args), check=True, capture_output=True, text=True).stdout.split("\n")
+    return [l for l in out if l]
+
+
+def take(lines, pos, tag):
+    hdr = lines[pos].split()
+    assert hdr[0] == tag, (hdr, tag)
+    dims = [int(x) for x in hdr[1:]]
+    cnt = int(np.prod(dims))
+    vals = np.array([float(x) for x in lines[pos + 1:pos + 1 + cnt]])
+    return vals.reshape(dims) if len(dims) > 1 else vals, pos + 1 + cnt
+
+
+def close32(a, b, what):
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    assert a.shape == b.shape, what
+    # float narrowing of two doubles that agree to 1e-6 relative: at most ~1 float ulp apart
+    assert np.all(np.abs(a - b) <= 2e-6 * np.maximum(np.abs(b), 1e-6) + 1e-12), what
+
+
+def test_contrafold_member(cli, oracle, golden):
+    seq = str(golden["mc/RyhB/seq"])
+    n = len(seq)
+    lines = run(cli, "contrafold", seq)
+    off, p = take(lines, 0, "offset")
+    bp, p = take(lines, p, "bp")
+    up, p = take(lines, p, "up")
+    assert list(off.astype(int)) == [i * (2 * (n + 1) - i - 1) // 2 for i in range(n + 1)]  # ractip.cpp:257
+    assert bp.size == tri_size(n) and up.size == n
+    o = oracle.inference(seq)
+    close32(bp, o["post"], "bp")
+    assert np.abs(up.astype(np.float32) - oracle.up_float(n, o["post"].astype(np.float32))).max() < 2e-6
+
+
+def test_contraduplex_threshold_and_rnaduplex(cli, oracle, golden):
+    s1, s2 = str(golden["mc/Tar/seq"]), str(golden["mc/Tarstar/seq"])
+    ref = oracle.duplex(s1, s2)["post"]
+    hp, _ = take(run(cli, "rnaduplex", s1, s2), 0, "hp")
+    close32(hp, ref, "rnaduplex hp")
+    th = 0.1
+    hp_t, _ = take(run(cli, "contraduplex", s1, s2, str(th)), 0, "hp")
+    expect = np.where(ref.astype(np.float32) >= np.float32(th), ref, 0.0)  # GetPosterior(th_hy_), ractip.cpp:237
+    edge = np.abs(ref - th) < 1e-6
+    close32(np.where(edge, 0, hp_t), np.where(edge, 0, expect), "contraduplex hp")
+
+
+def test_pf_duplex_shim_surface(cli, oracle, golden):
+    s1, s2 = str(golden["mc/R1inv/seq"]), str(golden["mc/R2inv/seq"])
+    lines = run(cli, "pfduplex", s1, s2)
+    assert lines[0].startswith("logZ")
+    z = float(lines[0].split()[1])
+    hp, _ = take(lines, 1, "hp")
+    o = oracle.duplex(s1, s2)
+    assert abs(z - o["logZ2"][0]) < 1e-9
+    assert np.abs(hp - o["post"]).max() < 1e-9
+
+
+def test_solve_probabilities_batch(cli, oracle, golden):
+    names = [("DIS", "DIS"), ("R1inv", "R2inv")]
+    args = []
+    for a, b in names:
+        args += [str(golden["mc/%s/seq" % a]), str(golden["mc/%s/seq" % b])]
+    lines = run(cli, "solve", *args)
+    p = 0
+    for a, b in names:
+        s1, s2 = str(golden["mc/%s/seq" % a]), str(golden["mc/%s/seq" % b])
+        z = [float(x) for x in lines[p].split()[1:]]
+        p += 1
+        o1, o2, od = oracle.inference(s1), oracle.inference(s2), oracle.duplex(s1, s2)
+        assert abs(z[0] - o1["logZ"]) < 1e-9 and abs(z[1] - o2["logZ"]) < 1e-9 and abs(z[2] - od["logZ2"][0]) < 1e-9
+        for o in (o1, o2):
+            _, p = take(lines, p, "offset")
+            bp, p = take(lines, p, "bp")
+            _, p = take(lines, p, "up")
+            close32(bp, o["post"], "bp")
+        hp, p = take(lines, p, "hp")
+        close32(hp, od["post"], "hp")
+
+
+def test_errors_become_logic_error_exit_code(cli):
+    r = subprocess.run([cli, "nosuchmode", "ACGU"], capture_output=True, text=True)
+    assert r.returncode == 1 and "unknown mode" in r.stderr
