@@ -47,6 +47,18 @@ rh_ctx* rh_create(int device, int model, const char* param_file);
 void rh_destroy(rh_ctx* ctx);
 const char* rh_last_error(const rh_ctx* ctx);
 
+/* Arithmetic path of the McCaskill sweeps.  AUTO (default): scaled linear-space kernels,
+ * and if any sequence of the batch leaves the double range (detected on device) the whole
+ * batch is recomputed by the log-space kernels, which follow the reference's own
+ * log-space arithmetic (src/contrafold/LogSpace.hpp).  LOG / LINEAR force one path
+ * (LINEAR reports RH_OK even if values overflowed: testing only). */
+#define RH_MODE_AUTO 0
+#define RH_MODE_LOG 1
+#define RH_MODE_LINEAR 2
+int rh_set_mode(rh_ctx* ctx, int mode);
+/* path taken by the last compute: 1 = linear, 2 = log-space, 3 = linear, then log-space fallback */
+int rh_last_path(const rh_ctx* ctx);
+
 /* Base-pairing probabilities of one sequence.  Replaces the body of
  * RactIP::contrafold up to GetPosterior (src/ractip.cpp:199-211:
  * ComputeInside/ComputeOutside/ComputePosterior/GetPosterior(0,...)) and, for

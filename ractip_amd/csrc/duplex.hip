@@ -114,23 +114,25 @@ __global__ __launch_bounds__(256) void dx_sweep_diag(DxBatch B, const ScoreModel
     if (!outside) {
         // inside[i][j] = open(i,j) (+) (+)_{p<i,q>j} inside[p][q] + step(p,q -> i,j)   (DuplexEngine.ipp:1029-1064)
         const double down = tm4(M, b, a, b_p1, a_m1) + bp_ab;  // terms of the downstream pair (i,j)
-        const int room = (i - 2) + (L2 - j - 1);
-        if (room >= 0) {
-            const int tmax = room < 28 ? room : 28;
-            const int cnt = (tmax + 1) * (tmax + 2) / 2;
-            for (int c = lane; c < cnt; c += 64) {
-                const int len = M->dx_combo_len[c];
-                const int l1 = len & 0xff, l2 = len >> 8;
-                const int p = i - 1 - l1, q = j + 1 + l2;
-                if (p < 1 || q > L2) continue;
-                double x;
-                if (c == 0) x = tab[D_IN * ts + (size_t)p * ldd + q] + bp_ab + hs4(M, s1[p], s2[q], a, b);
-                else {
-                    x = tab[D_INX * ts + (size_t)p * ldd + q] + down;
-                    if (c < 5) x += loop_nucs(M, l1, l2, s1[p + 1], s2[q - 1]);
-                }
-                lse_add(acc, x);
+        const int l1max = i - 2, l2max = L2 - j - 1;           // p = i-1-l1 >= 1, q = j+1+l2 <= L2
+        if (l1max >= 0 && l2max >= 0) {
+            const double* __restrict__ inx = tab + D_INX * ts + (size_t)(i - 1) * ldd + (j + 1);
+            Shape sh[kDxShapeIters];
+#pragma unroll
+            for (int u = 0; u < kDxShapeIters; u++) sh[u] = M->dx_shape[64 * u + lane];
+            double x[kDxShapeIters];
+#pragma unroll
+            for (int u = 0; u < kDxShapeIters; u++) {
+                const bool ok = sh[u].l1 <= l1max && sh[u].l2 <= l2max;
+                x[u] = ok ? inx[sh[u].l2 - (ptrdiff_t)sh[u].l1 * ldd] : kEmptyMax;
             }
+#pragma unroll
+            for (int u = 0; u < kDxShapeIters; u++) x[u] += down;
+            if (sh[0].l1 <= 1 && sh[0].l2 <= 1 && sh[0].l1 <= l1max && sh[0].l2 <= l2max)
+                x[0] += loop_nucs(M, sh[0].l1, sh[0].l2, s1[i - sh[0].l1], s2[j + sh[0].l2]);  // s1[p+1], s2[q-1]
+            if (lane == 0)  // stacked on (i-1,j+1)
+                x[0] = tab[D_IN * ts + (size_t)(i - 1) * ldd + (j + 1)] + bp_ab + hs4(M, a_m1, b_p1, a, b);
+            lse_add_group<kDxShapeIters>(acc, x);
         }
         if (lane == 0) lse_add(acc, open_score(M, i, j, L2, a, b, a_m1, b_p1));
         const double v = lse_wave_finish(acc);
@@ -142,25 +144,26 @@ __global__ __launch_bounds__(256) void dx_sweep_diag(DxBatch B, const ScoreModel
         // outside[p][q] = close(p,q) (+) (+)_{i>p,j<q} outside[i][j] + step(p,q -> i,j)  (DuplexEngine.ipp:1094-1129, pulled)
         // here (i,j) is the TARGET (p,q) of the reference's loop nest
         const double up = tm4(M, a, b, a_p1, b_m1);  // terms of the upstream pair (this cell)
-        const int room = (L1 - i - 1) + (j - 2);
-        if (room >= 0) {
-            const int tmax = room < 28 ? room : 28;
-            const int cnt = (tmax + 1) * (tmax + 2) / 2;
-            for (int c = lane; c < cnt; c += 64) {
-                const int len = M->dx_combo_len[c];
-                const int l1 = len & 0xff, l2 = len >> 8;
-                const int ii = i + 1 + l1, jj = j - 1 - l2;
-                if (ii > L1 || jj < 1) continue;
-                double x;
-                if (c == 0) {
-                    const int aa = s1[ii], bb = s2[jj];
-                    x = tab[D_OUT * ts + (size_t)ii * ldd + jj] + M->base_pair[aa * 5 + bb] + hs4(M, a, b, aa, bb);
-                } else {
-                    x = tab[D_OUTX * ts + (size_t)ii * ldd + jj] + up;
-                    if (c < 5) x += loop_nucs(M, l1, l2, a_p1, b_m1);
-                }
-                lse_add(acc, x);
+        const int l1max = L1 - i - 1, l2max = j - 2;  // ii = i+1+l1 <= L1, jj = j-1-l2 >= 1
+        if (l1max >= 0 && l2max >= 0) {
+            const double* __restrict__ outx = tab + D_OUTX * ts + (size_t)(i + 1) * ldd + (j - 1);
+            Shape sh[kDxShapeIters];
+#pragma unroll
+            for (int u = 0; u < kDxShapeIters; u++) sh[u] = M->dx_shape[64 * u + lane];
+            double x[kDxShapeIters];
+#pragma unroll
+            for (int u = 0; u < kDxShapeIters; u++) {
+                const bool ok = sh[u].l1 <= l1max && sh[u].l2 <= l2max;
+                x[u] = ok ? outx[(ptrdiff_t)sh[u].l1 * ldd - sh[u].l2] : kEmptyMax;
             }
+#pragma unroll
+            for (int u = 0; u < kDxShapeIters; u++) x[u] += up;
+            x[0] += loop_nucs(M, sh[0].l1, sh[0].l2, a_p1, b_m1);
+            if (lane == 0) {  // (i+1,j-1) stacked on this pair
+                const int aa = s1[i + 1], bb = s2[j - 1];
+                x[0] = tab[D_OUT * ts + (size_t)(i + 1) * ldd + (j - 1)] + M->base_pair[aa * 5 + bb] + hs4(M, a, b, aa, bb);
+            }
+            lse_add_group<kDxShapeIters>(acc, x);
         }
         if (lane == 0) lse_add(acc, close_score(M, i, j, L1, a, b, a_p1, b_m1));
         const double v = lse_wave_finish(acc);

@@ -81,13 +81,28 @@ __global__ void mc_init(McBatch B)
 }
 
 // ---------------------------------------------------------------------------------
+// Work distribution shared by the two sweeps.  A launch covers every sequence of the
+// batch; `pin` selects the block->(sequence, wave slot) map:
+//   pin = 1: blockIdx.x = sequence (fastest varying).  Workgroups are dealt round-robin
+//            over the 8 XCDs by linear id, so with ns % 8 == 0 all blocks of a sequence
+//            share one XCD and its 4 MiB L2 sees only ns/8 sequences' rows (speed only).
+//   pin = 0: blockIdx.y = sequence: few, large sequences are spread over all XCDs.
+__device__ __forceinline__ void block_map(int pin, int* sq, int* slot)
+{
+    *sq = pin ? blockIdx.x : blockIdx.y;
+    *slot = pin ? blockIdx.y : blockIdx.x;
+}
+
+// ---------------------------------------------------------------------------------
 // inside, diagonal d: cells (i, i+d), 1 <= i <= n-1-d, one wavefront each; the wave
 // after the last cell computes F5i[d+1].
-__global__ __launch_bounds__(256) void mc_inside_diag(McBatch B, const ScoreModel* __restrict__ M, int d)
+__global__ __launch_bounds__(256) void mc_inside_diag(McBatch B, const ScoreModel* __restrict__ M, int d, int pin)
 {
-    const int sq = blockIdx.y;
+    int sq, slot;
+    block_map(pin, &sq, &slot);
+    if (sq >= B.ns) return;
     const int n = B.n[sq];
-    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int wave = slot * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int ncell = n - 1 - d > 0 ? n - 1 - d : 0;
     if (d > n - 1 || wave > ncell) return;
@@ -103,7 +118,8 @@ __global__ __launch_bounds__(256) void mc_inside_diag(McBatch B, const ScoreMode
         const int jj = d + 1;
         const double* __restrict__ fcat = tab + T_FCAT * ts + (size_t)(jj - 1) * ld;
         Lse acc = lse_empty();
-        for (int k = lane; k <= jj - 2; k += 64) lse_add(acc, f5i[k] + M->external_paired + fcat[k + 1]);
+        lse_stream2<4>(acc, f5i, fcat + 1, 0, jj - 1, lane);
+        acc.m += M->external_paired;  // constant factor of every streamed term
         if (lane == 0) lse_add(acc, f5i[jj - 1] + M->external_unpaired);
         const double v = lse_wave_finish(acc);
         if (lane == 0) f5i[jj] = v;
@@ -112,56 +128,57 @@ __global__ __launch_bounds__(256) void mc_inside_diag(McBatch B, const ScoreMode
 
     const int i = wave + 1, j = i + d;
     const int s_im1 = s[i - 1], s_i = s[i], s_ip1 = s[i + 1], s_j = s[j], s_jp1 = s[j + 1], s_jp2 = s[j + 2];
+    const bool pairable = complementary(s_i, s_jp1);
+    const bool inner = d >= 2;  // cells of span 0/1 have no FM2, FM1, FM and no enclosed pair
+
+    // O(1) operands of FM1 / FM / the stacking term: issued before the streams so that they are in flight with them
+    double op_fca = kNeg, op_fm1 = kNeg, op_fm = kNeg, op_fc = kNeg;
+    if (inner) {
+        op_fca = tab[T_FCA * ts + (size_t)(i + 1) * ld + (j - 1)];
+        op_fm1 = tab[T_FM1 * ts + (size_t)(i + 1) * ld + j];
+        op_fm = tab[T_FM * ts + (size_t)i * ld + (j - 1)];
+        op_fc = tab[T_FC * ts + (size_t)(i + 1) * ld + (j - 1)];
+    }
+
+    // ---- single-branch gather of FC[i,j]: up to 8 x 64 shapes, all gathers in flight (ipp:3597-3619)
+    Lse acc_c = lse_empty();
+    const double jb = junction_b(M, s_i, s_jp1, s_ip1, s_j);
+    if (pairable && inner) {
+        const int tmax = d - 2 < kMaxSingle ? d - 2 : kMaxSingle;
+        const double* __restrict__ fcx = tab + T_FCX * ts + (size_t)(i + 1) * ld + (j - 1);
+        Shape sh[kMcShapeIters];
+#pragma unroll
+        for (int u = 0; u < kMcShapeIters; u++) sh[u] = M->mc_shape[64 * u + lane];
+        double x[kMcShapeIters];
+#pragma unroll
+        for (int u = 0; u < kMcShapeIters; u++) {
+            const bool ok = sh[u].l1 + sh[u].l2 <= tmax;
+            x[u] = ok ? fcx[(ptrdiff_t)sh[u].l1 * ld - sh[u].l2] : kEmptyMax;
+        }
+#pragma unroll
+        for (int u = 0; u < kMcShapeIters; u++) x[u] += sh[u].score + jb;
+        x[0] += single_nucs(M, sh[0].l1, sh[0].l2, s_ip1, s_j);
+        if (lane == 0)  // shape (0,0) is the stacking pair: FC[i+1,j-1] + ScoreBasePair(i+1,j) + ScoreHelixStacking(i,j+1)
+            x[0] = op_fc + M->base_pair[s_ip1 * 5 + s_j] + hs4(M, s_i, s_jp1, s_ip1, s_j);
+        lse_add_group<kMcShapeIters>(acc_c, x);
+    }
+    if (pairable && lane == 0 && d >= kMinHairpin) lse_add(acc_c, jb + M->hairpin_len[d < 30 ? d : 30]);  // ScoreHairpin
 
     // ---- FM2[i,j] = (+)_{i<k<j} FM1[i,k] + FM[k,j]        (ipp:3384-3411)
-    double fm2 = kNeg;
-    if (d >= 2) {
-        const double* __restrict__ r1 = tab + T_FM1 * ts + (size_t)i * ld;
-        const double* __restrict__ r2 = tab + T_FMT * ts + (size_t)j * ld;
-        Lse acc = lse_empty();
-        for (int k = i + 1 + lane; k < j; k += 64) lse_add(acc, r1[k] + r2[k]);
-        fm2 = lse_wave_finish(acc);
-    }
+    Lse acc_2 = lse_empty();
+    if (inner)
+        lse_stream2<8>(acc_2, tab + T_FM1 * ts + (size_t)i * ld, tab + T_FMT * ts + (size_t)j * ld, i + 1, j, lane);
 
-    // ---- FC[i,j]                                            (ipp:3567-3627)
-    double fc = kNeg;
-    const bool pairable = complementary(s_i, s_jp1);
-    if (pairable) {
-        Lse acc = lse_empty();
-        const double jb = junction_b(M, s_i, s_jp1, s_ip1, s_j);
-        if (d >= 2) {
-            const int tmax = d - 2 < kMaxSingle ? d - 2 : kMaxSingle;
-            const int cnt = (tmax + 1) * (tmax + 2) / 2;
-            const double* __restrict__ fcx = tab + T_FCX * ts;
-            for (int c = lane; c < cnt; c += 64) {
-                const int len = M->mc_combo_len[c];
-                const int l1 = len & 0xff, l2 = len >> 8;
-                double x;
-                if (c == 0) {  // stacking pair: FC[i+1,j-1] + ScoreBasePair(i+1,j) + ScoreHelixStacking(i,j+1)
-                    x = tab[T_FC * ts + (size_t)(i + 1) * ld + (j - 1)] + M->base_pair[s_ip1 * 5 + s_j] +
-                        hs4(M, s_i, s_jp1, s_ip1, s_j);
-                } else {
-                    x = fcx[(size_t)(i + 1 + l1) * ld + (j - 1 - l2)] + M->mc_combo_score[c] + jb;
-                    if (c < 5) x += single_nucs(M, l1, l2, s_ip1, s_j);
-                }
-                lse_add(acc, x);
-            }
-        }
-        if (lane == 0) {
-            if (d >= kMinHairpin) lse_add(acc, jb + M->hairpin_len[d < 30 ? d : 30]);  // ScoreHairpin, ipp:2123-2152
-            lse_add(acc, fm2 + junction_a(M, s_i, s_jp1, s_ip1, s_j) + M->multi_paired + M->multi_base);
-        }
-        fc = lse_wave_finish(acc);
-    }
+    double fm2, fc;
+    lse_wave_finish2(acc_2, acc_c, fm2, fc);
+    // multiloop closed by (i,j+1): FM2 + ScoreJunctionA(i,j) + multi_paired + multi_base (ipp:3622)
+    fc = pairable ? lse2(fc, fm2 + junction_a(M, s_i, s_jp1, s_ip1, s_j) + M->multi_paired + M->multi_base) : kNeg;
 
     // ---- FM1[i,j], FM[i,j]                                  (ipp:3641-3688)
     double fm1 = kNeg, fm = kNeg;
-    if (d >= 2) {
-        const double a = tab[T_FCA * ts + (size_t)(i + 1) * ld + (j - 1)] + M->multi_paired;
-        const double b = tab[T_FM1 * ts + (size_t)(i + 1) * ld + j] + M->multi_unpaired;
-        fm1 = lse2(a, b);
-        const double c = tab[T_FM * ts + (size_t)i * ld + (j - 1)] + M->multi_unpaired;
-        fm = lse3(fm2, c, fm1);
+    if (inner) {
+        fm1 = lse2(op_fca + M->multi_paired, op_fm1 + M->multi_unpaired);
+        fm = lse3(fm2, op_fm + M->multi_unpaired, fm1);
     }
 
     if (lane == 0) {
@@ -186,11 +203,13 @@ __global__ __launch_bounds__(256) void mc_inside_diag(McBatch B, const ScoreMode
 // ---------------------------------------------------------------------------------
 // outside (pull form) + posterior, diagonal d: cells (i, i+d), 1 <= i <= n-1-d; the
 // wave after the last cell computes F5o[d+1].
-__global__ __launch_bounds__(256) void mc_outside_diag(McBatch B, const ScoreModel* __restrict__ M, int d)
+__global__ __launch_bounds__(256) void mc_outside_diag(McBatch B, const ScoreModel* __restrict__ M, int d, int pin)
 {
-    const int sq = blockIdx.y;
+    int sq, slot;
+    block_map(pin, &sq, &slot);
+    if (sq >= B.ns) return;
     const int n = B.n[sq];
-    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int wave = slot * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int ncell = n - 1 - d;
     if (ncell < 1 || wave > ncell) return;
@@ -207,7 +226,8 @@ __global__ __launch_bounds__(256) void mc_outside_diag(McBatch B, const ScoreMod
         const int k = d + 1;
         const double* __restrict__ fca = tab + T_FCA * ts + (size_t)(k + 1) * ld;
         Lse acc = lse_empty();
-        for (int jj = k + 2 + lane; jj <= n; jj += 64) lse_add(acc, f5o[jj] + M->external_paired + fca[jj - 1]);
+        lse_stream2<4>(acc, f5o + 1, fca, k + 1, n, lane);  // index t = jj-1
+        acc.m += M->external_paired;
         if (lane == 0) lse_add(acc, f5o[k + 1] + M->external_unpaired);
         const double v = lse_wave_finish(acc);
         if (lane == 0) f5o[k] = v;
@@ -217,71 +237,75 @@ __global__ __launch_bounds__(256) void mc_outside_diag(McBatch B, const ScoreMod
     const int i = wave + 1, j = i + d;
     const int s_im1 = s[i - 1], s_i = s[i], s_ip1 = s[i + 1], s_j = s[j], s_jp1 = s[j + 1], s_jp2 = s[j + 2];
     const bool guard_m = d >= 2;
+    const bool pairable = complementary(s_i, s_jp1);
 
-    // ---- FMo[i,j], FM1o[i,j]
-    double fmo = kNeg, fm1o = kNeg;
+    // O(1) operands, issued up front
+    double op_fmo = kNeg, op_fm1o = kNeg, op_fm1o_up = kNeg, op_fco_up = kNeg, op_f5o = kNeg, op_f5i = kNeg;
     if (guard_m) {
-        {   // column gather: FM2o[i',j] + FM1i[i',i], i' = 1..i-1   (ipp:4046-4064, second update, pulled)
-            const double* __restrict__ r1 = tab + T_FM2OT * ts + (size_t)j * ld;
-            const double* __restrict__ r2 = tab + T_FM1T * ts + (size_t)i * ld;
-            Lse acc = lse_empty();
-            for (int k = 1 + lane; k < i; k += 64) lse_add(acc, r1[k] + r2[k]);
-            if (lane == 0 && j + 1 <= n - 1)  // FMo[i,j+1] + multi_unpaired (ipp:3806)
-                lse_add(acc, tab[T_FMO * ts + (size_t)i * ld + (j + 1)] + M->multi_unpaired);
-            fmo = lse_wave_finish(acc);
-        }
-        {   // row gather: FM2o[i,j'] + FMi[j,j'], j' = j+1..n-1      (ipp:4046-4064, first update, pulled)
-            const double* __restrict__ r1 = tab + T_FM2O * ts + (size_t)i * ld;
-            const double* __restrict__ r2 = tab + T_FM * ts + (size_t)j * ld;
-            Lse acc = lse_empty();
-            for (int k = j + 1 + lane; k <= n - 1; k += 64) lse_add(acc, r1[k] + r2[k]);
-            if (lane == 0) {
-                lse_add(acc, fmo);                                    // ipp:3809
-                if (i - 1 >= 1)                                       // FM1o[i-1,j] + multi_unpaired (ipp:3833)
-                    lse_add(acc, tab[T_FM1O * ts + (size_t)(i - 1) * ld + j] + M->multi_unpaired);
-            }
-            fm1o = lse_wave_finish(acc);
+        if (j + 1 <= n - 1) op_fmo = tab[T_FMO * ts + (size_t)i * ld + (j + 1)];          // FMo[i,j+1]   (ipp:3806)
+        if (i - 1 >= 1) op_fm1o = tab[T_FM1O * ts + (size_t)(i - 1) * ld + j];            // FM1o[i-1,j]  (ipp:3833)
+    }
+    if (pairable) {
+        op_f5o = f5o[j + 1];
+        op_f5i = f5i[i - 1];
+        if (i - 1 >= 1 && j + 1 <= n - 1) {
+            op_fm1o_up = tab[T_FM1O * ts + (size_t)(i - 1) * ld + (j + 1)];               // FM1o[i-1,j+1] (ipp:3828)
+            op_fco_up = tab[T_FCO * ts + (size_t)(i - 1) * ld + (j + 1)];                 // FCo[i-1,j+1]  (stacking)
         }
     }
+    const double fc_in = tab[T_FC * ts + (size_t)i * ld + j];
+    const double Z = f5i[n];
 
-    // ---- FCo[i,j]
-    double fco = kNeg;
-    const bool pairable = complementary(s_i, s_jp1);
+    // ---- enclosing single-branch loops of FCo[i,j] (ipp:4004-4024 pulled): source (i',j') = (i-1-l1, j+1+l2)
+    Lse acc_c = lse_empty();
+    const double bp = M->base_pair[s_i * 5 + s_jp1];
+    const double ja_in = junction_a(M, s_jp1, s_i, s_jp2, s_im1);  // ScoreJunctionA(j+1,i-1)
     if (pairable) {
-        const double bp = M->base_pair[s_i * 5 + s_jp1];
-        const double ja_in = junction_a(M, s_jp1, s_i, s_jp2, s_im1);  // ScoreJunctionA(j+1,i-1)
-        Lse acc = lse_empty();
+        const double dec = bp + junction_b(M, s_jp1, s_i, s_jp2, s_im1);  // BP(p+1,q) + JB(q,p)
+        const int l1max = i - 2, l2max = n - 2 - j;
+        if (l1max >= 0 && l2max >= 0) {
+            const double* __restrict__ fcox = tab + T_FCOX * ts + (size_t)(i - 1) * ld + (j + 1);
+            Shape sh[kMcShapeIters];
+#pragma unroll
+            for (int u = 0; u < kMcShapeIters; u++) sh[u] = M->mc_shape[64 * u + lane];
+            double x[kMcShapeIters];
+#pragma unroll
+            for (int u = 0; u < kMcShapeIters; u++) {
+                const bool ok = sh[u].l1 <= l1max && sh[u].l2 <= l2max;
+                x[u] = ok ? fcox[sh[u].l2 - (ptrdiff_t)sh[u].l1 * ld] : kEmptyMax;
+            }
+#pragma unroll
+            for (int u = 0; u < kMcShapeIters; u++) x[u] += sh[u].score + dec;
+            // nucleotide terms of the 0x1 / 1x0 / 1x1 shapes: letters i'+1 and j' of the ENCLOSING loop
+            if (sh[0].l1 <= 1 && sh[0].l2 <= 1 && sh[0].l1 <= l1max && sh[0].l2 <= l2max)
+                x[0] += single_nucs(M, sh[0].l1, sh[0].l2, s[i - sh[0].l1], s[j + 1 + sh[0].l2]);
+            if (lane == 0)  // stacked on (i-1,j+1): FCo + ScoreBasePair(i,j+1) + ScoreHelixStacking(i-1,j+2)
+                x[0] = op_fco_up + bp + hs4(M, s_im1, s_jp2, s_i, s_jp1);
+            lse_add_group<kMcShapeIters>(acc_c, x);
+        }
         if (lane == 0) {
             // exterior loop (ipp:3768-3776): F5o[j+1] + ext_paired + BP + JA(j+1,i-1) + F5i[i-1]
-            lse_add(acc, f5o[j + 1] + M->external_paired + bp + ja_in + f5i[i - 1]);
+            lse_add(acc_c, op_f5o + M->external_paired + bp + ja_in + op_f5i);
             // branch of a multiloop via FM1 (ipp:3828): FM1o[i-1,j+1] + JA + multi_paired + BP
-            if (i - 1 >= 1 && j + 1 <= n - 1 && d >= 0)
-                lse_add(acc, tab[T_FM1O * ts + (size_t)(i - 1) * ld + (j + 1)] + ja_in + M->multi_paired + bp);
+            lse_add(acc_c, op_fm1o_up + ja_in + M->multi_paired + bp);
         }
-        // enclosing single-branch loops (ipp:4004-4024 pulled): source (i',j') = (i-1-l1, j+1+l2)
-        const double dec = bp + junction_b(M, s_jp1, s_i, s_jp2, s_im1);  // BP(p+1,q) + JB(q,p)
-        const int room = (i - 2) + (n - 2 - j);  // max l1 + max l2
-        if (room >= 0) {
-            const int tmax = room < kMaxSingle ? room : kMaxSingle;
-            const int cnt = (tmax + 1) * (tmax + 2) / 2;
-            const double* __restrict__ fcox = tab + T_FCOX * ts;
-            for (int c = lane; c < cnt; c += 64) {
-                const int len = M->mc_combo_len[c];
-                const int l1 = len & 0xff, l2 = len >> 8;
-                const int ii = i - 1 - l1, jj = j + 1 + l2;
-                if (ii < 1 || jj > n - 1) continue;
-                double x;
-                if (c == 0) {  // stacked on (i-1,j+1): FCo + ScoreBasePair(i,j+1) + ScoreHelixStacking(i-1,j+2)
-                    x = tab[T_FCO * ts + (size_t)ii * ld + jj] + bp + hs4(M, s_im1, s_jp2, s_i, s_jp1);
-                } else {
-                    x = fcox[(size_t)ii * ld + jj] + M->mc_combo_score[c] + dec;
-                    if (c < 5) x += single_nucs(M, l1, l2, s[ii + 1], s[jj]);
-                }
-                lse_add(acc, x);
-            }
-        }
-        fco = lse_wave_finish(acc);
     }
+
+    // ---- FMo[i,j] column gather, FM1o[i,j] row gather (ipp:4046-4064 pulled)
+    Lse acc_m = lse_empty(), acc_1 = lse_empty();
+    if (guard_m) {
+        lse_stream2<4>(acc_m, tab + T_FM2OT * ts + (size_t)j * ld, tab + T_FM1T * ts + (size_t)i * ld, 1, i, lane);
+        lse_stream2<4>(acc_1, tab + T_FM2O * ts + (size_t)i * ld, tab + T_FM * ts + (size_t)j * ld, j + 1, n, lane);
+        if (lane == 0) {
+            lse_add(acc_m, op_fmo + M->multi_unpaired);
+            lse_add(acc_1, op_fm1o + M->multi_unpaired);
+        }
+    }
+    double fmo, fm1o, fco;
+    lse_wave_finish3(acc_m, acc_1, acc_c, fmo, fm1o, fco);
+    if (!guard_m) { fmo = kNeg; fm1o = kNeg; }
+    else fm1o = lse2(fm1o, fmo);  // FM1o[i,j] (+)= FMo[i,j]  (ipp:3809)
+    if (!pairable) fco = kNeg;
 
     // ---- FM2o[i,j] = FMo[i,j] (+) FCo[i,j] + ScoreJunctionA(i,j) + a + c   (ipp:3803, 4027)
     const double viafc = pairable ? fco + junction_a(M, s_i, s_jp1, s_ip1, s_j) + M->multi_paired + M->multi_base : kNeg;
@@ -296,8 +320,7 @@ __global__ __launch_bounds__(256) void mc_outside_diag(McBatch B, const ScoreMod
         tab[T_FM2O * ts + ij] = fm2o;
         tab[T_FM2OT * ts + ji] = fm2o;
         // posterior of pair (i, j+1): exp(FCo + FCi - Z), clipped to [0,1] (ipp:4689-4827)
-        const double Z = f5i[n];
-        const double e = fco + tab[T_FC * ts + ij] - Z;
+        const double e = fco + fc_in - Z;
         double p = e > kNeg / 2 ? exp(e) : 0.0;
         p = p > 1.0 ? 1.0 : p;
         B.bp[(size_t)sq * B.tri_stride + tri_offset(n, i) + (j + 1)] = pairable ? p : 0.0;

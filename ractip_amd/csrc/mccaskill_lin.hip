@@ -1,0 +1,332 @@
+// mccaskill_lin.hip -- McCaskill inside / outside / posterior in SCALED LINEAR space.
+//
+// Same recurrences as mccaskill.hip (reference: /root/reference/src/contrafold/
+// InferenceEngine.ipp:3356-3722 inside, 3731-4080 outside, 4498-4828 posterior), but
+//   * values are Q * lambda^span (lin_model.h), so every inner term is one FMA;
+//   * tables are stored DIAGONAL-MAJOR: cell (i, j=i+d) lives at [d*ld + i].  With one
+//     THREAD per cell and 64 consecutive cells of a diagonal per wavefront, every
+//     operand of every recurrence is a contiguous 512-byte row segment:
+//        FM2[i,d]   = sum_m FM1[m][i]     * FM[d-m][i+m]
+//        FMo[i,d]   = sum_e FM2o[d+e][i-e] * FM1[e][i-e]
+//        FM1o[i,d]  = sum_e FM2o[d+e][i]   * FM[e][i+d]
+//        FC gather  : FCX[d-2-t][i+1+l1],  FCo gather: FCoX[d+2+t][i-1-l1]
+//     so no transposed mirrors, no cross-lane reductions and no 64-wide execution of
+//     per-cell scalar work;
+//   * the term loops of a 64-cell group are split over the W wavefronts of its
+//     workgroup (partial sums meet in LDS) to keep thousands of waves in flight;
+//   * loop shapes are wave-uniform, so their (l1,l2,weight) come from scalar loads.
+#include <hip/hip_runtime.h>
+
+#include "batch.h"
+#include "lin_model.h"
+
+namespace rh {
+
+namespace {
+
+constexpr uint32_t kPairMaskL = (1u << (0 * 5 + 3)) | (1u << (3 * 5 + 0)) | (1u << (1 * 5 + 2)) |
+                                (1u << (2 * 5 + 1)) | (1u << (2 * 5 + 3)) | (1u << (3 * 5 + 2));
+__device__ __forceinline__ bool pairs(int a, int b) { return (kPairMaskL >> (a * 5 + b)) & 1u; }
+__device__ __forceinline__ size_t tri_off(int n, int i) { return (size_t)i * (size_t)(2 * (n + 1) - i - 1) / 2; }
+
+__device__ __forceinline__ double wsum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ void block_map(int pin, int* sq, int* slot)
+{
+    *sq = pin ? blockIdx.x : blockIdx.y;
+    *slot = pin ? blockIdx.y : blockIdx.x;
+}
+
+}  // namespace
+
+enum LinTable { L_FC = 0, L_FCX, L_FCA, L_FM1, L_FM, L_FCO, L_FCOX, L_FM2O, L_FMO, L_FM1O, L_COUNT };
+static_assert((int)L_COUNT <= (int)T_COUNT, "linear tables reuse the log-space table buffer");
+
+// F5i~[0] = 1, F5o~[n] = 1
+__global__ void lin_init(McBatch B, int* __restrict__ bad)
+{
+    const int sq = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sq >= B.ns) return;
+    B.f5i[(size_t)sq * B.ld] = 1.0;
+    B.f5o[(size_t)sq * B.ld + B.n[sq]] = 1.0;
+    bad[sq] = 0;
+}
+
+// ---------------------------------------------------------------------------------
+// inside, diagonal d.  Workgroup = 64 consecutive cells x W wavefronts; the group after
+// the last cell group computes F5i~[d+1] with its first wavefront.
+template <int W>
+__global__ __launch_bounds__(64 * W) void lin_inside_diag(McBatch B, const LinModel* __restrict__ L, int d, double lam_d, int pin)
+{
+    __shared__ double part[2][W][64];
+    int sq, slot;
+    block_map(pin, &sq, &slot);
+    if (sq >= B.ns) return;
+    const int n = B.n[sq];
+    if (d > n - 1) return;
+    const int ncell = n - 1 - d > 0 ? n - 1 - d : 0;
+    const int ngroup = (ncell + 63) >> 6;
+    if (slot > ngroup) return;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ld = B.ld;
+    const size_t ts = B.tab_stride;
+    const uint8_t* __restrict__ s = B.seq + (size_t)sq * B.lds;
+    double* __restrict__ tab = B.tab + (size_t)sq * B.seq_stride;
+    double* __restrict__ f5i = B.f5i + (size_t)sq * ld;
+
+    if (slot == ngroup) {
+        // F5i[jj] = F5i[jj-1]*ext_unpaired + sum_{k<=jj-2} F5i[k]*FCA[k+1,jj-1]*ext_paired   (ipp:3692-3717)
+        if (w != 0) return;
+        const int jj = d + 1;
+        const double* __restrict__ fca = tab + L_FCA * ts;
+        double acc = 0.0;
+        for (int k = lane; k <= jj - 2; k += 64) acc += f5i[k] * fca[(size_t)(jj - 2 - k) * ld + (k + 1)];
+        acc = wsum(acc);
+        if (lane == 0) f5i[jj] = f5i[jj - 1] * L->w_eu + acc * L->w_ep2;
+        return;
+    }
+
+    const int i = 1 + slot * 64 + lane, j = i + d;
+    const bool valid = i <= ncell;
+    int s_im1 = 4, s_i = 4, s_ip1 = 4, s_j = 4, s_jp1 = 4, s_jp2 = 4;
+    if (valid) { s_im1 = s[i - 1]; s_i = s[i]; s_ip1 = s[i + 1]; s_j = s[j]; s_jp1 = s[j + 1]; s_jp2 = s[j + 2]; }
+    const bool pairable = valid && pairs(s_i, s_jp1);
+
+    // ---- FM2[i,d] = sum_{m=1}^{d-1} FM1[m][i] * FM[d-m][i+m]          (ipp:3384-3411)
+    double acc2 = 0.0;
+    if (valid) {
+        const double* __restrict__ fm1 = tab + L_FM1 * ts + i;
+        const double* __restrict__ fm = tab + L_FM * ts + i;
+        int m = 1 + w;
+        for (; m + 3 * W <= d - 1; m += 4 * W) {
+            const double a0 = fm1[(size_t)m * ld], a1 = fm1[(size_t)(m + W) * ld], a2 = fm1[(size_t)(m + 2 * W) * ld],
+                         a3 = fm1[(size_t)(m + 3 * W) * ld];
+            const double b0 = fm[(size_t)(d - m) * ld + m], b1 = fm[(size_t)(d - m - W) * ld + m + W],
+                         b2 = fm[(size_t)(d - m - 2 * W) * ld + m + 2 * W], b3 = fm[(size_t)(d - m - 3 * W) * ld + m + 3 * W];
+            acc2 = fma(a0, b0, acc2); acc2 = fma(a1, b1, acc2); acc2 = fma(a2, b2, acc2); acc2 = fma(a3, b3, acc2);
+        }
+        for (; m <= d - 1; m += W) acc2 = fma(fm1[(size_t)m * ld], fm[(size_t)(d - m) * ld + m], acc2);
+    }
+
+    // ---- generic single-branch shapes of FC[i,d]: sum_c w_c * FCX[d-2-t][i+1+l1]   (ipp:3597-3619)
+    double accc = 0.0;
+    if (d >= 2) {
+        const int tmax = d - 2 < kMaxSingle ? d - 2 : kMaxSingle;
+        const int cnt = L->shape_cnt[tmax];
+        const double* __restrict__ fcx = tab + L_FCX * ts + (i + 1);
+        int c = w;
+        for (; c + 3 * W < cnt; c += 4 * W) {
+            double v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int l1 = L->shape_l1[c + u * W], l2 = L->shape_l2[c + u * W];
+                v[u] = pairable ? fcx[(size_t)(d - 2 - l1 - l2) * ld + l1] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) accc = fma(L->shape_w[c + u * W], v[u], accc);
+        }
+        for (; c < cnt; c += W) {
+            const int l1 = L->shape_l1[c], l2 = L->shape_l2[c];
+            const double v = pairable ? fcx[(size_t)(d - 2 - l1 - l2) * ld + l1] : 0.0;
+            accc = fma(L->shape_w[c], v, accc);
+        }
+    }
+
+    part[0][w][lane] = acc2;
+    part[1][w][lane] = accc;
+    __syncthreads();
+    if (w != 0 || !valid) return;
+    double fm2 = 0.0, g = 0.0;
+#pragma unroll
+    for (int k = 0; k < W; k++) { fm2 += part[0][k][lane]; g += part[1][k][lane]; }
+
+    const size_t at = (size_t)d * ld + i;
+    const int idx = 25 * (5 * s_i + s_ip1) + 5 * s_jp1 + s_j;       // (i,j)   as enclosing pair
+    const int idd = 25 * (5 * s_jp1 + s_jp2) + 5 * s_i + s_im1;     // (j+1,i-1) as enclosed pair
+    double fc = 0.0;
+    if (pairable) {
+        double sp = 0.0, st = 0.0, hp = 0.0;
+        if (d >= 3) {
+            const double* __restrict__ fcx = tab + L_FCX * ts;
+            sp = L->w01 * L->E_b01[s_j] * fcx[(size_t)(d - 3) * ld + i + 1] + L->w10 * L->E_b10[s_ip1] * fcx[(size_t)(d - 3) * ld + i + 2];
+            if (d >= 4) sp += L->w11 * L->E_11[s_ip1 * 5 + s_j] * fcx[(size_t)(d - 4) * ld + i + 2];
+            hp = lam_d * L->E_hairpin[d < 30 ? d : 30];               // ScoreHairpin (ipp:2123-2152)
+        }
+        if (d >= 2) st = tab[L_FC * ts + (size_t)(d - 2) * ld + i + 1] * L->lam2 * L->TST[idx];
+        fc = L->TJB[idx] * (g + sp + hp) + st + fm2 * L->TJA[idx] * L->e_mpmb;   // ipp:3573-3622
+    }
+    double fm1v = 0.0, fmv = 0.0;
+    if (d >= 2) {                                                     // ipp:3641-3688
+        fm1v = tab[L_FCA * ts + (size_t)(d - 2) * ld + i + 1] * L->w_mp2 + tab[L_FM1 * ts + (size_t)(d - 1) * ld + i + 1] * L->w_mu;
+        fmv = fm2 + tab[L_FM * ts + (size_t)(d - 1) * ld + i] * L->w_mu + fm1v;
+    }
+    const double ebp = L->E_bp[s_i * 5 + s_jp1];
+    tab[L_FC * ts + at] = fc;
+    tab[L_FCX * ts + at] = fc * ebp * L->TJB[idd];
+    tab[L_FCA * ts + at] = fc * ebp * L->TJA[idd];
+    tab[L_FM1 * ts + at] = fm1v;
+    tab[L_FM * ts + at] = fmv;
+}
+
+// ---------------------------------------------------------------------------------
+// outside (pull form) + posterior, diagonal d; last group: F5o~[d+1].
+template <int W>
+__global__ __launch_bounds__(64 * W) void lin_outside_diag(McBatch B, const LinModel* __restrict__ L, int d, int pin, int* __restrict__ bad)
+{
+    __shared__ double part[3][W][64];
+    int sq, slot;
+    block_map(pin, &sq, &slot);
+    if (sq >= B.ns) return;
+    const int n = B.n[sq];
+    const int ncell = n - 1 - d;
+    if (ncell < 1) return;
+    const int ngroup = (ncell + 63) >> 6;
+    if (slot > ngroup) return;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ld = B.ld;
+    const size_t ts = B.tab_stride;
+    const uint8_t* __restrict__ s = B.seq + (size_t)sq * B.lds;
+    double* __restrict__ tab = B.tab + (size_t)sq * B.seq_stride;
+    const double* __restrict__ f5i = B.f5i + (size_t)sq * ld;
+    double* __restrict__ f5o = B.f5o + (size_t)sq * ld;
+
+    if (slot == ngroup) {
+        // F5o[k] = F5o[k+1]*ext_unpaired + sum_{jj>=k+2} F5o[jj]*FCA[k+1,jj-1]*ext_paired   (ipp:3751-3780, pulled)
+        if (w != 0) return;
+        const int k = d + 1;
+        const double* __restrict__ fca = tab + L_FCA * ts + (k + 1);
+        double acc = 0.0;
+        for (int jj = k + 2 + lane; jj <= n; jj += 64) acc += f5o[jj] * fca[(size_t)(jj - 2 - k) * ld];
+        acc = wsum(acc);
+        if (lane == 0) f5o[k] = f5o[k + 1] * L->w_eu + acc * L->w_ep2;
+        return;
+    }
+
+    const int i0 = 1 + slot * 64;
+    const int i = i0 + lane, j = i + d;
+    const bool valid = i <= ncell;
+    int s_im1 = 4, s_i = 4, s_ip1 = 4, s_j = 4, s_jp1 = 4, s_jp2 = 4;
+    if (valid) { s_im1 = s[i - 1]; s_i = s[i]; s_ip1 = s[i + 1]; s_j = s[j]; s_jp1 = s[j + 1]; s_jp2 = s[j + 2]; }
+    const bool pairable = valid && pairs(s_i, s_jp1);
+    const bool guard_m = d >= 2;
+
+    double accm = 0.0, acc1 = 0.0, accc = 0.0;
+    if (guard_m) {
+        // FMo[i,d] += FM2o[d+e][i-e] * FM1[e][i-e], e = 1..i-1            (ipp:4046-4064, pulled)
+        {
+            const int i_last = ncell < i0 + 63 ? ncell : i0 + 63;
+            const int emax = i_last - 1;
+            const double* __restrict__ x = tab + L_FM2O * ts + i;
+            const double* __restrict__ y = tab + L_FM1 * ts + i;
+            const int mine = valid ? i - 1 : 0;
+            int e = 1 + w;
+            for (; e + W <= emax; e += 2 * W) {
+                const bool p0 = e <= mine, p1 = e + W <= mine;
+                const double x0 = p0 ? x[(size_t)(d + e) * ld - e] : 0.0, y0 = p0 ? y[(size_t)e * ld - e] : 0.0;
+                const double x1 = p1 ? x[(size_t)(d + e + W) * ld - e - W] : 0.0, y1 = p1 ? y[(size_t)(e + W) * ld - e - W] : 0.0;
+                accm = fma(x0, y0, accm); accm = fma(x1, y1, accm);
+            }
+            for (; e <= emax; e += W)
+                if (e <= mine) accm = fma(x[(size_t)(d + e) * ld - e], y[(size_t)e * ld - e], accm);
+        }
+        // FM1o[i,d] += FM2o[d+e][i] * FM[e][i+d], e = 1..n-1-j
+        {
+            const int emax = n - 1 - (i0 + d);
+            const double* __restrict__ x = tab + L_FM2O * ts + i;
+            const double* __restrict__ y = tab + L_FM * ts + j;
+            const int mine = valid ? n - 1 - j : 0;
+            int e = 1 + w;
+            for (; e + W <= emax; e += 2 * W) {
+                const bool p0 = e <= mine, p1 = e + W <= mine;
+                const double x0 = p0 ? x[(size_t)(d + e) * ld] : 0.0, y0 = p0 ? y[(size_t)e * ld] : 0.0;
+                const double x1 = p1 ? x[(size_t)(d + e + W) * ld] : 0.0, y1 = p1 ? y[(size_t)(e + W) * ld] : 0.0;
+                acc1 = fma(x0, y0, acc1); acc1 = fma(x1, y1, acc1);
+            }
+            for (; e <= emax; e += W)
+                if (e <= mine) acc1 = fma(x[(size_t)(d + e) * ld], y[(size_t)e * ld], acc1);
+        }
+    }
+    {   // enclosing single-branch loops: FCoX[d+2+t][i-1-l1] * w_c               (ipp:4004-4024, pulled)
+        const int room = n - 4 - d;  // source span d+2+t <= n-2
+        if (room >= 0) {
+            const int tmax = room < kMaxSingle ? room : kMaxSingle;
+            const int cnt = L->shape_cnt[tmax];
+            const double* __restrict__ fcox = tab + L_FCOX * ts + (i - 1);
+            for (int c = w; c < cnt; c += W) {
+                const int l1 = L->shape_l1[c], l2 = L->shape_l2[c];
+                const bool ok = pairable && l1 <= i - 2 && j + 1 + l2 <= n - 1;
+                const double v = ok ? fcox[(size_t)(d + 2 + l1 + l2) * ld - l1] : 0.0;
+                accc = fma(L->shape_w[c], v, accc);
+            }
+        }
+    }
+    part[0][w][lane] = accm;
+    part[1][w][lane] = acc1;
+    part[2][w][lane] = accc;
+    __syncthreads();
+    if (w != 0 || !valid) return;
+    double sm = 0.0, s1 = 0.0, g = 0.0;
+#pragma unroll
+    for (int k = 0; k < W; k++) { sm += part[0][k][lane]; s1 += part[1][k][lane]; g += part[2][k][lane]; }
+
+    const size_t at = (size_t)d * ld + i;
+    const bool up_ok = i - 1 >= 1 && j + 1 <= n - 1;  // the cell (i-1, j+1) is interior
+    double fmo = 0.0, fm1o = 0.0;
+    if (guard_m) {
+        fmo = sm + (j + 1 <= n - 1 ? tab[L_FMO * ts + (size_t)(d + 1) * ld + i] * L->w_mu : 0.0);       // ipp:3806
+        fm1o = s1 + fmo + (i - 1 >= 1 ? tab[L_FM1O * ts + (size_t)(d + 1) * ld + i - 1] * L->w_mu : 0.0); // ipp:3809, 3833
+    }
+    const int idx = 25 * (5 * s_i + s_ip1) + 5 * s_jp1 + s_j;
+    double fco = 0.0;
+    if (pairable) {
+        const int idd = 25 * (5 * s_jp1 + s_jp2) + 5 * s_i + s_im1;
+        const double ebp = L->E_bp[s_i * 5 + s_jp1];
+        const double ext = f5o[j + 1] * f5i[i - 1] * L->w_ep2;                                        // ipp:3768-3776
+        const double multi = up_ok ? tab[L_FM1O * ts + (size_t)(d + 2) * ld + i - 1] * L->w_mp2 : 0.0;  // ipp:3828
+        double sp = 0.0, st = 0.0;
+        const double* __restrict__ fcox = tab + L_FCOX * ts;
+        if (i - 1 >= 1 && j + 2 <= n - 1) sp += L->w01 * L->E_b01[s_jp2] * fcox[(size_t)(d + 3) * ld + i - 1];
+        if (i - 2 >= 1 && j + 1 <= n - 1) sp += L->w10 * L->E_b10[s_im1] * fcox[(size_t)(d + 3) * ld + i - 2];
+        if (i - 2 >= 1 && j + 2 <= n - 1) sp += L->w11 * L->E_11[s_im1 * 5 + s_jp2] * fcox[(size_t)(d + 4) * ld + i - 2];
+        if (up_ok) st = tab[L_FCO * ts + (size_t)(d + 2) * ld + i - 1] * L->lam2 * L->TST[25 * (5 * s_im1 + s_i) + 5 * s_jp2 + s_jp1];
+        fco = ebp * (L->TJA[idd] * (ext + multi) + L->TJB[idd] * (g + sp)) + st;
+    }
+    const double fm2o = fmo + fco * L->TJA[idx] * L->e_mpmb;                                          // ipp:3803, 4027
+    tab[L_FCO * ts + at] = fco;
+    tab[L_FCOX * ts + at] = fco * L->TJB[idx];
+    tab[L_FMO * ts + at] = fmo;
+    tab[L_FM1O * ts + at] = fm1o;
+    tab[L_FM2O * ts + at] = fm2o;
+    // posterior of pair (i, j+1) = FCo * FCi / Z, clipped to [0,1]                 (ipp:4689-4827)
+    double p = fco * tab[L_FC * ts + at] / f5i[n];
+    if (!(p == p) || p > 1e300) { atomicOr(&bad[sq], 1); p = 0.0; }
+    p = p > 1.0 ? 1.0 : (p < 0.0 ? 0.0 : p);
+    B.bp[(size_t)sq * B.tri_stride + tri_off(n, i) + (j + 1)] = p;
+}
+
+// logZ = log F5i~[n] + s*n; flags a sequence whose scaled values left the double range
+__global__ void lin_finish(McBatch B, const LinModel* __restrict__ L, double* __restrict__ logz, int* __restrict__ bad)
+{
+    const int sq = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sq >= B.ns) return;
+    const int n = B.n[sq];
+    const double z = B.f5i[(size_t)sq * B.ld + n];
+    const double zo = n >= 2 ? B.f5o[(size_t)sq * B.ld + 1] : 1.0;
+    if (!(z > 1e-280 && z < 1e280) || !(zo == zo) || zo > 1e300) atomicOr(&bad[sq], 1);
+    logz[sq] = log(z) + L->s * (double)n;
+}
+
+// the host side instantiates the group width it wants
+template __global__ void lin_inside_diag<4>(McBatch, const LinModel*, int, double, int);
+template __global__ void lin_inside_diag<8>(McBatch, const LinModel*, int, double, int);
+template __global__ void lin_inside_diag<16>(McBatch, const LinModel*, int, double, int);
+template __global__ void lin_outside_diag<4>(McBatch, const LinModel*, int, int, int*);
+template __global__ void lin_outside_diag<8>(McBatch, const LinModel*, int, int, int*);
+template __global__ void lin_outside_diag<16>(McBatch, const LinModel*, int, int, int*);
+
+}  // namespace rh

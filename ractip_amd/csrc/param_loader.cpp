@@ -5,6 +5,8 @@
 // 1386-1397, 1106-1197; DuplexEngine.ipp:83-602 registers the identical set).
 // Binding is by logical NAME, so the file may list the weights in any order.
 #include "score_model.h"
+#include "lin_model.h"
+#include <cmath>
 
 #include <algorithm>
 #include <cstdio>
@@ -113,23 +115,72 @@ bool load_score_model(const char* path, ScoreModel* m, char* err, int errlen)
         return s;
     };
 
-    // shapes sorted by total unpaired length t = l1+l2, then l1 ascending, so the
-    // shapes admissible for a span (t <= tmax) are a prefix of (tmax+1)(tmax+2)/2 entries
+    // shapes row-major in (l1, l2): consecutive entries are consecutive columns of one row
     int k = 0;
-    for (int t = 0; t <= kMaxSingle; t++)
-        for (int l1 = 0; l1 <= t; l1++, k++) {
-            m->mc_combo_len[k] = (uint16_t)(l1 | ((t - l1) << 8));
-            m->mc_combo_score[k] = single_len(l1, t - l1);
-        }
+    for (int l1 = 0; l1 <= kMaxSingle; l1++)
+        for (int l2 = 0; l1 + l2 <= kMaxSingle; l2++, k++) m->mc_shape[k] = Shape{single_len(l1, l2), l1, l2};
+    for (; k < kMcShapes; k++) m->mc_shape[k] = Shape{0.0, 1000, 1000};
     k = 0;
-    for (int t = 0; t <= 28; t++)  // DuplexEngine.ipp:1038-1042 works out to l1+l2 <= 28
-        for (int l1 = 0; l1 <= t; l1++, k++) m->dx_combo_len[k] = (uint16_t)(l1 | ((t - l1) << 8));
+    for (int l1 = 0; l1 <= 28; l1++)  // DuplexEngine.ipp:1038-1042 works out to l1+l2 <= 28
+        for (int l2 = 0; l1 + l2 <= 28; l2++, k++) m->dx_shape[k] = Shape{0.0, l1, l2};
+    for (; k < kDxShapes; k++) m->dx_shape[k] = Shape{0.0, 1000, 1000};
+    for (int u = 0; u < kMcShapeIters; u++) m->mc_iter_l1[u] = m->mc_shape[64 * u].l1;
+    for (int u = 0; u < kDxShapeIters; u++) m->dx_iter_l1[u] = m->dx_shape[64 * u].l1;
 
     if (w.missing) {
         snprintf(err, errlen, "%d weights missing in %s (first: %s)", w.missing, path, w.first_missing.c_str());
         return false;
     }
     return true;
+}
+
+void build_lin_model(const ScoreModel& m, double s, LinModel* L)
+{
+    std::memset(L, 0, sizeof(*L));
+    const double lam = std::exp(-s);
+    L->s = s; L->lam = lam; L->lam2 = lam * lam;
+    L->w_mu = lam * std::exp(m.multi_unpaired);
+    L->w_mp2 = lam * lam * std::exp(m.multi_paired);
+    L->w_eu = lam * std::exp(m.external_unpaired);
+    L->w_ep2 = lam * lam * std::exp(m.external_paired);
+    L->e_mpmb = std::exp(m.multi_paired + m.multi_base);
+    for (int a = 0; a < 5; a++)
+        for (int b = 0; b < 5; b++) {
+            L->E_bp[a * 5 + b] = std::exp(m.base_pair[a * 5 + b]);
+            L->E_11[a * 5 + b] = std::exp(m.internal_1x1[a * 5 + b]);
+        }
+    for (int a = 0; a < 5; a++) { L->E_b01[a] = std::exp(m.bulge_0x1[a]); L->E_b10[a] = std::exp(m.bulge_1x0[a]); }
+    for (int k = 0; k <= 30; k++) L->E_hairpin[k] = std::exp(m.hairpin_len[k]);
+    L->E_hairpin[31] = L->E_hairpin[30];
+    // letters: x = s[a], x1 = s[a+1], y1 = s[b+1], y = s[b];  index 25*(5x+x1) + (5y1+y)
+    for (int x = 0; x < 5; x++) for (int x1 = 0; x1 < 5; x1++) for (int y1 = 0; y1 < 5; y1++) for (int y = 0; y < 5; y++) {
+        const int idx = 25 * (5 * x + x1) + (5 * y1 + y);
+        const double hc = m.helix_closing[x * 5 + y1];
+        L->TJB[idx] = std::exp(hc + m.terminal_mismatch[((x * 5 + y1) * 5 + x1) * 5 + y]);
+        L->TJA[idx] = std::exp(hc + m.dangle_left[x * 25 + y1 * 5 + x1] + m.dangle_right[x * 25 + y1 * 5 + y]);
+        L->TST[idx] = std::exp(m.base_pair[x1 * 5 + y] + m.helix_stacking[((x * 5 + y1) * 5 + x1) * 5 + y]);
+    }
+    // shapes sorted by total length: recover cache_score_single from the row-major table
+    auto cs = [&](int l1, int l2) {
+        for (int k = 0; k < kMcShapes; k++)
+            if (m.mc_shape[k].l1 == l1 && m.mc_shape[k].l2 == l2) return m.mc_shape[k].score;
+        return 0.0;
+    };
+    int k = 0;
+    for (int t = 0; t <= kMaxSingle; t++) {
+        for (int l1 = 0; l1 <= t; l1++, k++) {
+            const int l2 = t - l1;
+            const double w = std::exp(cs(l1, l2)) * std::pow(lam, t + 2);
+            L->shape_l1[k] = l1; L->shape_l2[k] = l2;
+            const bool special = (l1 <= 1 && l2 <= 1);
+            L->shape_w[k] = special ? 0.0 : w;
+            if (l1 == 0 && l2 == 1) L->w01 = w;
+            if (l1 == 1 && l2 == 0) L->w10 = w;
+            if (l1 == 1 && l2 == 1) L->w11 = w;
+        }
+        L->shape_cnt[t] = k;
+    }
+    L->shape_cnt[31] = k;
 }
 
 }  // namespace rh

@@ -9,7 +9,9 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -18,27 +20,39 @@
 #include "../../include/ractip_hot.h"
 #include "batch.h"
 #include "score_model.h"
+#include "lin_model.h"
 
 namespace rh {
 __global__ void mc_init(McBatch B);
-__global__ void mc_inside_diag(McBatch B, const ScoreModel* __restrict__ M, int d);
-__global__ void mc_outside_diag(McBatch B, const ScoreModel* __restrict__ M, int d);
+__global__ void mc_inside_diag(McBatch B, const ScoreModel* __restrict__ M, int d, int pin);
+__global__ void mc_outside_diag(McBatch B, const ScoreModel* __restrict__ M, int d, int pin);
 __global__ void mc_unpaired(McBatch B);
 __global__ void dx_sweep_diag(DxBatch B, const ScoreModel* __restrict__ M, int t);
 __global__ void dx_logz(DxBatch B, const ScoreModel* __restrict__ M);
 __global__ void dx_posterior(DxBatch B);
+__global__ void lin_init(McBatch B, int* __restrict__ bad);
+template <int W> __global__ void lin_inside_diag(McBatch B, const LinModel* __restrict__ L, int d, double lam_d, int pin);
+template <int W> __global__ void lin_outside_diag(McBatch B, const LinModel* __restrict__ L, int d, int pin, int* __restrict__ bad);
+__global__ void lin_finish(McBatch B, const LinModel* __restrict__ L, double* __restrict__ logz, int* __restrict__ bad);
 }  // namespace rh
 
 using namespace rh;
 
 // out[3p..3p+2] = F5i[n] of sequences 2p, 2p+1 and the duplex logZ of pair p
-__global__ void collect_logz(McBatch B, DxBatch D, double* __restrict__ out)
+__global__ void collect_logz(const double* __restrict__ mc_logz, DxBatch D, double* __restrict__ out)
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= D.np) return;
-    out[3 * p + 0] = B.f5i[(size_t)(2 * p) * B.ld + B.n[2 * p]];
-    out[3 * p + 1] = B.f5i[(size_t)(2 * p + 1) * B.ld + B.n[2 * p + 1]];
+    out[3 * p + 0] = mc_logz[2 * p];
+    out[3 * p + 1] = mc_logz[2 * p + 1];
     out[3 * p + 2] = D.logz[p];
+}
+
+// log-space path: logZ = F5i[n] (InferenceEngine.ipp:4089-4094)
+__global__ void log_finish(McBatch B, double* __restrict__ logz)
+{
+    const int sq = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sq < B.ns) logz[sq] = B.f5i[(size_t)sq * B.ld + B.n[sq]];
 }
 
 static thread_local std::string g_create_error;
@@ -50,6 +64,11 @@ struct rh_ctx {
     hipStream_t s_mc = nullptr, s_dx = nullptr;
     hipEvent_t ev[6] = {};  // mc: start, after inside, after outside ; dx: start, end ; all: end
     ScoreModel* d_model = nullptr;
+    LinModel* d_lin = nullptr;
+    LinModel h_lin;
+    int mode = RH_MODE_AUTO;       // which McCaskill path rh_batch_compute takes
+    int lin_w = 8;                 // wavefronts per 64-cell group of the linear kernels
+    int last_path = 0;             // 1 = linear, 2 = log-space, 3 = linear then log-space fallback
 
     // current batch (host mirror)
     int np = 0, ns = 0;
@@ -68,6 +87,8 @@ struct rh_ctx {
     void* d_hp = nullptr;    size_t cap_hp = 0;
     void* d_logz = nullptr;  size_t cap_logz = 0;
     void* d_scal = nullptr;  size_t cap_scal = 0;
+    void* d_mclogz = nullptr; size_t cap_mclogz = 0;
+    void* d_bad = nullptr;   size_t cap_bad = 0;
     double ms[4] = {0, 0, 0, 0};
     int n_launch[3] = {0, 0, 0};
 };
@@ -171,6 +192,8 @@ int stage(rh_ctx* c, int ns, const char* const* seqs, const int* lens, bool with
         if ((rc = ensure(c, &c->d_mctab, &c->cap_mctab, sizeof(double) * B.seq_stride * ns, false))) return rc;
         if ((rc = ensure(c, &c->d_f5, &c->cap_f5, sizeof(double) * 2 * B.ld * ns, false))) return rc;
         if ((rc = ensure(c, &c->d_up, &c->cap_up, sizeof(double) * B.ld * ns, false))) return rc;
+        if ((rc = ensure(c, &c->d_mclogz, &c->cap_mclogz, sizeof(double) * ns, false))) return rc;
+        if ((rc = ensure(c, &c->d_bad, &c->cap_bad, sizeof(int) * ns, false))) return rc;
         // bp entries outside 1<=i<j<=n are never written by the sweep: keep them zero
         const size_t bp_bytes = sizeof(double) * B.tri_stride * ns;
         if ((rc = ensure(c, &c->d_bp, &c->cap_bp, bp_bytes, false))) return rc;
@@ -197,31 +220,72 @@ int stage(rh_ctx* c, int ns, const char* const* seqs, const int* lens, bool with
     return RH_OK;
 }
 
+// ---- McCaskill sweeps, log-space path (always valid)
+int launch_mc_log(rh_ctx* c, int pin)
+{
+    const McBatch& B = c->mc;
+    hipLaunchKernelGGL(mc_init, dim3((B.ns + 63) / 64), dim3(64), 0, c->s_mc, B);
+    for (int d = 0; d <= B.nmax - 1; d++) {
+        const int waves = std::max(B.nmax - 1 - d, 0) + 1;
+        hipLaunchKernelGGL(mc_inside_diag, pin ? dim3(B.ns, (waves + 3) / 4) : dim3((waves + 3) / 4, B.ns), dim3(256), 0,
+                           c->s_mc, B, c->d_model, d, pin);
+        c->n_launch[0]++;
+    }
+    HIP_TRY(c, hipEventRecord(c->ev[1], c->s_mc));
+    for (int d = B.nmax - 2; d >= 0; d--) {
+        const int waves = (B.nmax - 1 - d) + 1;
+        hipLaunchKernelGGL(mc_outside_diag, pin ? dim3(B.ns, (waves + 3) / 4) : dim3((waves + 3) / 4, B.ns), dim3(256), 0,
+                           c->s_mc, B, c->d_model, d, pin);
+        c->n_launch[1]++;
+    }
+    hipLaunchKernelGGL(log_finish, dim3((B.ns + 63) / 64), dim3(64), 0, c->s_mc, B, (double*)c->d_mclogz);
+    hipLaunchKernelGGL(mc_unpaired, dim3((B.nmax + 3) / 4, B.ns), dim3(256), 0, c->s_mc, B);
+    return RH_OK;
+}
+
+// ---- McCaskill sweeps, scaled linear-space path (fast; flags sequences that left the double range)
+template <int W>
+int launch_mc_lin(rh_ctx* c, int pin)
+{
+    const McBatch& B = c->mc;
+    int* bad = (int*)c->d_bad;
+    hipLaunchKernelGGL(lin_init, dim3((B.ns + 63) / 64), dim3(64), 0, c->s_mc, B, bad);
+    for (int d = 0; d <= B.nmax - 1; d++) {
+        const int groups = (std::max(B.nmax - 1 - d, 0) + 63) / 64 + 1;
+        hipLaunchKernelGGL(lin_inside_diag<W>, pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(64 * W), 0, c->s_mc, B,
+                           c->d_lin, d, std::exp(-c->h_lin.s * d), pin);
+        c->n_launch[0]++;
+    }
+    HIP_TRY(c, hipEventRecord(c->ev[1], c->s_mc));
+    for (int d = B.nmax - 2; d >= 0; d--) {
+        const int groups = (B.nmax - 1 - d + 63) / 64 + 1;
+        hipLaunchKernelGGL(lin_outside_diag<W>, pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(64 * W), 0, c->s_mc, B,
+                           c->d_lin, d, pin, bad);
+        c->n_launch[1]++;
+    }
+    hipLaunchKernelGGL(lin_finish, dim3((B.ns + 63) / 64), dim3(64), 0, c->s_mc, B, c->d_lin, (double*)c->d_mclogz, bad);
+    hipLaunchKernelGGL(mc_unpaired, dim3((B.nmax + 3) / 4, B.ns), dim3(256), 0, c->s_mc, B);
+    return RH_OK;
+}
+
+int launch_mc_lin_any(rh_ctx* c, int pin)
+{
+    switch (c->lin_w) {
+        case 4: return launch_mc_lin<4>(c, pin);
+        case 16: return launch_mc_lin<16>(c, pin);
+        default: return launch_mc_lin<8>(c, pin);
+    }
+}
+
 int compute(rh_ctx* c)
 {
     HIP_TRY(c, hipSetDevice(c->device));
     c->n_launch[0] = c->n_launch[1] = c->n_launch[2] = 0;
-    HIP_TRY(c, hipEventRecord(c->ev[0], c->s_mc));
-    if (c->has_mc) {
-        const McBatch& B = c->mc;
-        hipLaunchKernelGGL(mc_init, dim3((B.ns + 63) / 64), dim3(64), 0, c->s_mc, B);
-        for (int d = 0; d <= B.nmax - 1; d++) {
-            const int waves = std::max(B.nmax - 1 - d, 0) + 1;
-            hipLaunchKernelGGL(mc_inside_diag, dim3((waves + 3) / 4, B.ns), dim3(256), 0, c->s_mc, B, c->d_model, d);
-            c->n_launch[0]++;
-        }
-    }
-    HIP_TRY(c, hipEventRecord(c->ev[1], c->s_mc));
-    if (c->has_mc) {
-        const McBatch& B = c->mc;
-        for (int d = B.nmax - 2; d >= 0; d--) {
-            const int waves = (B.nmax - 1 - d) + 1;
-            hipLaunchKernelGGL(mc_outside_diag, dim3((waves + 3) / 4, B.ns), dim3(256), 0, c->s_mc, B, c->d_model, d);
-            c->n_launch[1]++;
-        }
-        hipLaunchKernelGGL(mc_unpaired, dim3((B.nmax + 3) / 4, B.ns), dim3(256), 0, c->s_mc, B);
-    }
-    HIP_TRY(c, hipEventRecord(c->ev[2], c->s_mc));
+    c->last_path = 0;
+    // sequence -> XCD affinity only when the batch spreads evenly over the 8 XCDs (speed only)
+    const int pin = (c->has_mc && c->mc.ns % 8 == 0) ? 1 : 0;
+    int rc;
+    // duplex first on its own stream: it is independent of the McCaskill sweeps and overlaps them
     HIP_TRY(c, hipEventRecord(c->ev[3], c->s_dx));
     if (c->has_dx) {
         const DxBatch& D = c->dx;
@@ -237,6 +301,30 @@ int compute(rh_ctx* c)
         hipLaunchKernelGGL(dx_posterior, dim3((cells + 255) / 256, D.np), dim3(256), 0, c->s_dx, D);
     }
     HIP_TRY(c, hipEventRecord(c->ev[4], c->s_dx));
+
+    HIP_TRY(c, hipEventRecord(c->ev[0], c->s_mc));
+    bool need_log = c->has_mc && c->mode == RH_MODE_LOG;
+    if (c->has_mc && c->mode != RH_MODE_LOG) {
+        if ((rc = launch_mc_lin_any(c, pin))) return rc;
+        c->last_path = 1;
+        if (c->mode == RH_MODE_AUTO) {  // did every sequence stay inside the double range?
+            std::vector<int> bad(c->mc.ns);
+            HIP_TRY(c, hipMemcpyAsync(bad.data(), c->d_bad, sizeof(int) * c->mc.ns, hipMemcpyDeviceToHost, c->s_mc));
+            HIP_TRY(c, hipStreamSynchronize(c->s_mc));
+            for (int b : bad) need_log |= (b != 0);
+            if (need_log) c->last_path = 3;
+        }
+    } else {
+        HIP_TRY(c, hipEventRecord(c->ev[1], c->s_mc));
+    }
+    if (need_log) {
+        c->n_launch[0] = c->n_launch[1] = 0;
+        HIP_TRY(c, hipEventRecord(c->ev[0], c->s_mc));
+        HIP_TRY(c, hipMemsetAsync(c->d_bp, 0, sizeof(double) * c->mc.tri_stride * c->mc.ns, c->s_mc));
+        if ((rc = launch_mc_log(c, pin))) return rc;
+        if (c->last_path == 0) c->last_path = 2;
+    }
+    HIP_TRY(c, hipEventRecord(c->ev[2], c->s_mc));
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(c->s_mc));
     HIP_TRY(c, hipStreamSynchronize(c->s_dx));
@@ -265,7 +353,7 @@ int fetch_up(rh_ctx* c, int sq, double* out)
 }
 int fetch_logz(rh_ctx* c, int sq, double* out)
 {
-    HIP_TRY(c, hipMemcpy(out, c->mc.f5i + (size_t)sq * c->mc.ld + c->n[sq], sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(out, (const double*)c->d_mclogz + sq, sizeof(double), hipMemcpyDeviceToHost));
     return RH_OK;
 }
 int fetch_hp(rh_ctx* c, int p, double* out, double* logz)
@@ -308,10 +396,16 @@ rh_ctx* rh_create(int device, int model, const char* param_file)
     }
     rh_ctx* c = new rh_ctx;
     c->device = device; c->model = model;
+    // scale exponent of the linear fast path: log Z per nucleotide of typical sequences under this model
+    // (random ACGU: 0.107..0.129 for n = 200..2000); deviations only cost dynamic range, never accuracy
+    build_lin_model(host_model, 0.12, &c->h_lin);
+    if (const char* e = std::getenv("RH_LIN_W")) c->lin_w = std::atoi(e);
     bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&c->s_mc, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&c->s_dx, hipStreamNonBlocking) == hipSuccess &&
               hipMalloc((void**)&c->d_model, sizeof(ScoreModel)) == hipSuccess &&
-              hipMemcpy(c->d_model, &host_model, sizeof(ScoreModel), hipMemcpyHostToDevice) == hipSuccess;
+              hipMemcpy(c->d_model, &host_model, sizeof(ScoreModel), hipMemcpyHostToDevice) == hipSuccess &&
+              hipMalloc((void**)&c->d_lin, sizeof(LinModel)) == hipSuccess &&
+              hipMemcpy(c->d_lin, &c->h_lin, sizeof(LinModel), hipMemcpyHostToDevice) == hipSuccess;
     for (int k = 0; ok && k < 6; k++) ok = hipEventCreate(&c->ev[k]) == hipSuccess;
     if (!ok) {
         fail(nullptr, RH_ERR_HIP, "context setup failed: %s", hipGetErrorString(hipGetLastError()));
@@ -325,7 +419,7 @@ void rh_destroy(rh_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    void* bufs[] = {c->d_seq, c->d_n, c->d_mctab, c->d_f5, c->d_bp, c->d_up, c->d_dxtab, c->d_hp, c->d_logz, c->d_scal, c->d_model};
+    void* bufs[] = {c->d_seq, c->d_n, c->d_mctab, c->d_f5, c->d_bp, c->d_up, c->d_dxtab, c->d_hp, c->d_logz, c->d_scal, c->d_mclogz, c->d_bad, c->d_model, c->d_lin};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->s_mc) (void)hipStreamDestroy(c->s_mc);
@@ -431,7 +525,7 @@ int rh_batch_logz(rh_ctx* c, double* out)
     if (!c->computed || !c->has_mc || !c->has_dx || !out) return fail(c, RH_ERR_ARG, "no computed pair batch");
     int rc;
     if ((rc = ensure(c, &c->d_scal, &c->cap_scal, sizeof(double) * 3 * c->np, false))) return rc;
-    hipLaunchKernelGGL(collect_logz, dim3((c->np + 63) / 64), dim3(64), 0, c->s_mc, c->mc, c->dx, (double*)c->d_scal);
+    hipLaunchKernelGGL(collect_logz, dim3((c->np + 63) / 64), dim3(64), 0, c->s_mc, (const double*)c->d_mclogz, c->dx, (double*)c->d_scal);
     HIP_TRY(c, hipMemcpyAsync(out, c->d_scal, sizeof(double) * 3 * c->np, hipMemcpyDeviceToHost, c->s_mc));
     HIP_TRY(c, hipStreamSynchronize(c->s_mc));
     return RH_OK;
@@ -473,6 +567,16 @@ int rh_batch_candidates(rh_ctx* c, int p, int which, float threshold, rh_cand* o
     }
     return found;
 }
+
+int rh_set_mode(rh_ctx* c, int mode)
+{
+    if (!c) return RH_ERR_ARG;
+    if (mode < RH_MODE_AUTO || mode > RH_MODE_LINEAR) return fail(c, RH_ERR_ARG, "unknown mode %d", mode);
+    c->mode = mode;
+    return RH_OK;
+}
+
+int rh_last_path(const rh_ctx* c) { return c ? c->last_path : RH_ERR_ARG; }
 
 int rh_batch_timings(rh_ctx* c, double ms[4], int n_launch[3])
 {

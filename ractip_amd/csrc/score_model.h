@@ -8,10 +8,11 @@
 // sentinels (code 4 at positions 0 and n+1) make the edge conditions of
 // ScoreJunctionA (ipp:1927-1956) fall out without branches.
 //
-// The single-branch loop shapes (l1,l2) are flattened into "combo" lists sorted by
-// total length so that the shapes valid for a span form a prefix:
-//   McCaskill: l1+l2 <= 30 (496 shapes, ipp:3601-3606)
-//   duplex   : l1 <= 29, l1+l2 <= 28 (435 shapes, DuplexEngine.ipp:1038-1042)
+// The single-branch loop shapes (l1,l2) are flattened row-major (l1 major, l2 minor) so
+// that consecutive lanes gather consecutive columns of one table row (coalesced), and
+// padded to a multiple of 64 with never-valid shapes:
+//   McCaskill: l1+l2 <= 30 (496 shapes -> 512, ipp:3601-3606)
+//   duplex   : l1+l2 <= 28 (435 shapes -> 448, DuplexEngine.ipp:1038-1042)
 #pragma once
 #include <stdint.h>
 
@@ -21,8 +22,15 @@ namespace rh {
 
 constexpr int kMaxSingle = 30;   // Config.hpp:213
 constexpr int kMinHairpin = 3;   // Config.hpp:212
-constexpr int kMcCombos = 496;
-constexpr int kDxCombos = 435;
+constexpr int kMcShapes = 512;   // 496 real
+constexpr int kDxShapes = 448;   // 435 real
+constexpr int kMcShapeIters = kMcShapes / 64;
+constexpr int kDxShapeIters = kDxShapes / 64;
+
+struct alignas(16) Shape {      // 16 bytes: one dwordx4 load
+    double score;   // cache_score_single[l1][l2] (McCaskill; 0 for the duplex, which has no length term)
+    int l1, l2;     // padding entries carry l1 = l2 = 1000
+};
 
 struct ScoreModel {
     double base_pair[25];         // [a*5+b]
@@ -37,12 +45,15 @@ struct ScoreModel {
     double helix_stacking[625];
     double multi_base, multi_unpaired, multi_paired;
     double external_unpaired, external_paired;
-    double pad_[3];
+    double pad_[4];   // keeps the shape tables 16-byte aligned
     // flattened single-branch shapes
-    double mc_combo_score[kMcCombos];   // cache_score_single[l1][l2]
-    uint16_t mc_combo_len[kMcCombos];   // l1 | l2<<8
-    uint16_t dx_combo_len[kDxCombos + 1];
+    Shape mc_shape[kMcShapes];
+    Shape dx_shape[kDxShapes];
+    int mc_iter_l1[kMcShapeIters];   // l1 of the first shape of each 64-wide iteration (early exit)
+    int dx_iter_l1[kDxShapeIters];
 };
+
+static_assert(sizeof(Shape) == 16, "Shape must be one 16-byte load");
 
 // host: parse a CONTRAfold "name value" file and bind it (param_loader.cpp)
 bool load_score_model(const char* path, ScoreModel* out, char* err, int errlen);

@@ -15,7 +15,7 @@ RH_MODEL_CONTRAFOLD = 0
 RH_MODEL_VIENNA_BL = 1
 
 EXPORTS = [
-    "rh_create", "rh_destroy", "rh_last_error", "rh_bpp", "rh_unpaired", "rh_fold", "rh_duplex",
+    "rh_create", "rh_destroy", "rh_last_error", "rh_set_mode", "rh_last_path", "rh_bpp", "rh_unpaired", "rh_fold", "rh_duplex",
     "rh_batch_upload", "rh_batch_compute", "rh_batch_results", "rh_batch_candidates",
     "rh_batch_timings", "rh_batch_device_views", "rh_batch_logz",
 ]
@@ -48,6 +48,10 @@ def load_library():
     L.rh_destroy.argtypes = [vp]
     L.rh_last_error.restype = cp
     L.rh_last_error.argtypes = [vp]
+    L.rh_set_mode.argtypes = [vp, ci]
+    L.rh_set_mode.restype = ci
+    L.rh_last_path.argtypes = [vp]
+    L.rh_last_path.restype = ci
     L.rh_bpp.argtypes = [vp, cp, ci, cp, vp, vp]
     L.rh_unpaired.argtypes = [vp, cp, ci, ci, vp]
     L.rh_fold.argtypes = [vp, cp, ci, vp, vp, vp]
@@ -99,6 +103,13 @@ class Context:
         if rc < 0:
             raise RhError("ractip_hot error %d: %s" % (rc, self.L.rh_last_error(self.h).decode()))
         return rc
+
+    def set_mode(self, mode):
+        """0 = auto (linear, log-space fallback), 1 = log-space, 2 = linear only."""
+        self._check(self.L.rh_set_mode(self.h, mode))
+
+    def last_path(self):
+        return self.L.rh_last_path(self.h)
 
     # ---- single-problem calls
     def bpp(self, seq):

@@ -150,6 +150,23 @@ def test_properties_full_size(ctx):
     assert abs(r["logZ"][0] - 258.796119) < 1e-5  # SURVEY 8c known answer, InferenceEngine<double>, n=2000
 
 
+def test_linear_path_is_taken_and_falls_back_on_overflow(ctx, oracle):
+    """Ordinary inputs run on the linear fast path; a long perfect GC helix drives the scaled
+    partition function out of the double range, which must be detected and recomputed in log space."""
+    if ctx.path_name != "auto":
+        pytest.skip("fallback logic belongs to the auto path")
+    s1, s2 = random_pair(300)
+    ctx.batch_upload([(s1, s2)])
+    ctx.batch_compute()
+    assert ctx.last_path() == 1
+    helix = "G" * 700 + "AAAA" + "C" * 700          # log Z ~ 1.5 per nucleotide >> the scale exponent
+    bp, z = ctx.bpp(helix)
+    assert ctx.last_path() == 3
+    o = oracle.inference(helix)
+    assert abs(z - o["logZ"]) < 1e-7 * abs(o["logZ"])
+    assert_prob_close(bp, o["post"], rel=REL, what="GC helix via fallback")
+
+
 def test_errors_are_reported_not_swallowed(ctx):
     import ractip_amd
     with pytest.raises(ractip_amd.RhError):
