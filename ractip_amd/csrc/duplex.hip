@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void dx_sweep_diag(DxBatch B, const ScoreModel
     const int pr = blockIdx.y;
     const int L1 = B.n[2 * pr], L2 = B.n[2 * pr + 1];
     const int lane = threadIdx.x & 63;
-    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int w = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform
     const bool outside = blockIdx.z != 0;
     const int s0 = outside ? (L1 + L2) - 2 * t - 1 : 2 + 2 * t;
     if (s0 + 1 < 2 || s0 > L1 + L2) return;

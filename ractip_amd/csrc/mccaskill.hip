@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void mc_inside_diag(McBatch B, const ScoreMode
     block_map(pin, &sq, &slot);
     if (sq >= B.ns) return;
     const int n = B.n[sq];
-    const int wave = slot * 4 + (threadIdx.x >> 6);
+    const int wave = slot * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: lets the cell's scores use scalar loads
     const int lane = threadIdx.x & 63;
     const int ncell = n - 1 - d > 0 ? n - 1 - d : 0;
     if (d > n - 1 || wave > ncell) return;
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void mc_outside_diag(McBatch B, const ScoreMod
     block_map(pin, &sq, &slot);
     if (sq >= B.ns) return;
     const int n = B.n[sq];
-    const int wave = slot * 4 + (threadIdx.x >> 6);
+    const int wave = slot * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: lets the cell's scores use scalar loads
     const int lane = threadIdx.x & 63;
     const int ncell = n - 1 - d;
     if (ncell < 1 || wave > ncell) return;

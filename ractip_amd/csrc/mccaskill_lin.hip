@@ -72,7 +72,7 @@ __global__ __launch_bounds__(64 * W) void lin_inside_diag(McBatch B, const LinMo
     const int ncell = n - 1 - d > 0 ? n - 1 - d : 0;
     const int ngroup = (ncell + 63) >> 6;
     if (slot > ngroup) return;
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // w is wave-uniform: scalar loads/addressing
     const int ld = B.ld;
     const size_t ts = B.tab_stride;
     const uint8_t* __restrict__ s = B.seq + (size_t)sq * B.lds;
@@ -81,13 +81,20 @@ __global__ __launch_bounds__(64 * W) void lin_inside_diag(McBatch B, const LinMo
 
     if (slot == ngroup) {
         // F5i[jj] = F5i[jj-1]*ext_unpaired + sum_{k<=jj-2} F5i[k]*FCA[k+1,jj-1]*ext_paired   (ipp:3692-3717)
-        if (w != 0) return;
+        // all W wavefronts: the column of FCA is an anti-diagonal of the diagonal-major table (one line per term)
         const int jj = d + 1;
         const double* __restrict__ fca = tab + L_FCA * ts;
         double acc = 0.0;
-        for (int k = lane; k <= jj - 2; k += 64) acc += f5i[k] * fca[(size_t)(jj - 2 - k) * ld + (k + 1)];
+        for (int k = threadIdx.x; k <= jj - 2; k += 64 * W) acc = fma(f5i[k], fca[(size_t)(jj - 2 - k) * ld + (k + 1)], acc);
         acc = wsum(acc);
-        if (lane == 0) f5i[jj] = f5i[jj - 1] * L->w_eu + acc * L->w_ep2;
+        if (lane == 0) part[0][w][0] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+#pragma unroll
+            for (int k = 0; k < W; k++) t += part[0][k][0];
+            f5i[jj] = f5i[jj - 1] * L->w_eu + t * L->w_ep2;
+        }
         return;
     }
 
@@ -97,45 +104,86 @@ __global__ __launch_bounds__(64 * W) void lin_inside_diag(McBatch B, const LinMo
     if (valid) { s_im1 = s[i - 1]; s_i = s[i]; s_ip1 = s[i + 1]; s_j = s[j]; s_jp1 = s[j + 1]; s_jp2 = s[j + 2]; }
     const bool pairable = valid && pairs(s_i, s_jp1);
 
+    // epilogue operands (wave 0 only): issued now so that their latency hides behind the term loops
+    const size_t at = (size_t)d * ld + i;
+    const int idx = 25 * (5 * s_i + s_ip1) + 5 * s_jp1 + s_j;       // (i,j)   as enclosing pair
+    const int idd = 25 * (5 * s_jp1 + s_jp2) + 5 * s_i + s_im1;     // (j+1,i-1) as enclosed pair
+    double e_tjb = 0, e_tja = 0, e_tst = 0, e_bp = 0, e_tjbd = 0, e_tjad = 0, e_n01 = 0, e_n10 = 0, e_n11 = 0;
+    double o_x01 = 0, o_x10 = 0, o_x11 = 0, o_fc = 0, o_fca = 0, o_fm1 = 0, o_fm = 0;
+    if (w == 0 && valid) {
+        e_tjb = L->TJB[idx]; e_tja = L->TJA[idx]; e_tst = L->TST[idx]; e_bp = L->E_bp[s_i * 5 + s_jp1];
+        e_tjbd = L->TJB[idd]; e_tjad = L->TJA[idd];
+        e_n01 = L->E_b01[s_j]; e_n10 = L->E_b10[s_ip1]; e_n11 = L->E_11[s_ip1 * 5 + s_j];
+        if (d >= 3) {
+            const double* __restrict__ fcx = tab + L_FCX * ts;
+            o_x01 = fcx[(size_t)(d - 3) * ld + i + 1];
+            o_x10 = fcx[(size_t)(d - 3) * ld + i + 2];
+            if (d >= 4) o_x11 = fcx[(size_t)(d - 4) * ld + i + 2];
+        }
+        if (d >= 2) {
+            o_fc = tab[L_FC * ts + (size_t)(d - 2) * ld + i + 1];
+            o_fca = tab[L_FCA * ts + (size_t)(d - 2) * ld + i + 1];
+            o_fm1 = tab[L_FM1 * ts + (size_t)(d - 1) * ld + i + 1];
+            o_fm = tab[L_FM * ts + (size_t)(d - 1) * ld + i];
+        }
+    }
+
     // ---- FM2[i,d] = sum_{m=1}^{d-1} FM1[m][i] * FM[d-m][i+m]          (ipp:3384-3411)
     double acc2 = 0.0;
+#ifndef RH_EXP_NOFM2
     if (valid) {
         const double* __restrict__ fm1 = tab + L_FM1 * ts + i;
         const double* __restrict__ fm = tab + L_FM * ts + i;
         int m = 1 + w;
-        for (; m + 3 * W <= d - 1; m += 4 * W) {
-            const double a0 = fm1[(size_t)m * ld], a1 = fm1[(size_t)(m + W) * ld], a2 = fm1[(size_t)(m + 2 * W) * ld],
-                         a3 = fm1[(size_t)(m + 3 * W) * ld];
-            const double b0 = fm[(size_t)(d - m) * ld + m], b1 = fm[(size_t)(d - m - W) * ld + m + W],
-                         b2 = fm[(size_t)(d - m - 2 * W) * ld + m + 2 * W], b3 = fm[(size_t)(d - m - 3 * W) * ld + m + 3 * W];
-            acc2 = fma(a0, b0, acc2); acc2 = fma(a1, b1, acc2); acc2 = fma(a2, b2, acc2); acc2 = fma(a3, b3, acc2);
+        constexpr int UF = 8;  // 2*UF row segments (512 B each) in flight per wavefront
+        for (; m + (UF - 1) * W <= d - 1; m += UF * W) {
+            double a[UF], b[UF];
+#pragma unroll
+            for (int u = 0; u < UF; u++) {
+                a[u] = fm1[(size_t)(m + u * W) * ld];
+                b[u] = fm[(size_t)(d - m - u * W) * ld + m + u * W];
+            }
+#pragma unroll
+            for (int u = 0; u < UF; u++) acc2 = fma(a[u], b[u], acc2);
         }
         for (; m <= d - 1; m += W) acc2 = fma(fm1[(size_t)m * ld], fm[(size_t)(d - m) * ld + m], acc2);
     }
+#endif
 
     // ---- generic single-branch shapes of FC[i,d]: sum_c w_c * FCX[d-2-t][i+1+l1]   (ipp:3597-3619)
     double accc = 0.0;
+#ifndef RH_EXP_NOGATHER
     if (d >= 2) {
         const int tmax = d - 2 < kMaxSingle ? d - 2 : kMaxSingle;
         const int cnt = L->shape_cnt[tmax];
         const double* __restrict__ fcx = tab + L_FCX * ts + (i + 1);
-        int c = w;
-        for (; c + 3 * W < cnt; c += 4 * W) {
-            double v[4];
+        // each wavefront takes a contiguous chunk of the shape list (its l1/l2/weight entries are then
+        // adjacent: wide scalar loads); lanes of non-pairable cells read element 0 and are masked out
+        const int chunk = (cnt + W - 1) / W;
+        const int c1 = (w + 1) * chunk < cnt ? (w + 1) * chunk : cnt;
+        const double keep = pairable ? 1.0 : 0.0;
+        const int dm2 = pairable ? d - 2 : 0;
+        int c = w * chunk;
+        constexpr int UG = 8;
+        for (; c + UG <= c1; c += UG) {
+            double v[UG];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int l1 = L->shape_l1[c + u * W], l2 = L->shape_l2[c + u * W];
-                v[u] = pairable ? fcx[(size_t)(d - 2 - l1 - l2) * ld + l1] : 0.0;
+            for (int u = 0; u < UG; u++) {
+                const int l1 = L->shape_l1[c + u], l2 = L->shape_l2[c + u];
+                const int row = pairable ? dm2 - l1 - l2 : 0;
+                v[u] = fcx[(size_t)row * ld + (pairable ? l1 : 0)];
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++) accc = fma(L->shape_w[c + u * W], v[u], accc);
+            for (int u = 0; u < UG; u++) accc = fma(L->shape_w[c + u], v[u], accc);
         }
-        for (; c < cnt; c += W) {
+        for (; c < c1; c++) {
             const int l1 = L->shape_l1[c], l2 = L->shape_l2[c];
-            const double v = pairable ? fcx[(size_t)(d - 2 - l1 - l2) * ld + l1] : 0.0;
-            accc = fma(L->shape_w[c], v, accc);
+            const int row = pairable ? dm2 - l1 - l2 : 0;
+            accc = fma(L->shape_w[c], fcx[(size_t)row * ld + (pairable ? l1 : 0)], accc);
         }
+        accc *= keep;
     }
+#endif
 
     part[0][w][lane] = acc2;
     part[1][w][lane] = accc;
@@ -145,30 +193,21 @@ __global__ __launch_bounds__(64 * W) void lin_inside_diag(McBatch B, const LinMo
 #pragma unroll
     for (int k = 0; k < W; k++) { fm2 += part[0][k][lane]; g += part[1][k][lane]; }
 
-    const size_t at = (size_t)d * ld + i;
-    const int idx = 25 * (5 * s_i + s_ip1) + 5 * s_jp1 + s_j;       // (i,j)   as enclosing pair
-    const int idd = 25 * (5 * s_jp1 + s_jp2) + 5 * s_i + s_im1;     // (j+1,i-1) as enclosed pair
     double fc = 0.0;
     if (pairable) {
-        double sp = 0.0, st = 0.0, hp = 0.0;
-        if (d >= 3) {
-            const double* __restrict__ fcx = tab + L_FCX * ts;
-            sp = L->w01 * L->E_b01[s_j] * fcx[(size_t)(d - 3) * ld + i + 1] + L->w10 * L->E_b10[s_ip1] * fcx[(size_t)(d - 3) * ld + i + 2];
-            if (d >= 4) sp += L->w11 * L->E_11[s_ip1 * 5 + s_j] * fcx[(size_t)(d - 4) * ld + i + 2];
-            hp = lam_d * L->E_hairpin[d < 30 ? d : 30];               // ScoreHairpin (ipp:2123-2152)
-        }
-        if (d >= 2) st = tab[L_FC * ts + (size_t)(d - 2) * ld + i + 1] * L->lam2 * L->TST[idx];
-        fc = L->TJB[idx] * (g + sp + hp) + st + fm2 * L->TJA[idx] * L->e_mpmb;   // ipp:3573-3622
+        const double sp = L->w01 * e_n01 * o_x01 + L->w10 * e_n10 * o_x10 + L->w11 * e_n11 * o_x11;
+        const double hp = d >= 3 ? lam_d * L->E_hairpin[d < 30 ? d : 30] : 0.0;   // ScoreHairpin (ipp:2123-2152)
+        const double st = o_fc * L->lam2 * e_tst;                                  // stacking pair (ipp:3595)
+        fc = e_tjb * (g + sp + hp) + st + fm2 * e_tja * L->e_mpmb;                 // ipp:3573-3622
     }
     double fm1v = 0.0, fmv = 0.0;
-    if (d >= 2) {                                                     // ipp:3641-3688
-        fm1v = tab[L_FCA * ts + (size_t)(d - 2) * ld + i + 1] * L->w_mp2 + tab[L_FM1 * ts + (size_t)(d - 1) * ld + i + 1] * L->w_mu;
-        fmv = fm2 + tab[L_FM * ts + (size_t)(d - 1) * ld + i] * L->w_mu + fm1v;
+    if (d >= 2) {                                                                  // ipp:3641-3688
+        fm1v = o_fca * L->w_mp2 + o_fm1 * L->w_mu;
+        fmv = fm2 + o_fm * L->w_mu + fm1v;
     }
-    const double ebp = L->E_bp[s_i * 5 + s_jp1];
     tab[L_FC * ts + at] = fc;
-    tab[L_FCX * ts + at] = fc * ebp * L->TJB[idd];
-    tab[L_FCA * ts + at] = fc * ebp * L->TJA[idd];
+    tab[L_FCX * ts + at] = fc * e_bp * e_tjbd;
+    tab[L_FCA * ts + at] = fc * e_bp * e_tjad;
     tab[L_FM1 * ts + at] = fm1v;
     tab[L_FM * ts + at] = fmv;
 }
@@ -187,7 +226,7 @@ __global__ __launch_bounds__(64 * W) void lin_outside_diag(McBatch B, const LinM
     if (ncell < 1) return;
     const int ngroup = (ncell + 63) >> 6;
     if (slot > ngroup) return;
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // w is wave-uniform: scalar loads/addressing
     const int ld = B.ld;
     const size_t ts = B.tab_stride;
     const uint8_t* __restrict__ s = B.seq + (size_t)sq * B.lds;
@@ -197,13 +236,19 @@ __global__ __launch_bounds__(64 * W) void lin_outside_diag(McBatch B, const LinM
 
     if (slot == ngroup) {
         // F5o[k] = F5o[k+1]*ext_unpaired + sum_{jj>=k+2} F5o[jj]*FCA[k+1,jj-1]*ext_paired   (ipp:3751-3780, pulled)
-        if (w != 0) return;
         const int k = d + 1;
         const double* __restrict__ fca = tab + L_FCA * ts + (k + 1);
         double acc = 0.0;
-        for (int jj = k + 2 + lane; jj <= n; jj += 64) acc += f5o[jj] * fca[(size_t)(jj - 2 - k) * ld];
+        for (int jj = k + 2 + threadIdx.x; jj <= n; jj += 64 * W) acc = fma(f5o[jj], fca[(size_t)(jj - 2 - k) * ld], acc);
         acc = wsum(acc);
-        if (lane == 0) f5o[k] = f5o[k + 1] * L->w_eu + acc * L->w_ep2;
+        if (lane == 0) part[0][w][0] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+#pragma unroll
+            for (int q = 0; q < W; q++) t += part[0][q][0];
+            f5o[k] = f5o[k + 1] * L->w_eu + t * L->w_ep2;
+        }
         return;
     }
 
@@ -215,6 +260,34 @@ __global__ __launch_bounds__(64 * W) void lin_outside_diag(McBatch B, const LinM
     const bool pairable = valid && pairs(s_i, s_jp1);
     const bool guard_m = d >= 2;
 
+    // epilogue operands (wave 0 only), issued ahead of the term loops
+    const size_t at = (size_t)d * ld + i;
+    const bool up_ok = i - 1 >= 1 && j + 1 <= n - 1;  // the cell (i-1, j+1) is interior
+    const int idx = 25 * (5 * s_i + s_ip1) + 5 * s_jp1 + s_j;
+    const int idd = 25 * (5 * s_jp1 + s_jp2) + 5 * s_i + s_im1;
+    double e_tjb = 0, e_tja = 0, e_tst = 0, e_bp = 0, e_tjbd = 0, e_tjad = 0, e_n01 = 0, e_n10 = 0, e_n11 = 0;
+    double o_fmo = 0, o_fm1o = 0, o_f5o = 0, o_f5i = 0, o_fm1o_up = 0, o_fco_up = 0, o_x01 = 0, o_x10 = 0, o_x11 = 0, o_fc = 0, o_z = 1;
+    if (w == 0 && valid) {
+        e_tjb = L->TJB[idx]; e_tja = L->TJA[idx]; e_bp = L->E_bp[s_i * 5 + s_jp1];
+        e_tjbd = L->TJB[idd]; e_tjad = L->TJA[idd];
+        e_tst = L->TST[25 * (5 * s_im1 + s_i) + 5 * s_jp2 + s_jp1];
+        e_n01 = L->E_b01[s_jp2]; e_n10 = L->E_b10[s_im1]; e_n11 = L->E_11[s_im1 * 5 + s_jp2];
+        if (guard_m) {
+            if (j + 1 <= n - 1) o_fmo = tab[L_FMO * ts + (size_t)(d + 1) * ld + i];            // ipp:3806
+            if (i - 1 >= 1) o_fm1o = tab[L_FM1O * ts + (size_t)(d + 1) * ld + i - 1];            // ipp:3833
+        }
+        o_f5o = f5o[j + 1]; o_f5i = f5i[i - 1]; o_z = f5i[n];
+        o_fc = tab[L_FC * ts + at];
+        const double* __restrict__ fcox = tab + L_FCOX * ts;
+        if (up_ok) {
+            o_fm1o_up = tab[L_FM1O * ts + (size_t)(d + 2) * ld + i - 1];                         // ipp:3828
+            o_fco_up = tab[L_FCO * ts + (size_t)(d + 2) * ld + i - 1];
+        }
+        if (i - 1 >= 1 && j + 2 <= n - 1) o_x01 = fcox[(size_t)(d + 3) * ld + i - 1];
+        if (i - 2 >= 1 && j + 1 <= n - 1) o_x10 = fcox[(size_t)(d + 3) * ld + i - 2];
+        if (i - 2 >= 1 && j + 2 <= n - 1) o_x11 = fcox[(size_t)(d + 4) * ld + i - 2];
+    }
+
     double accm = 0.0, acc1 = 0.0, accc = 0.0;
     if (guard_m) {
         // FMo[i,d] += FM2o[d+e][i-e] * FM1[e][i-e], e = 1..i-1            (ipp:4046-4064, pulled)
@@ -225,11 +298,18 @@ __global__ __launch_bounds__(64 * W) void lin_outside_diag(McBatch B, const LinM
             const double* __restrict__ y = tab + L_FM1 * ts + i;
             const int mine = valid ? i - 1 : 0;
             int e = 1 + w;
-            for (; e + W <= emax; e += 2 * W) {
-                const bool p0 = e <= mine, p1 = e + W <= mine;
-                const double x0 = p0 ? x[(size_t)(d + e) * ld - e] : 0.0, y0 = p0 ? y[(size_t)e * ld - e] : 0.0;
-                const double x1 = p1 ? x[(size_t)(d + e + W) * ld - e - W] : 0.0, y1 = p1 ? y[(size_t)(e + W) * ld - e - W] : 0.0;
-                accm = fma(x0, y0, accm); accm = fma(x1, y1, accm);
+            constexpr int UO = 6;
+            for (; e + (UO - 1) * W <= emax; e += UO * W) {
+                double xv[UO], yv[UO];
+#pragma unroll
+                for (int u = 0; u < UO; u++) {
+                    const int ee = e + u * W;
+                    const bool ok = ee <= mine;
+                    xv[u] = ok ? x[(size_t)(d + ee) * ld - ee] : 0.0;
+                    yv[u] = ok ? y[(size_t)ee * ld - ee] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < UO; u++) accm = fma(xv[u], yv[u], accm);
             }
             for (; e <= emax; e += W)
                 if (e <= mine) accm = fma(x[(size_t)(d + e) * ld - e], y[(size_t)e * ld - e], accm);
@@ -241,11 +321,18 @@ __global__ __launch_bounds__(64 * W) void lin_outside_diag(McBatch B, const LinM
             const double* __restrict__ y = tab + L_FM * ts + j;
             const int mine = valid ? n - 1 - j : 0;
             int e = 1 + w;
-            for (; e + W <= emax; e += 2 * W) {
-                const bool p0 = e <= mine, p1 = e + W <= mine;
-                const double x0 = p0 ? x[(size_t)(d + e) * ld] : 0.0, y0 = p0 ? y[(size_t)e * ld] : 0.0;
-                const double x1 = p1 ? x[(size_t)(d + e + W) * ld] : 0.0, y1 = p1 ? y[(size_t)(e + W) * ld] : 0.0;
-                acc1 = fma(x0, y0, acc1); acc1 = fma(x1, y1, acc1);
+            constexpr int UO = 6;
+            for (; e + (UO - 1) * W <= emax; e += UO * W) {
+                double xv[UO], yv[UO];
+#pragma unroll
+                for (int u = 0; u < UO; u++) {
+                    const int ee = e + u * W;
+                    const bool ok = ee <= mine;
+                    xv[u] = ok ? x[(size_t)(d + ee) * ld] : 0.0;
+                    yv[u] = ok ? y[(size_t)ee * ld] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < UO; u++) acc1 = fma(xv[u], yv[u], acc1);
             }
             for (; e <= emax; e += W)
                 if (e <= mine) acc1 = fma(x[(size_t)(d + e) * ld], y[(size_t)e * ld], acc1);
@@ -257,11 +344,28 @@ __global__ __launch_bounds__(64 * W) void lin_outside_diag(McBatch B, const LinM
             const int tmax = room < kMaxSingle ? room : kMaxSingle;
             const int cnt = L->shape_cnt[tmax];
             const double* __restrict__ fcox = tab + L_FCOX * ts + (i - 1);
-            for (int c = w; c < cnt; c += W) {
+            const int chunk = (cnt + W - 1) / W;
+            const int c1 = (w + 1) * chunk < cnt ? (w + 1) * chunk : cnt;
+            const int l1cap = pairable ? i - 2 : -1, l2cap = n - 2 - j;
+            int c = w * chunk;
+            constexpr int UG = 8;
+            for (; c + UG <= c1; c += UG) {
+                double v[UG];
+#pragma unroll
+                for (int u = 0; u < UG; u++) {
+                    const int l1 = L->shape_l1[c + u], l2 = L->shape_l2[c + u];
+                    const bool ok = l1 <= l1cap && l2 <= l2cap;
+                    const double x = fcox[ok ? (size_t)(d + 2 + l1 + l2) * ld - l1 : (size_t)1];
+                    v[u] = ok ? x : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < UG; u++) accc = fma(L->shape_w[c + u], v[u], accc);
+            }
+            for (; c < c1; c++) {
                 const int l1 = L->shape_l1[c], l2 = L->shape_l2[c];
-                const bool ok = pairable && l1 <= i - 2 && j + 1 + l2 <= n - 1;
-                const double v = ok ? fcox[(size_t)(d + 2 + l1 + l2) * ld - l1] : 0.0;
-                accc = fma(L->shape_w[c], v, accc);
+                const bool ok = l1 <= l1cap && l2 <= l2cap;
+                const double x = fcox[ok ? (size_t)(d + 2 + l1 + l2) * ld - l1 : (size_t)1];
+                accc = fma(L->shape_w[c], ok ? x : 0.0, accc);
             }
         }
     }
@@ -274,36 +378,27 @@ __global__ __launch_bounds__(64 * W) void lin_outside_diag(McBatch B, const LinM
 #pragma unroll
     for (int k = 0; k < W; k++) { sm += part[0][k][lane]; s1 += part[1][k][lane]; g += part[2][k][lane]; }
 
-    const size_t at = (size_t)d * ld + i;
-    const bool up_ok = i - 1 >= 1 && j + 1 <= n - 1;  // the cell (i-1, j+1) is interior
     double fmo = 0.0, fm1o = 0.0;
     if (guard_m) {
-        fmo = sm + (j + 1 <= n - 1 ? tab[L_FMO * ts + (size_t)(d + 1) * ld + i] * L->w_mu : 0.0);       // ipp:3806
-        fm1o = s1 + fmo + (i - 1 >= 1 ? tab[L_FM1O * ts + (size_t)(d + 1) * ld + i - 1] * L->w_mu : 0.0); // ipp:3809, 3833
+        fmo = sm + o_fmo * L->w_mu;                   // ipp:3806
+        fm1o = s1 + fmo + o_fm1o * L->w_mu;           // ipp:3809, 3833
     }
-    const int idx = 25 * (5 * s_i + s_ip1) + 5 * s_jp1 + s_j;
     double fco = 0.0;
     if (pairable) {
-        const int idd = 25 * (5 * s_jp1 + s_jp2) + 5 * s_i + s_im1;
-        const double ebp = L->E_bp[s_i * 5 + s_jp1];
-        const double ext = f5o[j + 1] * f5i[i - 1] * L->w_ep2;                                        // ipp:3768-3776
-        const double multi = up_ok ? tab[L_FM1O * ts + (size_t)(d + 2) * ld + i - 1] * L->w_mp2 : 0.0;  // ipp:3828
-        double sp = 0.0, st = 0.0;
-        const double* __restrict__ fcox = tab + L_FCOX * ts;
-        if (i - 1 >= 1 && j + 2 <= n - 1) sp += L->w01 * L->E_b01[s_jp2] * fcox[(size_t)(d + 3) * ld + i - 1];
-        if (i - 2 >= 1 && j + 1 <= n - 1) sp += L->w10 * L->E_b10[s_im1] * fcox[(size_t)(d + 3) * ld + i - 2];
-        if (i - 2 >= 1 && j + 2 <= n - 1) sp += L->w11 * L->E_11[s_im1 * 5 + s_jp2] * fcox[(size_t)(d + 4) * ld + i - 2];
-        if (up_ok) st = tab[L_FCO * ts + (size_t)(d + 2) * ld + i - 1] * L->lam2 * L->TST[25 * (5 * s_im1 + s_i) + 5 * s_jp2 + s_jp1];
-        fco = ebp * (L->TJA[idd] * (ext + multi) + L->TJB[idd] * (g + sp)) + st;
+        const double ext = o_f5o * o_f5i * L->w_ep2;  // exterior loop, ipp:3768-3776
+        const double multi = o_fm1o_up * L->w_mp2;    // branch of a multiloop, ipp:3828
+        const double sp = L->w01 * e_n01 * o_x01 + L->w10 * e_n10 * o_x10 + L->w11 * e_n11 * o_x11;
+        const double st = o_fco_up * L->lam2 * e_tst; // stacked on (i-1,j+1)
+        fco = e_bp * (e_tjad * (ext + multi) + e_tjbd * (g + sp)) + st;
     }
-    const double fm2o = fmo + fco * L->TJA[idx] * L->e_mpmb;                                          // ipp:3803, 4027
+    const double fm2o = fmo + fco * e_tja * L->e_mpmb;                                                // ipp:3803, 4027
     tab[L_FCO * ts + at] = fco;
-    tab[L_FCOX * ts + at] = fco * L->TJB[idx];
+    tab[L_FCOX * ts + at] = fco * e_tjb;
     tab[L_FMO * ts + at] = fmo;
     tab[L_FM1O * ts + at] = fm1o;
     tab[L_FM2O * ts + at] = fm2o;
     // posterior of pair (i, j+1) = FCo * FCi / Z, clipped to [0,1]                 (ipp:4689-4827)
-    double p = fco * tab[L_FC * ts + at] / f5i[n];
+    double p = fco * o_fc / o_z;
     if (!(p == p) || p > 1e300) { atomicOr(&bad[sq], 1); p = 0.0; }
     p = p > 1.0 ? 1.0 : (p < 0.0 ? 0.0 : p);
     B.bp[(size_t)sq * B.tri_stride + tri_off(n, i) + (j + 1)] = p;

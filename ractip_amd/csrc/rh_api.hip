@@ -286,8 +286,11 @@ int compute(rh_ctx* c)
     const int pin = (c->has_mc && c->mc.ns % 8 == 0) ? 1 : 0;
     int rc;
     // duplex first on its own stream: it is independent of the McCaskill sweeps and overlaps them
+    // RH_EXP_SKIP=dx|mc: timing experiments only (results of the skipped engine are stale)
+    const char* skip = std::getenv("RH_EXP_SKIP");
+    const bool skip_dx = skip && !std::strcmp(skip, "dx"), skip_mc = skip && !std::strcmp(skip, "mc");
     HIP_TRY(c, hipEventRecord(c->ev[3], c->s_dx));
-    if (c->has_dx) {
+    if (c->has_dx && !skip_dx) {
         const DxBatch& D = c->dx;
         const int smax = D.n1max + D.n2max;
         const int steps = smax / 2;
@@ -303,8 +306,8 @@ int compute(rh_ctx* c)
     HIP_TRY(c, hipEventRecord(c->ev[4], c->s_dx));
 
     HIP_TRY(c, hipEventRecord(c->ev[0], c->s_mc));
-    bool need_log = c->has_mc && c->mode == RH_MODE_LOG;
-    if (c->has_mc && c->mode != RH_MODE_LOG) {
+    bool need_log = c->has_mc && c->mode == RH_MODE_LOG && !skip_mc;
+    if (c->has_mc && c->mode != RH_MODE_LOG && !skip_mc) {
         if ((rc = launch_mc_lin_any(c, pin))) return rc;
         c->last_path = 1;
         if (c->mode == RH_MODE_AUTO) {  // did every sequence stay inside the double range?
