@@ -92,12 +92,12 @@ def main():
     ctx = ractip_amd.Context(device=local_rank)
     ctx.batch_upload(pairs)  # sequences -> HBM, tables allocated: outside the timed region
 
+    from ractip_amd import shard
+
     def step():
         ctx.batch_compute()  # all DP kernels, blocks until the device is done
-        if dist is not None:  # z-score gather: 3 doubles per pair (ractip.cpp:1655-1663 needs 2 floats)
-            z = torch.from_numpy(ctx.batch_logz().ravel()).cuda()
-            out = [torch.empty_like(z) for _ in range(world)]
-            dist.all_gather(out, z)
+        if dist is not None:  # the shard's only exchange: per-pair scalars to every rank (ractip.cpp:1655-1663)
+            shard.gather_in_order(ctx.batch_logz(), batch * world, dist, device=torch.device("cuda", local_rank))
 
     def fence():
         if dist is not None:

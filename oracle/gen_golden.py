@@ -110,6 +110,26 @@ out["dx500/idx"] = idx.astype(np.int64)
 out["dx500/val"] = post[idx]
 print("dx500 logZ=%.9f sum=%.9f nnz=%d" % (z2[0], post.sum(), idx.size))
 
+# z-score shuffles: the reference's own ushuffle.c (oracle/_ref/libref_ushuffle.so) driven exactly as
+# src/ractip.cpp:1636-1643 does (srandom(seed); shuffle(s1) then shuffle(s2) per iteration, k=2)
+ush = ctypes.CDLL(os.path.join(here, "_ref", "libref_ushuffle.so"))
+libc = ctypes.CDLL(None)
+ush.shuffle.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
+for tag, a, b, mode, seed, num in (("OxyS+fhlA/12/1", "OxyS", "fhlA", 12, 1, 12), ("DIS+Tar/1/7", "DIS", "Tar", 1, 7, 6),
+                                   ("R1inv+R2inv/2/3", "R1inv", "R2inv", 2, 3, 6), ("rnd2+rnd3/12/5", "rnd2", "rnd3", 12, 5, 4)):
+    s1, s2 = seqs[a], seqs[b]
+    t1, t2 = ctypes.create_string_buffer(s1.encode()), ctypes.create_string_buffer(s2.encode())
+    libc.srandom(seed)
+    rows = []
+    for it in range(num):
+        if mode in (1, 12):
+            ush.shuffle(s1.encode(), t1, len(s1), 2)
+        if mode in (2, 12):
+            ush.shuffle(s2.encode(), t2, len(s2), 2)
+        rows.append(t1.value.decode() + "|" + t2.value.decode())
+    out["zs/%s" % tag] = np.array(rows)
+    print("zs", tag, rows[0][:40])
+
 out["mc_names"] = np.array(names)
 out["dx_names"] = np.array(pnames)
 dst = os.path.join(here, "..", "tests", "golden", "contrafold_golden.npz")

@@ -55,6 +55,75 @@ __global__ void log_finish(McBatch B, double* __restrict__ logz)
     if (sq < B.ns) logz[sq] = B.f5i[(size_t)sq * B.ld + B.n[sq]];
 }
 
+// ---- ordered threshold compaction (the scans of /root/reference/src/ractip.cpp:557-568, 578-589,
+//      598-608, 621-627 done on device): one wavefront per matrix row; probabilities are narrowed
+//      to float BEFORE the comparison, as the reference's VF containers do (src/ractip.cpp:82-83).
+struct CandView {
+    const double* base;
+    int kind;   // 0 = bp triangle (row i: j = i+1..n), 1 = hp matrix (row i: j = 1..n2), 2 = up vector
+    int n, n2, ld;
+};
+struct RowSpan {
+    const double* p;  // row base: element j of the row is p[j]
+    int i, j0, j1;
+    bool ok;
+};
+__device__ __forceinline__ RowSpan cand_row(const double* base, int kind, int n, int n2, int ld, int row)
+{
+    RowSpan r;
+    if (kind == 0) {
+        r.i = row + 1; r.j0 = r.i + 1; r.j1 = n;
+        r.p = base + (size_t)r.i * (size_t)(2 * (n + 1) - r.i - 1) / 2;
+        r.ok = r.i <= n;
+    } else if (kind == 1) {
+        r.i = row + 1; r.j0 = 1; r.j1 = n2;
+        r.p = base + (size_t)r.i * (size_t)ld;
+        r.ok = r.i <= n;
+    } else {
+        r.i = 0; r.j0 = 0; r.j1 = n - 1; r.p = base;
+        r.ok = row == 0;
+    }
+    return r;
+}
+__global__ __launch_bounds__(256) void cand_count(const double* __restrict__ base, int kind, int n, int n2, int ld, float th,
+                                                  int nrows, int* __restrict__ counts)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= nrows) return;
+    const RowSpan r = cand_row(base, kind, n, n2, ld, row);
+    if (!r.ok) return;
+    int c = 0;
+    for (int j = r.j0 + lane; j <= r.j1; j += 64) c += ((float)r.p[j] > th) ? 1 : 0;
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if (lane == 0) counts[row] = c;
+}
+__global__ __launch_bounds__(256) void cand_write(const double* __restrict__ base, int kind, int n, int n2, int ld, float th,
+                                                  int nrows, const int* __restrict__ offsets, rh_cand* __restrict__ out, int cap)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= nrows) return;
+    const RowSpan r = cand_row(base, kind, n, n2, ld, row);
+    if (!r.ok) return;
+    int pos = offsets[row];
+    for (int jb = r.j0; jb <= r.j1; jb += 64) {
+        const int j = jb + lane;
+        const float pf = j <= r.j1 ? (float)r.p[j] : 0.0f;
+        const bool hit = j <= r.j1 && pf > th;
+        const unsigned long long m = __ballot(hit);
+        if (hit) {
+            const int k = pos + __popcll(m & ((1ull << lane) - 1ull));
+            if (k < cap) {
+                rh_cand e;
+                e.i = kind == 2 ? j : r.i;
+                e.j = kind == 2 ? 0 : j;
+                e.p = pf;
+                out[k] = e;
+            }
+        }
+        pos += __popcll(m);
+    }
+}
+
 static thread_local std::string g_create_error;
 
 struct rh_ctx {
@@ -89,6 +158,8 @@ struct rh_ctx {
     void* d_scal = nullptr;  size_t cap_scal = 0;
     void* d_mclogz = nullptr; size_t cap_mclogz = 0;
     void* d_bad = nullptr;   size_t cap_bad = 0;
+    void* d_cnt = nullptr;   size_t cap_cnt = 0;
+    void* d_cand = nullptr;  size_t cap_cand = 0;
     double ms[4] = {0, 0, 0, 0};
     int n_launch[3] = {0, 0, 0};
 };
@@ -422,7 +493,7 @@ void rh_destroy(rh_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    void* bufs[] = {c->d_seq, c->d_n, c->d_mctab, c->d_f5, c->d_bp, c->d_up, c->d_dxtab, c->d_hp, c->d_logz, c->d_scal, c->d_mclogz, c->d_bad, c->d_model, c->d_lin};
+    void* bufs[] = {c->d_seq, c->d_n, c->d_mctab, c->d_f5, c->d_bp, c->d_up, c->d_dxtab, c->d_hp, c->d_logz, c->d_scal, c->d_mclogz, c->d_bad, c->d_cnt, c->d_cand, c->d_model, c->d_lin};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->s_mc) (void)hipStreamDestroy(c->s_mc);
@@ -538,35 +609,40 @@ int rh_batch_candidates(rh_ctx* c, int p, int which, float threshold, rh_cand* o
 {
     if (!c) return RH_ERR_ARG;
     if (!c->computed) return fail(c, RH_ERR_ARG, "no computed batch");
-    if (p < 0 || p >= c->np || which < 0 || which > 4) return fail(c, RH_ERR_ARG, "bad pair/which");
-    // dense fetch + host scan in the reference's order; the on-device compaction replaces this next
-    int found = 0, rc;
+    if (p < 0 || p >= c->np || which < 0 || which > 4 || cap < 0 || (cap > 0 && !out)) return fail(c, RH_ERR_ARG, "bad pair/which/cap");
+    HIP_TRY(c, hipSetDevice(c->device));
+    CandView v{};
+    int nrows;
     if (which <= 1) {
-        const int sq = 2 * p + which, n = c->n[sq];
-        std::vector<double> bp(tri_size(n));
-        if ((rc = fetch_bp(c, sq, bp.data()))) return rc;
-        for (int i = 1; i <= n; i++)          // src/ractip.cpp:557-568: j outer? no: i<j row-major over the triangle
-            for (int j = i + 1; j <= n; j++) {
-                const float pf = (float)bp[tri_offset(n, i) + j];
-                if (pf > threshold) { if (out && found < cap) out[found] = rh_cand{i, j, pf}; found++; }
-            }
+        const int sq = 2 * p + which;
+        v = CandView{(const double*)c->d_bp + (size_t)sq * c->mc.tri_stride, 0, c->n[sq], 0, 0};
+        nrows = c->n[sq];
     } else if (which == 2) {
-        const int n1 = c->n[2 * p], n2 = c->n[2 * p + 1];
-        std::vector<double> hp((size_t)(n1 + 1) * (n2 + 1));
-        if ((rc = fetch_hp(c, p, hp.data(), nullptr))) return rc;
-        for (int i = 1; i <= n1; i++)
-            for (int j = 1; j <= n2; j++) {
-                const float pf = (float)hp[(size_t)i * (n2 + 1) + j];
-                if (pf > threshold) { if (out && found < cap) out[found] = rh_cand{i, j, pf}; found++; }
-            }
+        v = CandView{(const double*)c->d_hp + (size_t)p * c->dx.tab_stride, 1, c->n[2 * p], c->n[2 * p + 1], c->dx.ldd};
+        nrows = c->n[2 * p];
     } else {
-        const int sq = 2 * p + (which - 3), n = c->n[sq];
-        std::vector<double> up(n);
-        if ((rc = fetch_up(c, sq, up.data()))) return rc;
-        for (int i = 0; i < n; i++) {
-            const float pf = (float)up[i];
-            if (pf > threshold) { if (out && found < cap) out[found] = rh_cand{i, 0, pf}; found++; }
-        }
+        const int sq = 2 * p + (which - 3);
+        v = CandView{(const double*)c->d_up + (size_t)sq * c->mc.ld, 2, c->n[sq], 0, 0};
+        nrows = 1;
+    }
+    int rc;
+    if ((rc = ensure(c, &c->d_cnt, &c->cap_cnt, sizeof(int) * 2 * (size_t)(nrows + 1), false))) return rc;
+    int* d_counts = (int*)c->d_cnt;
+    int* d_offsets = d_counts + (nrows + 1);
+    hipLaunchKernelGGL(cand_count, dim3((nrows + 3) / 4), dim3(256), 0, c->s_mc, v.base, v.kind, v.n, v.n2, v.ld, threshold, nrows, d_counts);
+    std::vector<int> counts(nrows), offsets(nrows);
+    HIP_TRY(c, hipMemcpyAsync(counts.data(), d_counts, sizeof(int) * nrows, hipMemcpyDeviceToHost, c->s_mc));
+    HIP_TRY(c, hipStreamSynchronize(c->s_mc));
+    int found = 0;
+    for (int r = 0; r < nrows; r++) { offsets[r] = found; found += counts[r]; }
+    const int take = std::min(found, cap);
+    if (take > 0) {
+        if ((rc = ensure(c, &c->d_cand, &c->cap_cand, sizeof(rh_cand) * (size_t)take, false))) return rc;
+        HIP_TRY(c, hipMemcpyAsync(d_offsets, offsets.data(), sizeof(int) * nrows, hipMemcpyHostToDevice, c->s_mc));
+        hipLaunchKernelGGL(cand_write, dim3((nrows + 3) / 4), dim3(256), 0, c->s_mc, v.base, v.kind, v.n, v.n2, v.ld, threshold,
+                           nrows, d_offsets, (rh_cand*)c->d_cand, take);
+        HIP_TRY(c, hipMemcpyAsync(out, c->d_cand, sizeof(rh_cand) * (size_t)take, hipMemcpyDeviceToHost, c->s_mc));
+        HIP_TRY(c, hipStreamSynchronize(c->s_mc));
     }
     return found;
 }

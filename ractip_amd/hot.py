@@ -168,6 +168,7 @@ class Context:
     def batch_candidates(self, p, which, threshold, cap=1 << 20):
         buf = (Cand * cap)()
         k = self._check(self.L.rh_batch_candidates(self.h, p, which, ctypes.c_float(threshold), buf, cap))
+        self.last_candidate_count = k
         return [(buf[t].i, buf[t].j, buf[t].p) for t in range(min(k, cap))]
 
     def batch_timings(self):

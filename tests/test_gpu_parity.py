@@ -167,6 +167,31 @@ def test_linear_path_is_taken_and_falls_back_on_overflow(ctx, oracle):
     assert_prob_close(bp, o["post"], rel=REL, what="GC helix via fallback")
 
 
+def test_threshold_candidates_match_reference_scans(ctx, oracle, golden):
+    """rh_batch_candidates == the reference's scans (ractip.cpp:557-568, 578-589, 598-608) applied to the
+    float-narrowed oracle matrices: same entries, same (row-major) order, p > threshold in float."""
+    s1, s2 = str(golden["mc/OxyS/seq"]), str(golden["mc/fhlA/seq"])
+    ctx.batch_upload([(s1, s2)])
+    ctx.batch_compute()
+    r = ctx.batch_results(0)
+    th_ss, th_hy, th_ac = np.float32(0.5), np.float32(0.1), np.float32(0.003)   # cmdline.c defaults
+    for which, s, dense in ((0, s1, r["bp1"]), (1, s2, r["bp2"])):
+        n = len(s)
+        want = [(i, j) for i in range(1, n + 1) for j in range(i + 1, n + 1)
+                if np.float32(dense[tri_offset(n, i) + j]) > th_ss]
+        got = ctx.batch_candidates(0, which, float(th_ss))
+        assert [(i, j) for i, j, _ in got] == want
+        assert all(np.float32(p) == np.float32(dense[tri_offset(n, i) + j]) for i, j, p in got)
+        o = oracle.inference(s)["post"]
+        assert want == [(i, j) for i in range(1, n + 1) for j in range(i + 1, n + 1) if np.float32(o[tri_offset(n, i) + j]) > th_ss]
+    want = [(i, j) for i in range(1, len(s1) + 1) for j in range(1, len(s2) + 1) if np.float32(r["hp"][i, j]) > th_hy]
+    got = ctx.batch_candidates(0, 2, float(th_hy))
+    assert [(i, j) for i, j, _ in got] == want and len(want) > 0
+    got = ctx.batch_candidates(0, 3, float(th_ac))
+    assert [i for i, _, _ in got] == [i for i in range(len(s1)) if np.float32(r["up1"][i]) > th_ac]
+    assert len(ctx.batch_candidates(0, 2, float(th_hy), cap=5)) == 5      # cap truncates the copy, not the count
+
+
 def test_errors_are_reported_not_swallowed(ctx):
     import ractip_amd
     with pytest.raises(ractip_amd.RhError):
