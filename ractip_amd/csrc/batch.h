@@ -68,4 +68,21 @@ struct DxBatch {
     size_t pair_stride;  // D_COUNT*rows*ldd
 };
 
+// ---- duplex, scaled linear path: anti-diagonal-major tables [sd*lda + kDxPad + a], a = i, sd = i + (L2+1-j)
+constexpr int kDxPad = 32;   // zero columns on both sides of every row (>= 29: the longest window reach)
+enum DxLinTable { DL_IN = 0, DL_INX, DL_OUT, DL_OUTX, DL_COUNT };
+
+struct DxLinBatch {
+    const uint8_t* seq;
+    const int* n;        // [2*NP]
+    double* tab;         // [NP][DL_COUNT][rows*lda]
+    double* hp;          // same posterior buffer / layout as DxBatch::hp
+    int np, n1max, n2max, lda, lds, ldd;
+    size_t tab_stride;   // rows*lda (+ slack)
+    size_t pair_stride;  // DL_COUNT*tab_stride
+    size_t hp_stride;
+    double pw_in[2];     // (lam*e^eu)^(sd-2) * lam^2 for the two inside diagonals of this launch
+    double pw_out[2];    // (lam*e^eu)^(L1+L2-sd) * lam^2 for the two outside diagonals
+};
+
 }  // namespace rh

@@ -45,4 +45,16 @@ struct LinModel {
 
 void build_lin_model(const ScoreModel& m, double s, LinModel* out);
 
+// duplex scores in scaled linear space (duplex_lin.hip); lam = exp(-s) per unit of a+b
+struct DxLinModel {
+    double E_tm[625], E_hs[625];
+    double E_bp[25], E_hc[25], E_11[25];
+    double E_dl[125], E_dr[125];
+    double E_b01[8], E_b10[8];
+    double lam_pow[32];   // lam^k
+    double lam_eu;        // lam * exp(external_unpaired)
+    double s;
+};
+void build_dx_lin_model(const ScoreModel& m, double s, DxLinModel* out);
+
 }  // namespace rh

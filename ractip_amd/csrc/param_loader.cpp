@@ -183,4 +183,19 @@ void build_lin_model(const ScoreModel& m, double s, LinModel* L)
     L->shape_cnt[31] = k;
 }
 
+void build_dx_lin_model(const ScoreModel& m, double s, DxLinModel* D)
+{
+    std::memset(D, 0, sizeof(*D));
+    D->s = s;
+    const double lam = std::exp(-s);
+    for (int k = 0; k < 32; k++) D->lam_pow[k] = std::pow(lam, k);
+    D->lam_eu = lam * std::exp(m.external_unpaired);
+    for (int k = 0; k < 625; k++) { D->E_tm[k] = std::exp(m.terminal_mismatch[k]); D->E_hs[k] = std::exp(m.helix_stacking[k]); }
+    for (int k = 0; k < 25; k++) {
+        D->E_bp[k] = std::exp(m.base_pair[k]); D->E_hc[k] = std::exp(m.helix_closing[k]); D->E_11[k] = std::exp(m.internal_1x1[k]);
+    }
+    for (int k = 0; k < 125; k++) { D->E_dl[k] = std::exp(m.dangle_left[k]); D->E_dr[k] = std::exp(m.dangle_right[k]); }
+    for (int k = 0; k < 5; k++) { D->E_b01[k] = std::exp(m.bulge_0x1[k]); D->E_b10[k] = std::exp(m.bulge_1x0[k]); }
+}
+
 }  // namespace rh

@@ -34,6 +34,9 @@ __global__ void lin_init(McBatch B, int* __restrict__ bad);
 template <int W> __global__ void lin_inside_diag(McBatch B, const LinModel* __restrict__ L, int d, double lam_d, int pin);
 template <int W> __global__ void lin_outside_diag(McBatch B, const LinModel* __restrict__ L, int d, int pin, int* __restrict__ bad);
 __global__ void lin_finish(McBatch B, const LinModel* __restrict__ L, double* __restrict__ logz, int* __restrict__ bad);
+template <int W> __global__ void dxl_sweep(DxLinBatch B, const DxLinModel* __restrict__ L, int step, int groups);
+__global__ void dxl_logz(DxLinBatch B, const DxLinModel* __restrict__ L, double* __restrict__ zbar, double* __restrict__ logz, int* __restrict__ bad);
+__global__ void dxl_posterior(DxLinBatch B, const double* __restrict__ zbar, int* __restrict__ bad);
 }  // namespace rh
 
 using namespace rh;
@@ -135,6 +138,12 @@ struct rh_ctx {
     ScoreModel* d_model = nullptr;
     LinModel* d_lin = nullptr;
     LinModel h_lin;
+    DxLinModel* d_dxlin = nullptr;
+    DxLinModel h_dxlin;
+    DxLinBatch dxl = {};
+    size_t dxl_layout = 0;         // (lda, rows) signature of the zero-padded table image currently in HBM
+    int dx_w = 4;                  // wavefronts per 64-cell group of the linear duplex kernel
+    int last_dx_path = 0;
     int mode = RH_MODE_AUTO;       // which McCaskill path rh_batch_compute takes
     int lin_w = 8;                 // wavefronts per 64-cell group of the linear kernels
     int last_path = 0;             // 1 = linear, 2 = log-space, 3 = linear then log-space fallback
@@ -159,6 +168,8 @@ struct rh_ctx {
     void* d_mclogz = nullptr; size_t cap_mclogz = 0;
     void* d_bad = nullptr;   size_t cap_bad = 0;
     void* d_cnt = nullptr;   size_t cap_cnt = 0;
+    void* d_dxbad = nullptr; size_t cap_dxbad = 0;
+    void* d_zbar = nullptr;  size_t cap_zbar = 0;
     void* d_cand = nullptr;  size_t cap_cand = 0;
     double ms[4] = {0, 0, 0, 0};
     int n_launch[3] = {0, 0, 0};
@@ -280,13 +291,31 @@ int stage(rh_ctx* c, int ns, const char* const* seqs, const int* lens, bool with
         D.ldd = (n2max + 2 + 1) & ~1;
         D.tab_stride = (size_t)(n1max + 2) * D.ldd;
         D.pair_stride = D.tab_stride * D_COUNT;
-        if ((rc = ensure(c, &c->d_dxtab, &c->cap_dxtab, sizeof(double) * D.pair_stride * D.np, false))) return rc;
+        // the linear path keeps anti-diagonal-major tables in the same buffer (sequential use)
+        DxLinBatch& X = c->dxl;
+        X.np = D.np; X.n1max = n1max; X.n2max = n2max; X.lds = lds; X.ldd = D.ldd;
+        X.lda = (n1max + 2 + 2 * kDxPad + 1) & ~1;
+        const size_t rows = (size_t)n1max + n2max + 3;
+        X.tab_stride = rows * X.lda + 128;   // slack: the staged 96-column segments may run past the last row
+        X.pair_stride = X.tab_stride * DL_COUNT;
+        const size_t dx_bytes = sizeof(double) * std::max(D.pair_stride, X.pair_stride) * D.np;
+        void* before = c->d_dxtab;
+        if ((rc = ensure(c, &c->d_dxtab, &c->cap_dxtab, dx_bytes, false))) return rc;
+        const size_t layout = ((size_t)X.lda << 32) ^ rows ^ ((size_t)D.np << 48);
+        if (c->d_dxtab != before || layout != c->dxl_layout || c->last_dx_path != 1) {
+            // pad columns must be zero and a different layout (or the log-space path) leaves arbitrary bytes there
+            HIP_TRY(c, hipMemsetAsync(c->d_dxtab, 0, dx_bytes, c->s_dx));
+            c->dxl_layout = layout;
+        }
+        if ((rc = ensure(c, &c->d_dxbad, &c->cap_dxbad, sizeof(int) * D.np, false))) return rc;
+        if ((rc = ensure(c, &c->d_zbar, &c->cap_zbar, sizeof(double) * D.np, false))) return rc;
         if ((rc = ensure(c, &c->d_logz, &c->cap_logz, sizeof(double) * D.np, false))) return rc;
         const size_t hp_bytes = sizeof(double) * D.tab_stride * D.np;
         if ((rc = ensure(c, &c->d_hp, &c->cap_hp, hp_bytes, false))) return rc;
         HIP_TRY(c, hipMemsetAsync(c->d_hp, 0, hp_bytes, c->s_dx));  // row 0 / column 0 stay zero
         D.seq = (const uint8_t*)c->d_seq; D.n = (const int*)c->d_n;
         D.tab = (double*)c->d_dxtab; D.hp = (double*)c->d_hp; D.logz = (double*)c->d_logz;
+        X.seq = D.seq; X.n = D.n; X.tab = D.tab; X.hp = D.hp; X.hp_stride = D.tab_stride;
     }
     return RH_OK;
 }
@@ -348,6 +377,55 @@ int launch_mc_lin_any(rh_ctx* c, int pin)
     }
 }
 
+// ---- duplex sweeps, log-space path
+int launch_dx_log(rh_ctx* c)
+{
+    const DxBatch& D = c->dx;
+    const int smax = D.n1max + D.n2max;
+    const int steps = smax / 2;
+    const int waves = 2 * std::min(D.n1max, D.n2max);
+    for (int t = 0; t < steps; t++) {
+        hipLaunchKernelGGL(dx_sweep_diag, dim3((waves + 3) / 4, D.np, 2), dim3(256), 0, c->s_dx, D, c->d_model, t);
+        c->n_launch[2]++;
+    }
+    hipLaunchKernelGGL(dx_logz, dim3(D.np), dim3(1024), 0, c->s_dx, D, c->d_model);
+    const int cells = D.n1max * D.n2max;
+    hipLaunchKernelGGL(dx_posterior, dim3((cells + 255) / 256, D.np), dim3(256), 0, c->s_dx, D);
+    return RH_OK;
+}
+
+// ---- duplex sweeps, scaled linear path
+template <int W>
+int launch_dx_lin(rh_ctx* c)
+{
+    DxLinBatch X = c->dxl;
+    const int smax = X.n1max + X.n2max;
+    const int steps = smax / 2;
+    const int groups = (X.n1max + 2 + 63) / 64;
+    const double leu = c->h_dxlin.lam_eu, l2 = c->h_dxlin.lam_pow[2];
+    for (int t = 0; t < steps; t++) {
+        // inside diagonal sd = 2+2t+k: (lam e^eu)^(sd-2) lam^2 ; outside sd = Smax-2t-1+k: (lam e^eu)^(2t+1-k) lam^2
+        X.pw_in[0] = std::pow(leu, 2.0 * t) * l2;      X.pw_in[1] = X.pw_in[0] * leu;
+        X.pw_out[1] = std::pow(leu, 2.0 * t) * l2;     X.pw_out[0] = X.pw_out[1] * leu;
+        hipLaunchKernelGGL(dxl_sweep<W>, dim3(2 * groups, X.np, 2), dim3(64 * W), 0, c->s_dx, X, c->d_dxlin, t, groups);
+        c->n_launch[2]++;
+    }
+    hipLaunchKernelGGL(dxl_logz, dim3(X.np), dim3(1024), 0, c->s_dx, X, c->d_dxlin, (double*)c->d_zbar, (double*)c->d_logz,
+                       (int*)c->d_dxbad);
+    const int cells = X.n1max * X.n2max;
+    hipLaunchKernelGGL(dxl_posterior, dim3((cells + 255) / 256, X.np), dim3(256), 0, c->s_dx, X, (const double*)c->d_zbar,
+                       (int*)c->d_dxbad);
+    return RH_OK;
+}
+int launch_dx_lin_any(rh_ctx* c)
+{
+    switch (c->dx_w) {
+        case 2: return launch_dx_lin<2>(c);
+        case 8: return launch_dx_lin<8>(c);
+        default: return launch_dx_lin<4>(c);
+    }
+}
+
 int compute(rh_ctx* c)
 {
     HIP_TRY(c, hipSetDevice(c->device));
@@ -361,20 +439,16 @@ int compute(rh_ctx* c)
     const char* skip = std::getenv("RH_EXP_SKIP");
     const bool skip_dx = skip && !std::strcmp(skip, "dx"), skip_mc = skip && !std::strcmp(skip, "mc");
     HIP_TRY(c, hipEventRecord(c->ev[3], c->s_dx));
+    bool dx_lin_launched = false;
     if (c->has_dx && !skip_dx) {
-        const DxBatch& D = c->dx;
-        const int smax = D.n1max + D.n2max;
-        const int steps = smax / 2;
-        const int waves = 2 * std::min(D.n1max, D.n2max);
-        for (int t = 0; t < steps; t++) {
-            hipLaunchKernelGGL(dx_sweep_diag, dim3((waves + 3) / 4, D.np, 2), dim3(256), 0, c->s_dx, D, c->d_model, t);
-            c->n_launch[2]++;
+        if (c->mode != RH_MODE_LOG) {
+            if ((rc = launch_dx_lin_any(c))) return rc;
+            dx_lin_launched = true;
+        } else {
+            if ((rc = launch_dx_log(c))) return rc;
+            c->last_dx_path = 2;
         }
-        hipLaunchKernelGGL(dx_logz, dim3(D.np), dim3(1024), 0, c->s_dx, D, c->d_model);
-        const int cells = D.n1max * D.n2max;
-        hipLaunchKernelGGL(dx_posterior, dim3((cells + 255) / 256, D.np), dim3(256), 0, c->s_dx, D);
     }
-    HIP_TRY(c, hipEventRecord(c->ev[4], c->s_dx));
 
     HIP_TRY(c, hipEventRecord(c->ev[0], c->s_mc));
     bool need_log = c->has_mc && c->mode == RH_MODE_LOG && !skip_mc;
@@ -399,6 +473,22 @@ int compute(rh_ctx* c)
         if (c->last_path == 0) c->last_path = 2;
     }
     HIP_TRY(c, hipEventRecord(c->ev[2], c->s_mc));
+    if (dx_lin_launched) {
+        c->last_dx_path = 1;
+        if (c->mode == RH_MODE_AUTO) {
+            std::vector<int> bad(c->dx.np);
+            HIP_TRY(c, hipMemcpyAsync(bad.data(), c->d_dxbad, sizeof(int) * c->dx.np, hipMemcpyDeviceToHost, c->s_dx));
+            HIP_TRY(c, hipStreamSynchronize(c->s_dx));
+            bool redo = false;
+            for (int b : bad) redo |= (b != 0);
+            if (redo) {  // some pair left the double range: recompute the batch with the log-space kernels
+                c->n_launch[2] = 0;
+                if ((rc = launch_dx_log(c))) return rc;
+                c->last_dx_path = 3;
+            }
+        }
+    }
+    HIP_TRY(c, hipEventRecord(c->ev[4], c->s_dx));
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(c->s_mc));
     HIP_TRY(c, hipStreamSynchronize(c->s_dx));
@@ -473,13 +563,18 @@ rh_ctx* rh_create(int device, int model, const char* param_file)
     // scale exponent of the linear fast path: log Z per nucleotide of typical sequences under this model
     // (random ACGU: 0.107..0.129 for n = 200..2000); deviations only cost dynamic range, never accuracy
     build_lin_model(host_model, 0.12, &c->h_lin);
+    // duplex: log Z per unit of (i + L2+1-j) is 0.62..0.82 on the bundled pairs, 0.645 for random sequences
+    build_dx_lin_model(host_model, 0.65, &c->h_dxlin);
     if (const char* e = std::getenv("RH_LIN_W")) c->lin_w = std::atoi(e);
+    if (const char* e = std::getenv("RH_DX_W")) c->dx_w = std::atoi(e);
     bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&c->s_mc, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&c->s_dx, hipStreamNonBlocking) == hipSuccess &&
               hipMalloc((void**)&c->d_model, sizeof(ScoreModel)) == hipSuccess &&
               hipMemcpy(c->d_model, &host_model, sizeof(ScoreModel), hipMemcpyHostToDevice) == hipSuccess &&
               hipMalloc((void**)&c->d_lin, sizeof(LinModel)) == hipSuccess &&
-              hipMemcpy(c->d_lin, &c->h_lin, sizeof(LinModel), hipMemcpyHostToDevice) == hipSuccess;
+              hipMemcpy(c->d_lin, &c->h_lin, sizeof(LinModel), hipMemcpyHostToDevice) == hipSuccess &&
+              hipMalloc((void**)&c->d_dxlin, sizeof(DxLinModel)) == hipSuccess &&
+              hipMemcpy(c->d_dxlin, &c->h_dxlin, sizeof(DxLinModel), hipMemcpyHostToDevice) == hipSuccess;
     for (int k = 0; ok && k < 6; k++) ok = hipEventCreate(&c->ev[k]) == hipSuccess;
     if (!ok) {
         fail(nullptr, RH_ERR_HIP, "context setup failed: %s", hipGetErrorString(hipGetLastError()));
@@ -493,7 +588,7 @@ void rh_destroy(rh_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    void* bufs[] = {c->d_seq, c->d_n, c->d_mctab, c->d_f5, c->d_bp, c->d_up, c->d_dxtab, c->d_hp, c->d_logz, c->d_scal, c->d_mclogz, c->d_bad, c->d_cnt, c->d_cand, c->d_model, c->d_lin};
+    void* bufs[] = {c->d_seq, c->d_n, c->d_mctab, c->d_f5, c->d_bp, c->d_up, c->d_dxtab, c->d_hp, c->d_logz, c->d_scal, c->d_mclogz, c->d_bad, c->d_cnt, c->d_cand, c->d_dxbad, c->d_zbar, c->d_model, c->d_lin, c->d_dxlin};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->s_mc) (void)hipStreamDestroy(c->s_mc);
