@@ -84,7 +84,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     n = args.n
-    batch = args.batch or (32 if n <= 600 else (8 if n <= 1200 else 2))
+    batch = args.batch or (64 if n <= 600 else (16 if n <= 1200 else 4))
     # every rank draws from ONE stream and keeps its own slice: distinct pairs per rank (weak scaling)
     all_pairs = random_pairs(batch * world, n, seed=12345)
     pairs = all_pairs[rank * batch:(rank + 1) * batch]
@@ -137,6 +137,14 @@ def main():
                            "avg_launch_us": float(ms_k) * 1e3 / max(1, launches),
                            "achieved_GBs": bytes_ / 1e9 / (ms_k / 1e3) if ms_k > 0 else None}
         dom = max(("mc_inside_diag", "mc_outside_diag"), key=lambda k: phases[k]["ms_per_step"])
+        # HBM-side traffic per launch of that kernel: measured separately with rocprofv3 PMC passes
+        # (profiles/pmc_traffic.json); null for configurations that were not profiled
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            traffic = tj.get("n%d_b%d" % (n, batch), {}).get(dom)
+        except (OSError, ValueError):
+            pass
         ach = phases[dom]["achieved_GBs"]
         line = {
             "metric": "sequence-pairs/sec (incl. bp+hp+ap DP) at n=%d" % n,
@@ -155,7 +163,7 @@ def main():
                                    % (n, n, "3" if n == 500 else ("4" if n == 2000 else "-")),
                        "pairs_per_gpu_per_step": batch, "model": None, "scoring": "CONTRAfold complementary (708 weights)"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS if ach else None, "traffic": None,
+                         "frac": ach / HBM_PEAK_GBS if ach else None, "traffic": traffic,
                          "alg_bytes_per_launch": phases[dom]["alg_GB_per_step"] * 1e9 / max(1, phases[dom]["launches"]),
                          "avg_launch_us": phases[dom]["avg_launch_us"],
                          "whole_path": {"alg_GB_per_pair": b["total"] / 1e9 / batch,

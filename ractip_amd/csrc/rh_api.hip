@@ -449,6 +449,7 @@ int compute(rh_ctx* c)
             c->last_dx_path = 2;
         }
     }
+    HIP_TRY(c, hipEventRecord(c->ev[4], c->s_dx));
 
     HIP_TRY(c, hipEventRecord(c->ev[0], c->s_mc));
     bool need_log = c->has_mc && c->mode == RH_MODE_LOG && !skip_mc;
@@ -483,12 +484,13 @@ int compute(rh_ctx* c)
             for (int b : bad) redo |= (b != 0);
             if (redo) {  // some pair left the double range: recompute the batch with the log-space kernels
                 c->n_launch[2] = 0;
+                HIP_TRY(c, hipEventRecord(c->ev[3], c->s_dx));
                 if ((rc = launch_dx_log(c))) return rc;
+                HIP_TRY(c, hipEventRecord(c->ev[4], c->s_dx));
                 c->last_dx_path = 3;
             }
         }
     }
-    HIP_TRY(c, hipEventRecord(c->ev[4], c->s_dx));
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(c->s_mc));
     HIP_TRY(c, hipStreamSynchronize(c->s_dx));
