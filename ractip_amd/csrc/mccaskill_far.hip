@@ -1,0 +1,156 @@
+// mccaskill_far.hip -- block products for the O(n^3) terms of the linear-space McCaskill sweeps.
+//
+// The multibranch terms (reference: /root/reference/src/contrafold/InferenceEngine.ipp:3384-3411 inside,
+// 4046-4064 outside) are triangular matrix products.  With positions cut into blocks of BS:
+//   FM2 [i,j] = sum_k  FM1[i,k]  * FM[k,j]      k in blocks  I+2 .. J-2   ("far"),  rest "near"
+//   FMo [i,j] = sum_i' FM1[i',i] * FM2o[i',j]   i' in blocks 0   .. I-2
+//   FM1o[i,j] = sum_j' FM2o[i,j']* FM[j,j']     j' in blocks J+2 .. last
+// Every operand block of a far term is COMPLETE (all its cells final) at least one fine diagonal before
+// the first cell of tile (I,J) is due, so the far part of a whole tile is one dense BSxBS product per
+// operand block pair: each operand element is read once per tile instead of once per cell (HBM traffic
+// / BS), staged through LDS.  The per-diagonal kernels (mccaskill_lin.hip) add the <= 4*BS near terms.
+// In scaled linear space the products need no exponent handling: (k-i)+(j-k) = j-i.
+#include <hip/hip_runtime.h>
+
+#include "batch.h"
+#include "lin_model.h"
+
+namespace rh {
+
+enum LinTableFar { LF_FM1 = 3, LF_FM = 4, LF_FM2O = 7, LF_FM2F = 10, LF_FMOF = 11, LF_FM1OF = 12 };
+
+namespace {
+
+// cell (x,y) of a diagonal-major table, zero outside the interior 1 <= x <= y <= n-1
+__device__ __forceinline__ double cellv(const double* __restrict__ T, int ld, int n, int x, int y)
+{
+    return (x >= 1 && x <= y && y <= n - 1) ? T[(size_t)(y - x) * ld + x] : 0.0;
+}
+
+// Load the BSxBS chunk {cell(T, x0+u, y0+v)} into LDS as dst[u][v] (TR = false) or dst[v][u] (TR = true).
+// Threads walk the chunk along its diagonals v-u = const: those are contiguous runs of the table.
+template <int BS, bool TR>
+__device__ __forceinline__ void load_chunk(double (*dst)[BS + 1], const double* __restrict__ T, int ld, int n, int x0, int y0)
+{
+    const int u = threadIdx.x % BS;
+    constexpr int DPP = 256 / BS;  // diagonals per pass
+    for (int dd = threadIdx.x / BS; dd < 2 * BS - 1; dd += DPP) {
+        const int v = u + dd - (BS - 1);
+        if (v >= 0 && v < BS) {
+            const double val = cellv(T, ld, n, x0 + u, y0 + v);
+            if (TR) dst[v][u] = val; else dst[u][v] = val;
+        }
+    }
+}
+
+// C[r][c] += sum_kk A[r][kk] * Bm[kk][c] for this thread's outputs (1 for BS=16, 2x2 for BS=32)
+template <int BS>
+struct Acc {
+    static constexpr int R = BS / 16;
+    double c[R][R];
+    __device__ __forceinline__ void zero()
+    {
+#pragma unroll
+        for (int a = 0; a < R; a++)
+#pragma unroll
+            for (int b = 0; b < R; b++) c[a][b] = 0.0;
+    }
+    __device__ __forceinline__ void mac(const double (*A)[BS + 1], const double (*Bm)[BS + 1])
+    {
+        const int r0 = (threadIdx.x / 16) * R, c0 = (threadIdx.x % 16) * R;
+#pragma unroll 8
+        for (int kk = 0; kk < BS; kk++) {
+            double a[R], b[R];
+#pragma unroll
+            for (int q = 0; q < R; q++) { a[q] = A[r0 + q][kk]; b[q] = Bm[kk][c0 + q]; }
+#pragma unroll
+            for (int p = 0; p < R; p++)
+#pragma unroll
+                for (int q = 0; q < R; q++) c[p][q] = fma(a[p], b[q], c[p][q]);
+        }
+    }
+    __device__ __forceinline__ void store(double* __restrict__ T, int ld, int n, int i0, int j0) const
+    {
+        const int r0 = (threadIdx.x / 16) * R, c0 = (threadIdx.x % 16) * R;
+#pragma unroll
+        for (int p = 0; p < R; p++)
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                const int i = i0 + r0 + p, j = j0 + c0 + q;
+                if (i >= 1 && i <= j && j <= n - 1) T[(size_t)(j - i) * ld + i] = c[p][q];
+            }
+    }
+};
+
+}  // namespace
+
+// inside: FM2F[tile (I, I+D)] = sum_{K=I+2}^{J-2} FM1(I,K) x FM(K,J);  grid = (tiles I, sequences)
+template <int BS>
+__global__ __launch_bounds__(256) void lin_far_inside(McBatch B, int D)
+{
+    __shared__ double A[BS][BS + 1], Bm[BS][BS + 1];
+    const int sq = blockIdx.y;
+    const int n = B.n[sq];
+    const int I = blockIdx.x, J = I + D;
+    if (J * BS > n - 1) return;  // no interior column in this tile
+    const int ld = B.ld;
+    double* __restrict__ tab = B.tab + (size_t)sq * B.seq_stride;
+    const double* __restrict__ fm1 = tab + (size_t)LF_FM1 * B.tab_stride;
+    const double* __restrict__ fm = tab + (size_t)LF_FM * B.tab_stride;
+    Acc<BS> acc;
+    acc.zero();
+    for (int K = I + 2; K <= J - 2; K++) {
+        load_chunk<BS, false>(A, fm1, ld, n, I * BS, K * BS);   // A[r][kk]  = FM1[i0+r, k0+kk]
+        load_chunk<BS, false>(Bm, fm, ld, n, K * BS, J * BS);   // Bm[kk][c] = FM [k0+kk, j0+c]
+        __syncthreads();
+        acc.mac(A, Bm);
+        __syncthreads();
+    }
+    acc.store(tab + (size_t)LF_FM2F * B.tab_stride, ld, n, I * BS, J * BS);
+}
+
+// outside: FMOF[tile]  = sum_{K<=I-2} FM1(K,I)^T x FM2o(K,J)
+//          FM1OF[tile] = sum_{K>=J+2} FM2o(I,K)   x FM(J,K)^T ;  grid = (tiles I, sequences, 2)
+template <int BS>
+__global__ __launch_bounds__(256) void lin_far_outside(McBatch B, int D)
+{
+    __shared__ double A[BS][BS + 1], Bm[BS][BS + 1];
+    const int sq = blockIdx.y;
+    const int n = B.n[sq];
+    const int I = blockIdx.x, J = I + D;
+    if (J * BS > n - 1) return;
+    const int ld = B.ld;
+    double* __restrict__ tab = B.tab + (size_t)sq * B.seq_stride;
+    const double* __restrict__ fm1 = tab + (size_t)LF_FM1 * B.tab_stride;
+    const double* __restrict__ fm = tab + (size_t)LF_FM * B.tab_stride;
+    const double* __restrict__ fm2o = tab + (size_t)LF_FM2O * B.tab_stride;
+    Acc<BS> acc;
+    acc.zero();
+    if (blockIdx.z == 0) {
+        for (int K = 0; K <= I - 2; K++) {
+            load_chunk<BS, true>(A, fm1, ld, n, K * BS, I * BS);     // A[r][kk]  = FM1 [k0+kk, i0+r]
+            load_chunk<BS, false>(Bm, fm2o, ld, n, K * BS, J * BS);  // Bm[kk][c] = FM2o[k0+kk, j0+c]
+            __syncthreads();
+            acc.mac(A, Bm);
+            __syncthreads();
+        }
+        acc.store(tab + (size_t)LF_FMOF * B.tab_stride, ld, n, I * BS, J * BS);
+    } else {
+        const int last = (n - 1) / BS;
+        for (int K = J + 2; K <= last; K++) {
+            load_chunk<BS, false>(A, fm2o, ld, n, I * BS, K * BS);   // A[r][kk]  = FM2o[i0+r, k0+kk]
+            load_chunk<BS, true>(Bm, fm, ld, n, J * BS, K * BS);     // Bm[kk][c] = FM  [j0+c, k0+kk]
+            __syncthreads();
+            acc.mac(A, Bm);
+            __syncthreads();
+        }
+        acc.store(tab + (size_t)LF_FM1OF * B.tab_stride, ld, n, I * BS, J * BS);
+    }
+}
+
+template __global__ void lin_far_inside<16>(McBatch, int);
+template __global__ void lin_far_inside<32>(McBatch, int);
+template __global__ void lin_far_outside<16>(McBatch, int);
+template __global__ void lin_far_outside<32>(McBatch, int);
+
+}  // namespace rh

@@ -44,7 +44,9 @@ __device__ __forceinline__ void block_map(int pin, int* sq, int* slot)
 
 }  // namespace
 
-enum LinTable { L_FC = 0, L_FCX, L_FCA, L_FM1, L_FM, L_FCO, L_FCOX, L_FM2O, L_FMO, L_FM1O, L_COUNT };
+enum LinTable { L_FC = 0, L_FCX, L_FCA, L_FM1, L_FM, L_FCO, L_FCOX, L_FM2O, L_FMO, L_FM1O,
+                L_FM2F, L_FMOF, L_FM1OF,  // far-block partial sums (mccaskill_far.hip)
+                L_COUNT };
 static_assert((int)L_COUNT <= (int)T_COUNT, "linear tables reuse the log-space table buffer");
 
 // F5i~[0] = 1, F5o~[n] = 1
@@ -60,7 +62,9 @@ __global__ void lin_init(McBatch B, int* __restrict__ bad)
 // ---------------------------------------------------------------------------------
 // inside, diagonal d.  Workgroup = 64 consecutive cells x W wavefronts; the group after
 // the last cell group computes F5i~[d+1] with its first wavefront.
-template <int W>
+// BS > 0: the k-terms that lie in complete blocks (I+2 .. J-2) come from FM2F (mccaskill_far.hip); only the
+// <= 4*BS near terms are streamed here.  BS = 0: the whole sum is streamed.
+template <int W, int BS>
 __global__ __launch_bounds__(64 * W) void lin_inside_diag(McBatch B, const LinModel* __restrict__ L, int d, double lam_d, int pin)
 {
     __shared__ double part[2][W][64];
@@ -131,22 +135,37 @@ __global__ __launch_bounds__(64 * W) void lin_inside_diag(McBatch B, const LinMo
     // ---- FM2[i,d] = sum_{m=1}^{d-1} FM1[m][i] * FM[d-m][i+m]          (ipp:3384-3411)
     double acc2 = 0.0;
 #ifndef RH_EXP_NOFM2
-    if (valid) {
+    {
         const double* __restrict__ fm1 = tab + L_FM1 * ts + i;
         const double* __restrict__ fm = tab + L_FM * ts + i;
-        int m = 1 + w;
-        constexpr int UF = 8;  // 2*UF row segments (512 B each) in flight per wavefront
-        for (; m + (UF - 1) * W <= d - 1; m += UF * W) {
-            double a[UF], b[UF];
-#pragma unroll
-            for (int u = 0; u < UF; u++) {
-                a[u] = fm1[(size_t)(m + u * W) * ld];
-                b[u] = fm[(size_t)(d - m - u * W) * ld + m + u * W];
-            }
-#pragma unroll
-            for (int u = 0; u < UF; u++) acc2 = fma(a[u], b[u], acc2);
+        // near set of this cell in k = i+m: k < kA or k >= kB (everything when the tile has no far blocks)
+        int kA = 1 << 30, kB = 0;
+        if (BS > 0) {
+            const int I = i / BS, J = j / BS;
+            if (J - I >= 4) { kA = (I + 2) * BS; kB = (J - 1) * BS; }
         }
-        for (; m <= d - 1; m += W) acc2 = fma(fm1[(size_t)m * ld], fm[(size_t)(d - m) * ld + m], acc2);
+        constexpr int UF = 8;  // 2*UF row segments (512 B each) in flight per wavefront
+        // uniform m-ranges that cover every lane's near set: [1, d-1], or its two ends when far blocks exist
+        const bool split = BS > 0 && d - 1 > 4 * BS;
+        const int lo0 = 1, hi0 = split ? 2 * BS : d - 1;
+        const int lo1 = split ? d - 2 * BS : 1, hi1 = split ? d - 1 : 0;
+#pragma unroll
+        for (int part_i = 0; part_i < 2; part_i++) {
+            const int lo = part_i ? lo1 : lo0, hi = part_i ? hi1 : hi0;
+            for (int m = lo + w; m <= hi; m += UF * W) {
+                double a[UF], b[UF];
+#pragma unroll
+                for (int u = 0; u < UF; u++) {
+                    const int mm = m + u * W, k = i + mm;
+                    const bool ok = valid && mm <= hi && (k < kA || k >= kB);
+                    a[u] = ok ? fm1[(size_t)mm * ld] : 0.0;
+                    b[u] = ok ? fm[(size_t)(d - mm) * ld + mm] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < UF; u++) acc2 = fma(a[u], b[u], acc2);
+            }
+        }
+        if (BS > 0 && valid && kB > 0) acc2 += (w == 0) ? tab[L_FM2F * ts + (size_t)d * ld + i] : 0.0;
     }
 #endif
 
@@ -214,7 +233,7 @@ __global__ __launch_bounds__(64 * W) void lin_inside_diag(McBatch B, const LinMo
 
 // ---------------------------------------------------------------------------------
 // outside (pull form) + posterior, diagonal d; last group: F5o~[d+1].
-template <int W>
+template <int W, int BS>
 __global__ __launch_bounds__(64 * W) void lin_outside_diag(McBatch B, const LinModel* __restrict__ L, int d, int pin, int* __restrict__ bad)
 {
     __shared__ double part[3][W][64];
@@ -290,16 +309,17 @@ __global__ __launch_bounds__(64 * W) void lin_outside_diag(McBatch B, const LinM
 
     double accm = 0.0, acc1 = 0.0, accc = 0.0;
     if (guard_m) {
+        constexpr int UO = 6;
         // FMo[i,d] += FM2o[d+e][i-e] * FM1[e][i-e], e = 1..i-1            (ipp:4046-4064, pulled)
+        // with blocks: only i' = i-e in blocks I-1, I are streamed; blocks <= I-2 come from FMOF
         {
             const int i_last = ncell < i0 + 63 ? ncell : i0 + 63;
-            const int emax = i_last - 1;
+            const int emax = BS > 0 ? (i_last - 1 < 2 * BS ? i_last - 1 : 2 * BS) : i_last - 1;
             const double* __restrict__ x = tab + L_FM2O * ts + i;
             const double* __restrict__ y = tab + L_FM1 * ts + i;
-            const int mine = valid ? i - 1 : 0;
-            int e = 1 + w;
-            constexpr int UO = 6;
-            for (; e + (UO - 1) * W <= emax; e += UO * W) {
+            int mine = valid ? i - 1 : 0;
+            if (BS > 0 && valid) { const int lim = i - (i / BS - 1) * BS; mine = mine < lim ? mine : lim; }
+            for (int e = 1 + w; e <= emax; e += UO * W) {
                 double xv[UO], yv[UO];
 #pragma unroll
                 for (int u = 0; u < UO; u++) {
@@ -311,18 +331,17 @@ __global__ __launch_bounds__(64 * W) void lin_outside_diag(McBatch B, const LinM
 #pragma unroll
                 for (int u = 0; u < UO; u++) accm = fma(xv[u], yv[u], accm);
             }
-            for (; e <= emax; e += W)
-                if (e <= mine) accm = fma(x[(size_t)(d + e) * ld - e], y[(size_t)e * ld - e], accm);
+            if (BS > 0 && valid && w == 0) accm += tab[L_FMOF * ts + (size_t)d * ld + i];
         }
-        // FM1o[i,d] += FM2o[d+e][i] * FM[e][i+d], e = 1..n-1-j
+        // FM1o[i,d] += FM2o[d+e][i] * FM[e][i+d], e = 1..n-1-j; blocks >= J+2 come from FM1OF
         {
-            const int emax = n - 1 - (i0 + d);
+            const int emax_all = n - 1 - (i0 + d);
+            const int emax = BS > 0 ? (emax_all < 2 * BS ? emax_all : 2 * BS) : emax_all;
             const double* __restrict__ x = tab + L_FM2O * ts + i;
             const double* __restrict__ y = tab + L_FM * ts + j;
-            const int mine = valid ? n - 1 - j : 0;
-            int e = 1 + w;
-            constexpr int UO = 6;
-            for (; e + (UO - 1) * W <= emax; e += UO * W) {
+            int mine = valid ? n - 1 - j : 0;
+            if (BS > 0 && valid) { const int lim = (j / BS + 2) * BS - 1 - j; mine = mine < lim ? mine : lim; }
+            for (int e = 1 + w; e <= emax; e += UO * W) {
                 double xv[UO], yv[UO];
 #pragma unroll
                 for (int u = 0; u < UO; u++) {
@@ -334,8 +353,7 @@ __global__ __launch_bounds__(64 * W) void lin_outside_diag(McBatch B, const LinM
 #pragma unroll
                 for (int u = 0; u < UO; u++) acc1 = fma(xv[u], yv[u], acc1);
             }
-            for (; e <= emax; e += W)
-                if (e <= mine) acc1 = fma(x[(size_t)(d + e) * ld], y[(size_t)e * ld], acc1);
+            if (BS > 0 && valid && w == 0) acc1 += tab[L_FM1OF * ts + (size_t)d * ld + i];
         }
     }
     {   // enclosing single-branch loops: FCoX[d+2+t][i-1-l1] * w_c               (ipp:4004-4024, pulled)
@@ -416,12 +434,13 @@ __global__ void lin_finish(McBatch B, const LinModel* __restrict__ L, double* __
     logz[sq] = log(z) + L->s * (double)n;
 }
 
-// the host side instantiates the group width it wants
-template __global__ void lin_inside_diag<4>(McBatch, const LinModel*, int, double, int);
-template __global__ void lin_inside_diag<8>(McBatch, const LinModel*, int, double, int);
-template __global__ void lin_inside_diag<16>(McBatch, const LinModel*, int, double, int);
-template __global__ void lin_outside_diag<4>(McBatch, const LinModel*, int, int, int*);
-template __global__ void lin_outside_diag<8>(McBatch, const LinModel*, int, int, int*);
-template __global__ void lin_outside_diag<16>(McBatch, const LinModel*, int, int, int*);
+// the host side instantiates the group width / block size it wants
+#define RH_INST(W, BS)                                                                             \
+    template __global__ void lin_inside_diag<W, BS>(McBatch, const LinModel*, int, double, int);  \
+    template __global__ void lin_outside_diag<W, BS>(McBatch, const LinModel*, int, int, int*);
+RH_INST(4, 0) RH_INST(8, 0) RH_INST(16, 0)
+RH_INST(4, 16) RH_INST(8, 16) RH_INST(16, 16)
+RH_INST(4, 32) RH_INST(8, 32) RH_INST(16, 32)
+#undef RH_INST
 
 }  // namespace rh

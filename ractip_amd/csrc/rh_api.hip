@@ -31,8 +31,10 @@ __global__ void dx_sweep_diag(DxBatch B, const ScoreModel* __restrict__ M, int t
 __global__ void dx_logz(DxBatch B, const ScoreModel* __restrict__ M);
 __global__ void dx_posterior(DxBatch B);
 __global__ void lin_init(McBatch B, int* __restrict__ bad);
-template <int W> __global__ void lin_inside_diag(McBatch B, const LinModel* __restrict__ L, int d, double lam_d, int pin);
-template <int W> __global__ void lin_outside_diag(McBatch B, const LinModel* __restrict__ L, int d, int pin, int* __restrict__ bad);
+template <int W, int BS> __global__ void lin_inside_diag(McBatch B, const LinModel* __restrict__ L, int d, double lam_d, int pin);
+template <int W, int BS> __global__ void lin_outside_diag(McBatch B, const LinModel* __restrict__ L, int d, int pin, int* __restrict__ bad);
+template <int BS> __global__ void lin_far_inside(McBatch B, int D);
+template <int BS> __global__ void lin_far_outside(McBatch B, int D);
 __global__ void lin_finish(McBatch B, const LinModel* __restrict__ L, double* __restrict__ logz, int* __restrict__ bad);
 template <int W> __global__ void dxl_sweep(DxLinBatch B, const DxLinModel* __restrict__ L, int step, int groups);
 __global__ void dxl_logz(DxLinBatch B, const DxLinModel* __restrict__ L, double* __restrict__ zbar, double* __restrict__ logz, int* __restrict__ bad);
@@ -146,6 +148,7 @@ struct rh_ctx {
     int last_dx_path = 0;
     int mode = RH_MODE_AUTO;       // which McCaskill path rh_batch_compute takes
     int lin_w = 8;                 // wavefronts per 64-cell group of the linear kernels
+    int lin_bs = 16;               // block size of the far/near split of the O(n^3) terms (0 = off)
     int last_path = 0;             // 1 = linear, 2 = log-space, 3 = linear then log-space fallback
 
     // current batch (host mirror)
@@ -344,22 +347,43 @@ int launch_mc_log(rh_ctx* c, int pin)
 }
 
 // ---- McCaskill sweeps, scaled linear-space path (fast; flags sequences that left the double range)
-template <int W>
+// BS > 0: block products (mccaskill_far.hip) take the k-terms of complete blocks; schedule:
+//   inside : far(D) right after fine diagonal (D-1)*BS-1  (its operands are final, tile (I,I+D) starts at (D-1)*BS+1)
+//   outside: far(D) right before fine diagonal (D+1)*BS-1 (operands: spans >= (D+1)*BS+1, already final)
+template <int W, int BS>
 int launch_mc_lin(rh_ctx* c, int pin)
 {
     const McBatch& B = c->mc;
     int* bad = (int*)c->d_bad;
+    const int last_block = BS > 0 ? (B.nmax - 1) / BS : 0;
     hipLaunchKernelGGL(lin_init, dim3((B.ns + 63) / 64), dim3(64), 0, c->s_mc, B, bad);
     for (int d = 0; d <= B.nmax - 1; d++) {
         const int groups = (std::max(B.nmax - 1 - d, 0) + 63) / 64 + 1;
-        hipLaunchKernelGGL(lin_inside_diag<W>, pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(64 * W), 0, c->s_mc, B,
+        hipLaunchKernelGGL((lin_inside_diag<W, BS>), pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(64 * W), 0, c->s_mc, B,
                            c->d_lin, d, std::exp(-c->h_lin.s * d), pin);
         c->n_launch[0]++;
+        if (BS > 0 && (d + 1) % BS == 0) {
+            const int D = (d + 1) / BS + 1;
+            if (D >= 4 && D <= last_block) {
+                hipLaunchKernelGGL(lin_far_inside<(BS > 0 ? BS : 16)>, dim3(last_block - D + 1, B.ns), dim3(256), 0, c->s_mc, B, D);
+                c->n_launch[0]++;
+            }
+        }
     }
     HIP_TRY(c, hipEventRecord(c->ev[1], c->s_mc));
+    if (BS > 0)  // tiles whose first cell would come before the first outside diagonal: their far sums are empty
+        for (int D = last_block; D >= 0 && (D + 1) * BS - 1 > B.nmax - 2; D--)
+            hipLaunchKernelGGL(lin_far_outside<(BS > 0 ? BS : 16)>, dim3(last_block - D + 1, B.ns, 2), dim3(256), 0, c->s_mc, B, D);
     for (int d = B.nmax - 2; d >= 0; d--) {
+        if (BS > 0 && (d + 1) % BS == 0) {
+            const int D = (d + 1) / BS - 1;
+            if (D >= 0 && D <= last_block) {
+                hipLaunchKernelGGL(lin_far_outside<(BS > 0 ? BS : 16)>, dim3(last_block - D + 1, B.ns, 2), dim3(256), 0, c->s_mc, B, D);
+                c->n_launch[1]++;
+            }
+        }
         const int groups = (B.nmax - 1 - d + 63) / 64 + 1;
-        hipLaunchKernelGGL(lin_outside_diag<W>, pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(64 * W), 0, c->s_mc, B,
+        hipLaunchKernelGGL((lin_outside_diag<W, BS>), pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(64 * W), 0, c->s_mc, B,
                            c->d_lin, d, pin, bad);
         c->n_launch[1]++;
     }
@@ -368,12 +392,21 @@ int launch_mc_lin(rh_ctx* c, int pin)
     return RH_OK;
 }
 
-int launch_mc_lin_any(rh_ctx* c, int pin)
+template <int BS>
+int launch_mc_lin_w(rh_ctx* c, int pin)
 {
     switch (c->lin_w) {
-        case 4: return launch_mc_lin<4>(c, pin);
-        case 16: return launch_mc_lin<16>(c, pin);
-        default: return launch_mc_lin<8>(c, pin);
+        case 4: return launch_mc_lin<4, BS>(c, pin);
+        case 16: return launch_mc_lin<16, BS>(c, pin);
+        default: return launch_mc_lin<8, BS>(c, pin);
+    }
+}
+int launch_mc_lin_any(rh_ctx* c, int pin)
+{
+    switch (c->lin_bs) {
+        case 0: return launch_mc_lin_w<0>(c, pin);
+        case 32: return launch_mc_lin_w<32>(c, pin);
+        default: return launch_mc_lin_w<16>(c, pin);
     }
 }
 
@@ -568,6 +601,7 @@ rh_ctx* rh_create(int device, int model, const char* param_file)
     // duplex: log Z per unit of (i + L2+1-j) is 0.62..0.82 on the bundled pairs, 0.645 for random sequences
     build_dx_lin_model(host_model, 0.65, &c->h_dxlin);
     if (const char* e = std::getenv("RH_LIN_W")) c->lin_w = std::atoi(e);
+    if (const char* e = std::getenv("RH_LIN_BS")) c->lin_bs = std::atoi(e);
     if (const char* e = std::getenv("RH_DX_W")) c->dx_w = std::atoi(e);
     bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&c->s_mc, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&c->s_dx, hipStreamNonBlocking) == hipSuccess &&
