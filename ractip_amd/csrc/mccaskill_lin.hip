@@ -68,6 +68,7 @@ template <int W, int BS>
 __global__ __launch_bounds__(64 * W) void lin_inside_diag(McBatch B, const LinModel* __restrict__ L, int d, double lam_d, int pin)
 {
     __shared__ double part[2][W][64];
+    __shared__ double gbuf[W][96];
     int sq, slot;
     block_map(pin, &sq, &slot);
     if (sq >= B.ns) return;
@@ -169,38 +170,32 @@ __global__ __launch_bounds__(64 * W) void lin_inside_diag(McBatch B, const LinMo
     }
 #endif
 
-    // ---- generic single-branch shapes of FC[i,d]: sum_c w_c * FCX[d-2-t][i+1+l1]   (ipp:3597-3619)
+    // ---- generic single-branch shapes of FC[i,d]: sum_t sum_l1 w(l1,t-l1) * FCX[d-2-t][i+1+l1]   (ipp:3597-3619)
+    // For one t the 64 cells of the group read overlapping windows of ONE row: the segment is staged in LDS
+    // once and each lane runs a (t+1)-tap filter over it; shape weights are wave-uniform (scalar loads).
+    // t and 30-t go to the same wavefront so that every wavefront filters ~62 taps.
     double accc = 0.0;
 #ifndef RH_EXP_NOGATHER
     if (d >= 2) {
         const int tmax = d - 2 < kMaxSingle ? d - 2 : kMaxSingle;
-        const int cnt = L->shape_cnt[tmax];
-        const double* __restrict__ fcx = tab + L_FCX * ts + (i + 1);
-        // each wavefront takes a contiguous chunk of the shape list (its l1/l2/weight entries are then
-        // adjacent: wide scalar loads); lanes of non-pairable cells read element 0 and are masked out
-        const int chunk = (cnt + W - 1) / W;
-        const int c1 = (w + 1) * chunk < cnt ? (w + 1) * chunk : cnt;
-        const double keep = pairable ? 1.0 : 0.0;
-        const int dm2 = pairable ? d - 2 : 0;
-        int c = w * chunk;
-        constexpr int UG = 8;
-        for (; c + UG <= c1; c += UG) {
-            double v[UG];
+        const int i0 = 1 + slot * 64;
+        const double* __restrict__ fcx = tab + L_FCX * ts;
+        for (int g = w; g <= kMaxSingle / 2; g += W) {
 #pragma unroll
-            for (int u = 0; u < UG; u++) {
-                const int l1 = L->shape_l1[c + u], l2 = L->shape_l2[c + u];
-                const int row = pairable ? dm2 - l1 - l2 : 0;
-                v[u] = fcx[(size_t)row * ld + (pairable ? l1 : 0)];
+            for (int side = 0; side < 2; side++) {
+                const int t = side ? kMaxSingle - g : g;
+                if ((side && t == g) || t > tmax) continue;   // wave-uniform
+                const int col0 = i0 + 1;                      // lane k of the segment = column col0+k of row d-2-t
+                const double* __restrict__ row = fcx + (size_t)(d - 2 - t) * ld + col0;
+                gbuf[w][lane] = col0 + lane < ld ? row[lane] : 0.0;
+                if (lane < 32) gbuf[w][64 + lane] = col0 + 64 + lane < ld ? row[64 + lane] : 0.0;
+                const double* __restrict__ wt = L->shape_w + t * (t + 1) / 2;
+                double sacc = 0.0;
+                for (int l1 = 0; l1 <= t; l1++) sacc = fma(wt[l1], gbuf[w][lane + l1], sacc);
+                accc += sacc;
             }
-#pragma unroll
-            for (int u = 0; u < UG; u++) accc = fma(L->shape_w[c + u], v[u], accc);
         }
-        for (; c < c1; c++) {
-            const int l1 = L->shape_l1[c], l2 = L->shape_l2[c];
-            const int row = pairable ? dm2 - l1 - l2 : 0;
-            accc = fma(L->shape_w[c], fcx[(size_t)row * ld + (pairable ? l1 : 0)], accc);
-        }
-        accc *= keep;
+        if (!pairable) accc = 0.0;
     }
 #endif
 
@@ -237,6 +232,7 @@ template <int W, int BS>
 __global__ __launch_bounds__(64 * W) void lin_outside_diag(McBatch B, const LinModel* __restrict__ L, int d, int pin, int* __restrict__ bad)
 {
     __shared__ double part[3][W][64];
+    __shared__ double gbuf[W][96];
     int sq, slot;
     block_map(pin, &sq, &slot);
     if (sq >= B.ns) return;
@@ -356,35 +352,37 @@ __global__ __launch_bounds__(64 * W) void lin_outside_diag(McBatch B, const LinM
             if (BS > 0 && valid && w == 0) acc1 += tab[L_FM1OF * ts + (size_t)d * ld + i];
         }
     }
-    {   // enclosing single-branch loops: FCoX[d+2+t][i-1-l1] * w_c               (ipp:4004-4024, pulled)
+    {   // enclosing single-branch loops: sum_t sum_l1 w(l1,t-l1) * FCoX[d+2+t][i-1-l1]       (ipp:4004-4024, pulled)
+        // same LDS-staged filter as the inside sweep; a tap is valid when its enclosing pair (i-1-l1, j+1+l2)
+        // is interior: column >= 1 (zero-filled while staging) and l2 = t-l1 <= n-2-j (per-lane mask)
         const int room = n - 4 - d;  // source span d+2+t <= n-2
         if (room >= 0) {
             const int tmax = room < kMaxSingle ? room : kMaxSingle;
-            const int cnt = L->shape_cnt[tmax];
-            const double* __restrict__ fcox = tab + L_FCOX * ts + (i - 1);
-            const int chunk = (cnt + W - 1) / W;
-            const int c1 = (w + 1) * chunk < cnt ? (w + 1) * chunk : cnt;
-            const int l1cap = pairable ? i - 2 : -1, l2cap = n - 2 - j;
-            int c = w * chunk;
-            constexpr int UG = 8;
-            for (; c + UG <= c1; c += UG) {
-                double v[UG];
+            const double* __restrict__ fcox = tab + L_FCOX * ts;
+            const int l2cap = valid ? n - 2 - j : -1;
+            for (int g = w; g <= kMaxSingle / 2; g += W) {
 #pragma unroll
-                for (int u = 0; u < UG; u++) {
-                    const int l1 = L->shape_l1[c + u], l2 = L->shape_l2[c + u];
-                    const bool ok = l1 <= l1cap && l2 <= l2cap;
-                    const double x = fcox[ok ? (size_t)(d + 2 + l1 + l2) * ld - l1 : (size_t)1];
-                    v[u] = ok ? x : 0.0;
+                for (int side = 0; side < 2; side++) {
+                    const int t = side ? kMaxSingle - g : g;
+                    if ((side && t == g) || t > tmax) continue;   // wave-uniform
+                    const int col0 = i0 - 1 - t;                  // segment column of lane k: col0+k; window of cell i: [i-1-t, i-1]
+                    const double* __restrict__ row = fcox + (size_t)(d + 2 + t) * ld;
+                    {
+                        const int c = col0 + lane;
+                        gbuf[w][lane] = (c >= 1 && c < ld) ? row[c] : 0.0;
+                        const int c2 = col0 + 64 + lane;
+                        if (lane < 32) gbuf[w][64 + lane] = (c2 >= 1 && c2 < ld) ? row[c2] : 0.0;
+                    }
+                    const double* __restrict__ wt = L->shape_w + t * (t + 1) / 2;
+                    double sacc = 0.0;
+                    for (int l1 = 0; l1 <= t; l1++) {
+                        const double v = gbuf[w][lane + t - l1];
+                        sacc = fma(wt[l1], (t - l1) <= l2cap ? v : 0.0, sacc);
+                    }
+                    accc += sacc;
                 }
-#pragma unroll
-                for (int u = 0; u < UG; u++) accc = fma(L->shape_w[c + u], v[u], accc);
             }
-            for (; c < c1; c++) {
-                const int l1 = L->shape_l1[c], l2 = L->shape_l2[c];
-                const bool ok = l1 <= l1cap && l2 <= l2cap;
-                const double x = fcox[ok ? (size_t)(d + 2 + l1 + l2) * ld - l1 : (size_t)1];
-                accc = fma(L->shape_w[c], ok ? x : 0.0, accc);
-            }
+            if (!pairable) accc = 0.0;
         }
     }
     part[0][w][lane] = accm;
