@@ -7,7 +7,7 @@ hot path (2x McCaskill inside/outside/posterior + up + duplex fw/bk/posterior)
 over one batch of synthetic pairs (mt19937(12345) stream),
 inputs already resident in HBM when the timed region starts.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--n 500] [--batch B]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--seqlen 500] [--batch B]
 
 N > 1: one process per GPU (launched by torch.distributed.run); independent pairs
 are sharded across ranks (weak scaling, the z-score shard of ractip.cpp:1638-1657)
@@ -59,9 +59,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", type=int, default=500, help="sequence length (BASELINE config 3: 500; config 4: 2000)")
+    ap.add_argument("--seqlen", "--n", dest="n", type=int, default=500,
+                    help="sequence length (BASELINE config 3: 500; config 4: 2000); use --seqlen under torch.distributed.run")
     ap.add_argument("--batch", type=int, default=0, help="pairs per GPU per step (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only for "
+                    "rehearsing the multi-rank path on a one-GPU box, where all ranks share cuda:0)")
     args = ap.parse_args()
 
     import torch
@@ -77,11 +80,15 @@ def main():
                          % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback to measure)")
-    torch.cuda.set_device(local_rank)
+    device_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(args.backend)
 
     n = args.n
     batch = args.batch or (64 if n <= 600 else (16 if n <= 1200 else 4))
@@ -89,7 +96,7 @@ def main():
     all_pairs = random_pairs(batch * world, n, seed=12345)
     pairs = all_pairs[rank * batch:(rank + 1) * batch]
 
-    ctx = ractip_amd.Context(device=local_rank)
+    ctx = ractip_amd.Context(device=device_index)
     ctx.batch_upload(pairs)  # sequences -> HBM, tables allocated: outside the timed region
 
     from ractip_amd import shard
@@ -97,7 +104,8 @@ def main():
     def step():
         ctx.batch_compute()  # all DP kernels, blocks until the device is done
         if dist is not None:  # the shard's only exchange: per-pair scalars to every rank (ractip.cpp:1655-1663)
-            shard.gather_in_order(ctx.batch_logz(), batch * world, dist, device=torch.device("cuda", local_rank))
+            shard.gather_in_order(ctx.batch_logz(), batch * world, dist,
+                                  device=torch.device("cuda", device_index) if args.backend == "nccl" else None)
 
     def fence():
         if dist is not None:
@@ -116,7 +124,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

@@ -75,6 +75,18 @@ for nm, s in (("mt500a", s500a), ("mt500b", s500b)):
     out["mc500/%s/val" % nm] = post[idx]
     print("mc500 %s logZ=%.9f sum=%.9f nnz(>1e-4)=%d" % (nm, z, post.sum(), idx.size))
 
+# n=1000 (several far blocks per tile row in the GPU kernels): scalars + sparse posterior
+s1000 = random_pair(1000)[0]
+post = np.zeros(1001 * 1002 // 2)
+z = lib.ref_inference(s1000.encode(), 0, post.ctypes.data, None, None)
+out["mc1000/seq"] = np.array(s1000)
+out["mc1000/logZ"] = np.array(z)
+out["mc1000/post_sum"] = np.array(post.sum())
+idx = np.flatnonzero(post > 1e-4)
+out["mc1000/idx"] = idx.astype(np.int64)
+out["mc1000/val"] = post[idx]
+print("mc1000 logZ=%.9f sum=%.9f nnz=%d" % (z, post.sum(), idx.size))
+
 pairs = [("DIS", "DIS"), ("CopA", "CopT"), ("IncRNA54", "RepZ"), ("MicA", "ompA"), ("OxyS", "fhlA"),
          ("R1inv", "R2inv"), ("RyhB", "SodB"), ("Tar", "Tarstar"), ("rnd1", "rnd3"), ("rnd5", "rnd8"),
          ("rnd17", "rnd33"), ("rnd40", "rnd64"), ("rnd65", "rnd31"), ("mixedTN", "rnd17"), ("polyA", "polyA"),

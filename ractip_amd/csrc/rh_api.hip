@@ -131,6 +131,12 @@ __global__ __launch_bounds__(256) void cand_write(const double* __restrict__ bas
 
 static thread_local std::string g_create_error;
 
+struct GraphSlot {   // one captured launch sequence (see run_graphed)
+    hipGraphExec_t exec = nullptr;
+    size_t key = 0;
+    int launches = 0;
+};
+
 struct rh_ctx {
     int device = 0;
     int model = 0;
@@ -146,6 +152,8 @@ struct rh_ctx {
     size_t dxl_layout = 0;         // (lda, rows) signature of the zero-padded table image currently in HBM
     int dx_w = 4;                  // wavefronts per 64-cell group of the linear duplex kernel
     int last_dx_path = 0;
+    bool use_graphs = true;        // RH_NO_GRAPH=1 launches every kernel from the host instead
+    GraphSlot g_in, g_out, g_dx;
     int mode = RH_MODE_AUTO;       // which McCaskill path rh_batch_compute takes
     int lin_w = 8;                 // wavefronts per 64-cell group of the linear kernels
     int lin_bs = 16;               // block size of the far/near split of the O(n^3) terms (0 = off)
@@ -351,11 +359,12 @@ int launch_mc_log(rh_ctx* c, int pin)
 //   inside : far(D) right after fine diagonal (D-1)*BS-1  (its operands are final, tile (I,I+D) starts at (D-1)*BS+1)
 //   outside: far(D) right before fine diagonal (D+1)*BS-1 (operands: spans >= (D+1)*BS+1, already final)
 template <int W, int BS>
-int launch_mc_lin(rh_ctx* c, int pin)
+int launch_mc_lin(rh_ctx* c, int pin, int phase)
 {
     const McBatch& B = c->mc;
     int* bad = (int*)c->d_bad;
     const int last_block = BS > 0 ? (B.nmax - 1) / BS : 0;
+    if (phase == 0) {
     hipLaunchKernelGGL(lin_init, dim3((B.ns + 63) / 64), dim3(64), 0, c->s_mc, B, bad);
     for (int d = 0; d <= B.nmax - 1; d++) {
         const int groups = (std::max(B.nmax - 1 - d, 0) + 63) / 64 + 1;
@@ -370,7 +379,8 @@ int launch_mc_lin(rh_ctx* c, int pin)
             }
         }
     }
-    HIP_TRY(c, hipEventRecord(c->ev[1], c->s_mc));
+    return RH_OK;
+    }
     if (BS > 0)  // tiles whose first cell would come before the first outside diagonal: their far sums are empty
         for (int D = last_block; D >= 0 && (D + 1) * BS - 1 > B.nmax - 2; D--)
             hipLaunchKernelGGL(lin_far_outside<(BS > 0 ? BS : 16)>, dim3(last_block - D + 1, B.ns, 2), dim3(256), 0, c->s_mc, B, D);
@@ -393,21 +403,50 @@ int launch_mc_lin(rh_ctx* c, int pin)
 }
 
 template <int BS>
-int launch_mc_lin_w(rh_ctx* c, int pin)
+int launch_mc_lin_w(rh_ctx* c, int pin, int phase)
 {
     switch (c->lin_w) {
-        case 4: return launch_mc_lin<4, BS>(c, pin);
-        case 16: return launch_mc_lin<16, BS>(c, pin);
-        default: return launch_mc_lin<8, BS>(c, pin);
+        case 4: return launch_mc_lin<4, BS>(c, pin, phase);
+        case 16: return launch_mc_lin<16, BS>(c, pin, phase);
+        default: return launch_mc_lin<8, BS>(c, pin, phase);
     }
 }
-int launch_mc_lin_any(rh_ctx* c, int pin)
+int launch_mc_lin_any(rh_ctx* c, int pin, int phase)
 {
     switch (c->lin_bs) {
-        case 0: return launch_mc_lin_w<0>(c, pin);
-        case 32: return launch_mc_lin_w<32>(c, pin);
-        default: return launch_mc_lin_w<16>(c, pin);
+        case 0: return launch_mc_lin_w<0>(c, pin, phase);
+        case 32: return launch_mc_lin_w<32>(c, pin, phase);
+        default: return launch_mc_lin_w<16>(c, pin, phase);
     }
+}
+
+// ---- hipGraph replay of the fast path.  The launch sequence of a batch depends only on its shape (and on the
+// buffer addresses baked into the kernel arguments), so it is captured once per shape and replayed: the ~1000
+// launches per sweep then cost the GPU-side ~1.5 us boundary instead of a host launch each.
+size_t shape_key(const rh_ctx* c, int which);
+
+template <class F>
+int run_graphed(rh_ctx* c, GraphSlot& g, size_t key, hipStream_t stream, int* launch_counter, F&& launch)
+{
+    if (!c->use_graphs) return launch();
+    if (!g.exec || g.key != key) {
+        if (g.exec) { HIP_TRY(c, hipGraphExecDestroy(g.exec)); g.exec = nullptr; }
+        hipGraph_t graph = nullptr;
+        const int before = *launch_counter;
+        HIP_TRY(c, hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+        const int rc = launch();
+        hipError_t e = hipStreamEndCapture(stream, &graph);
+        if (rc) return rc;
+        if (e != hipSuccess) return fail(c, RH_ERR_HIP, "graph capture failed: %s", hipGetErrorString(e));
+        HIP_TRY(c, hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0));
+        HIP_TRY(c, hipGraphDestroy(graph));
+        g.key = key;
+        g.launches = *launch_counter - before;
+        *launch_counter = before;
+    }
+    HIP_TRY(c, hipGraphLaunch(g.exec, stream));
+    *launch_counter += g.launches;
+    return RH_OK;
 }
 
 // ---- duplex sweeps, log-space path
@@ -459,6 +498,25 @@ int launch_dx_lin_any(rh_ctx* c)
     }
 }
 
+size_t shape_key(const rh_ctx* c, int which)
+{
+    auto mix = [](size_t h, size_t v) { return (h ^ v) * 0x100000001b3ull + 0x9e3779b97f4a7c15ull; };
+    size_t h = 1469598103934665603ull + which;
+    if (which <= 1) {
+        const McBatch& B = c->mc;
+        for (size_t v : {(size_t)B.ns, (size_t)B.nmax, (size_t)B.ld, (size_t)B.lds, (size_t)B.tab, (size_t)B.seq, (size_t)B.n,
+                         (size_t)B.f5i, (size_t)B.bp, (size_t)B.up, (size_t)c->d_bad, (size_t)c->d_mclogz, (size_t)c->lin_w,
+                         (size_t)c->lin_bs, (size_t)B.tri_stride})
+            h = mix(h, v);
+    } else {
+        const DxLinBatch& X = c->dxl;
+        for (size_t v : {(size_t)X.np, (size_t)X.n1max, (size_t)X.n2max, (size_t)X.lda, (size_t)X.ldd, (size_t)X.tab, (size_t)X.hp,
+                         (size_t)X.seq, (size_t)X.n, (size_t)c->d_zbar, (size_t)c->d_logz, (size_t)c->d_dxbad, (size_t)c->dx_w})
+            h = mix(h, v);
+    }
+    return h;
+}
+
 int compute(rh_ctx* c)
 {
     HIP_TRY(c, hipSetDevice(c->device));
@@ -475,7 +533,7 @@ int compute(rh_ctx* c)
     bool dx_lin_launched = false;
     if (c->has_dx && !skip_dx) {
         if (c->mode != RH_MODE_LOG) {
-            if ((rc = launch_dx_lin_any(c))) return rc;
+            if ((rc = run_graphed(c, c->g_dx, shape_key(c, 2), c->s_dx, &c->n_launch[2], [&] { return launch_dx_lin_any(c); }))) return rc;
             dx_lin_launched = true;
         } else {
             if ((rc = launch_dx_log(c))) return rc;
@@ -487,7 +545,9 @@ int compute(rh_ctx* c)
     HIP_TRY(c, hipEventRecord(c->ev[0], c->s_mc));
     bool need_log = c->has_mc && c->mode == RH_MODE_LOG && !skip_mc;
     if (c->has_mc && c->mode != RH_MODE_LOG && !skip_mc) {
-        if ((rc = launch_mc_lin_any(c, pin))) return rc;
+        if ((rc = run_graphed(c, c->g_in, shape_key(c, 0), c->s_mc, &c->n_launch[0], [&] { return launch_mc_lin_any(c, pin, 0); }))) return rc;
+        HIP_TRY(c, hipEventRecord(c->ev[1], c->s_mc));
+        if ((rc = run_graphed(c, c->g_out, shape_key(c, 1), c->s_mc, &c->n_launch[1], [&] { return launch_mc_lin_any(c, pin, 1); }))) return rc;
         c->last_path = 1;
         if (c->mode == RH_MODE_AUTO) {  // did every sequence stay inside the double range?
             std::vector<int> bad(c->mc.ns);
@@ -602,6 +662,7 @@ rh_ctx* rh_create(int device, int model, const char* param_file)
     build_dx_lin_model(host_model, 0.65, &c->h_dxlin);
     if (const char* e = std::getenv("RH_LIN_W")) c->lin_w = std::atoi(e);
     if (const char* e = std::getenv("RH_LIN_BS")) c->lin_bs = std::atoi(e);
+    if (const char* e = std::getenv("RH_NO_GRAPH")) c->use_graphs = std::atoi(e) == 0;
     if (const char* e = std::getenv("RH_DX_W")) c->dx_w = std::atoi(e);
     bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&c->s_mc, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&c->s_dx, hipStreamNonBlocking) == hipSuccess &&
@@ -626,6 +687,7 @@ void rh_destroy(rh_ctx* c)
     (void)hipSetDevice(c->device);
     void* bufs[] = {c->d_seq, c->d_n, c->d_mctab, c->d_f5, c->d_bp, c->d_up, c->d_dxtab, c->d_hp, c->d_logz, c->d_scal, c->d_mclogz, c->d_bad, c->d_cnt, c->d_cand, c->d_dxbad, c->d_zbar, c->d_model, c->d_lin, c->d_dxlin};
     for (void* b : bufs) if (b) (void)hipFree(b);
+    for (GraphSlot* g : {&c->g_in, &c->g_out, &c->g_dx}) if (g->exec) (void)hipGraphExecDestroy(g->exec);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->s_mc) (void)hipStreamDestroy(c->s_mc);
     if (c->s_dx) (void)hipStreamDestroy(c->s_dx);

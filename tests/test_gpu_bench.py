@@ -1,0 +1,44 @@
+"""GPU suite: bench.py's contract -- one JSON line with the required fields at N=1, and the multi-rank path
+(torch.distributed.run, shard + gather + max-over-ranks) rehearsed with 2 ranks sharing the one GPU (gloo)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"]
+
+
+def last_json(stdout):
+    return json.loads([l for l in stdout.split("\n") if l.startswith("{")][-1])
+
+
+def test_single_gpu_line(hotlib):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--n", "120", "--batch", "8", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = last_json(r.stdout)
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["unit"] == "pairs/s" and d["value"] > 0
+    assert d["dtype"] == "f64" and d["data"] == "synthetic" and d["vs_baseline"] is None and d["scaling"] == "weak"
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert "workload" in d["config"] and "model" in d["config"] and d["config"]["model"] is None
+
+
+def test_two_ranks_on_one_gpu_gloo(hotlib):
+    port = 29700 + os.getpid() % 200
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--seqlen", "120",
+           "--batch", "8", "--steps", "2", "--warmup", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["cpu_baseline"] is None
+    assert d["config"]["pairs_per_gpu_per_step"] == 8

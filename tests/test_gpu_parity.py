@@ -70,6 +70,15 @@ def test_n500_vs_golden(ctx, golden):
     assert_prob_close(hp[golden["dx500/idx"]], golden["dx500/val"], rel=REL, what="hp n=500")
 
 
+def test_n1000_vs_golden(ctx, golden):
+    """n=1000: every tile row of the blocked kernels has many far blocks; reference posterior (sparse) + logZ."""
+    seq = str(golden["mc1000/seq"])
+    bp, z = ctx.bpp(seq)
+    assert abs(z - float(golden["mc1000/logZ"])) < 1e-8       # SURVEY 8c: 123.307843
+    assert abs(bp.sum() - float(golden["mc1000/post_sum"])) < 1e-6
+    assert_prob_close(bp[golden["mc1000/idx"]], golden["mc1000/val"], rel=REL, what="bp n=1000")
+
+
 def test_random_vs_oracle_ragged_batch(ctx, oracle):
     """Seeded random pairs of unequal lengths in ONE batch (ragged), every matrix vs the oracle."""
     rng = np.random.RandomState(4242)
