@@ -145,12 +145,13 @@ def main():
                            "avg_launch_us": float(ms_k) * 1e3 / max(1, launches),
                            "achieved_GBs": bytes_ / 1e9 / (ms_k / 1e3) if ms_k > 0 else None}
         dom = max(("mc_inside_diag", "mc_outside_diag"), key=lambda k: phases[k]["ms_per_step"])
-        # HBM-side traffic per launch of that kernel: measured separately with rocprofv3 PMC passes
-        # (profiles/pmc_traffic.json); null for configurations that were not profiled
+        # HBM-side traffic per launch of that phase: measured separately with rocprofv3 PMC passes
+        # (profiles/pmc_traffic.json holds bytes per step); null for configurations that were not profiled
         traffic = None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            traffic = tj.get("n%d_b%d" % (n, batch), {}).get(dom)
+            per_step = tj.get("n%d_b%d" % (n, batch), {}).get(dom)
+            traffic = per_step / max(1, phases[dom]["launches"]) if per_step else None
         except (OSError, ValueError):
             pass
         ach = phases[dom]["achieved_GBs"]
