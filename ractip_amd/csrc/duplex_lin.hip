@@ -25,6 +25,28 @@ namespace {
 constexpr uint32_t kPairMaskD = (1u << (0 * 5 + 3)) | (1u << (3 * 5 + 0)) | (1u << (1 * 5 + 2)) |
                                 (1u << (2 * 5 + 1)) | (1u << (2 * 5 + 3)) | (1u << (3 * 5 + 2));
 __device__ __forceinline__ bool pairs(int a, int b) { return (kPairMaskD >> (a * 5 + b)) & 1u; }
+// (T+1)-wide window sum over an LDS-resident segment, fully unrolled (no scalar loop control per tap)
+template <int T>
+__device__ __forceinline__ double win_sum(const double* seg)
+{
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int k = 0; k <= T; k += 2) {
+        s0 += seg[k];
+        if (k + 1 <= T) s1 += seg[k + 1];
+    }
+    return s0 + s1;
+}
+__device__ __forceinline__ double win_sum_any(int t, const double* seg)
+{
+    switch (t) {
+#define X(T) case T: return win_sum<T>(seg);
+        X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22)
+        X(23) X(24) X(25) X(26) X(27) X(28)
+#undef X
+    }
+    return 0.0;
+}
 }  // namespace
 
 // ---------------------------------------------------------------------------------
@@ -34,7 +56,7 @@ __device__ __forceinline__ bool pairs(int a, int b) { return (kPairMaskD >> (a *
 template <int W>
 __global__ __launch_bounds__(64 * W) void dxl_sweep(DxLinBatch B, const DxLinModel* __restrict__ L, int step, int groups)
 {
-    __shared__ double buf[W][96];
+    __shared__ double buf[W][(26 + W - 1) / W][96];
     __shared__ double part[W][64];
     const int pr = blockIdx.y;
     const int L1 = B.n[2 * pr], L2 = B.n[2 * pr + 1];
@@ -56,25 +78,71 @@ __global__ __launch_bounds__(64 * W) void dxl_sweep(DxLinBatch B, const DxLinMod
     const uint8_t* __restrict__ s1 = B.seq + (size_t)(2 * pr) * B.lds;
     const uint8_t* __restrict__ s2 = B.seq + (size_t)(2 * pr + 1) * B.lds;
 
+    const size_t at = (size_t)sd * lda + kDxPad + a;
+    {   // groups entirely outside this diagonal's cells [max(1, sd-L2), min(L1, sd-1)] only clear their columns
+        const int alo = sd - L2 > 1 ? sd - L2 : 1, ahi = sd - 1 < L1 ? sd - 1 : L1;
+        if (a0 + 63 < alo || a0 > ahi) {
+            if (w == 0 && a <= B.n1max + 1) {
+                tab[(outside ? DL_OUT : DL_IN) * ts + at] = 0.0;
+                tab[(outside ? DL_OUTX : DL_INX) * ts + at] = 0.0;
+            }
+            return;
+        }
+    }
     int x = 4, xm = 4, xp = 4, y = 4, ym = 4, yp = 4;  // s1[i], s1[i-1], s1[i+1], s2[j], s2[j-1], s2[j+1]
     if (incell) { x = s1[i]; xm = s1[i - 1]; xp = s1[i + 1]; y = s2[j]; ym = s2[j - 1]; yp = s2[j + 1]; }
     const bool pairable = incell && pairs(x, y);
 
+    // epilogue operands (wave 0): issued before the window work so that their latency hides behind it
+    const double* __restrict__ rawt = tab + (outside ? DL_OUT : DL_IN) * ts + kDxPad;
+    const double* __restrict__ dect = tab + (outside ? DL_OUTX : DL_INX) * ts + kDxPad;
+    double o_st = 0, o_01 = 0, o_10 = 0, o_02 = 0, o_11 = 0, o_20 = 0;
+    double e_up = 0, e_dn = 0, e_ends = 0, e_st = 0, e_b01 = 0, e_b10 = 0, e_11 = 0;
+    if (w == 0 && pairable) {
+        const int dir = outside ? 1 : -1;     // sources lie at rows sd + dir*(2+t), columns a + dir*(1+l1)
+        const int r2 = sd + 2 * dir, r3 = sd + 3 * dir, r4 = sd + 4 * dir;
+        if (r2 >= 2 && r2 <= smax) o_st = rawt[(size_t)r2 * lda + a + dir];
+        if (r3 >= 2 && r3 <= smax) { o_01 = dect[(size_t)r3 * lda + a + dir]; o_10 = dect[(size_t)r3 * lda + a + 2 * dir]; }
+        if (r4 >= 2 && r4 <= smax) {
+            o_02 = dect[(size_t)r4 * lda + a + dir]; o_11 = dect[(size_t)r4 * lda + a + 2 * dir]; o_20 = dect[(size_t)r4 * lda + a + 3 * dir];
+        }
+        e_up = L->E_tm[((x * 5 + y) * 5 + xp) * 5 + ym];                          // terminal_mismatch[s1[i]][s2[j]][s1[i+1]][s2[j-1]]
+        e_dn = L->E_tm[((y * 5 + x) * 5 + yp) * 5 + xm] * L->E_bp[x * 5 + y];     // terminal_mismatch[s2[j]][s1[i]][s2[j+1]][s1[i-1]] * base_pair
+        if (!outside) {
+            e_ends = L->E_dr[y * 25 + x * 5 + xm] * L->E_dl[y * 25 + x * 5 + yp] * L->E_bp[y * 5 + x] * L->E_hc[y * 5 + x];
+            e_st = L->E_bp[x * 5 + y] * L->E_hs[((xm * 5 + yp) * 5 + x) * 5 + y];
+            e_b01 = L->E_b01[yp]; e_b10 = L->E_b10[xm]; e_11 = L->E_11[xm * 5 + yp];
+        } else {
+            e_ends = L->E_dl[x * 25 + y * 5 + xp] * L->E_dr[x * 25 + y * 5 + ym] * L->E_hc[x * 5 + y];
+            e_st = L->E_bp[xp * 5 + ym] * L->E_hs[((x * 5 + y) * 5 + xp) * 5 + ym];
+            e_b01 = L->E_b01[ym]; e_b10 = L->E_b10[xp]; e_11 = L->E_11[xp * 5 + ym];
+        }
+    }
+
     // ---- windows t = 3..28: sum_{l1=0..t} SRC[sd -/+ (2+t)][a -/+ (1+l1)] * lam^(t+2)
     const double* __restrict__ src = tab + (outside ? DL_OUTX : DL_INX) * ts + kDxPad;
     double acc = 0.0;
-    for (int t = 3 + w; t <= 28; t += W) {
+    constexpr int NSEG = (26 + W - 1) / W;   // windows t = 3..28 dealt round-robin to the W wavefronts
+    int tseg[NSEG];
+    // pass 1: stage every segment this wavefront sums (all row loads in flight at once)
+#pragma unroll
+    for (int q = 0; q < NSEG; q++) {
+        const int t = 3 + w + q * W;
         const int row = outside ? sd + 2 + t : sd - 2 - t;
-        if (row < 2 || row > smax) continue;  // wave-uniform
-        // segment start: inside a0-1-t (window = [a-1-t, a-1]); outside a0+1 (window = [a+1, a+1+t])
-        const int c0 = outside ? a0 + 1 : a0 - 1 - t;
-        const double* __restrict__ r = src + (size_t)row * lda + c0;
-        buf[w][lane] = r[lane];
-        if (lane < 32) buf[w][64 + lane] = r[64 + lane];
-        double sum = 0.0;
-        for (int k = 0; k <= t; k++) sum += buf[w][lane + k];
-        acc = fma(L->lam_pow[t + 2], sum, acc);
+        const bool on = t <= 28 && row >= 2 && row <= smax;   // wave-uniform
+        tseg[q] = on ? t : -1;
+        if (on) {
+            // segment start: inside a0-1-t (window = [a-1-t, a-1]); outside a0+1 (window = [a+1, a+1+t])
+            const int c0 = outside ? a0 + 1 : a0 - 1 - t;
+            const double* __restrict__ r = src + (size_t)row * lda + c0;
+            buf[w][q][lane] = r[lane];
+            if (lane < 32) buf[w][q][64 + lane] = r[64 + lane];
+        }
     }
+    // pass 2: the window sums
+#pragma unroll
+    for (int q = 0; q < NSEG; q++)
+        if (tseg[q] >= 0) acc = fma(L->lam_pow[tseg[q] + 2], win_sum_any(tseg[q], &buf[w][q][lane]), acc);
     part[w][lane] = acc;
     __syncthreads();
     if (w != 0) return;
@@ -82,42 +150,16 @@ __global__ __launch_bounds__(64 * W) void dxl_sweep(DxLinBatch B, const DxLinMod
 #pragma unroll
     for (int k = 0; k < W; k++) g += part[k][lane];
 
-    const size_t at = (size_t)sd * lda + kDxPad + a;
     double v = 0.0, vx = 0.0;
     if (pairable) {
-        const int tm_up = ((x * 5 + y) * 5 + xp) * 5 + ym;    // terminal_mismatch[s1[i]][s2[j]][s1[i+1]][s2[j-1]]
-        const int tm_dn = ((y * 5 + x) * 5 + yp) * 5 + xm;    // terminal_mismatch[s2[j]][s1[i]][s2[j+1]][s1[i-1]]
-        const double e_up = L->E_tm[tm_up], e_dn = L->E_tm[tm_dn] * L->E_bp[x * 5 + y];
+        // inside : inside[i][j]  = open  + stack + down * (0x1/1x0/t=2 shapes + windows)   (DuplexEngine.ipp:1029-1064)
+        // outside: outside[p][q] = close + stack + up   * (...)                             (DuplexEngine.ipp:1094-1129, pulled)
         const double l2 = L->lam_pow[2], l3 = L->lam_pow[3], l4 = L->lam_pow[4];
-        if (!outside) {
-            // inside[i][j] = open + stack + down * (specials + windows)          (DuplexEngine.ipp:1029-1064)
-            const double* __restrict__ inx = tab + DL_INX * ts + kDxPad;
-            const double* __restrict__ in = tab + DL_IN * ts + kDxPad;
-            const double open = B.pw_in[which] * L->E_dr[y * 25 + x * 5 + xm] * L->E_dl[y * 25 + x * 5 + yp] *
-                                L->E_bp[y * 5 + x] * L->E_hc[y * 5 + x];
-            const double st = sd >= 4 ? in[(size_t)(sd - 2) * lda + a - 1] * l2 * L->E_bp[x * 5 + y] *
-                                            L->E_hs[((xm * 5 + yp) * 5 + x) * 5 + y] : 0.0;
-            double sp = 0.0;
-            if (sd >= 5) sp += l3 * (L->E_b01[yp] * inx[(size_t)(sd - 3) * lda + a - 1] + L->E_b10[xm] * inx[(size_t)(sd - 3) * lda + a - 2]);
-            if (sd >= 6) sp += l4 * (inx[(size_t)(sd - 4) * lda + a - 1] + L->E_11[xm * 5 + yp] * inx[(size_t)(sd - 4) * lda + a - 2] +
-                                     inx[(size_t)(sd - 4) * lda + a - 3]);
-            v = open + st + e_dn * (sp + g);
-            vx = v * e_up;      // as the upstream pair of a later loop
-        } else {
-            // outside[p][q] = close + stack + up * (specials + windows)           (DuplexEngine.ipp:1094-1129, pulled)
-            const double* __restrict__ outx = tab + DL_OUTX * ts + kDxPad;
-            const double* __restrict__ out = tab + DL_OUT * ts + kDxPad;
-            const double close = B.pw_out[which] * L->E_dl[x * 25 + y * 5 + xp] * L->E_dr[x * 25 + y * 5 + ym] * L->E_hc[x * 5 + y];
-            // (i+1, j-1) stacked on this pair: base_pair[s1[i+1]][s2[j-1]] * helix_stacking[s1[i]][s2[j]][s1[i+1]][s2[j-1]]
-            const double st = sd + 2 <= smax ? out[(size_t)(sd + 2) * lda + a + 1] * l2 * L->E_bp[xp * 5 + ym] *
-                                                   L->E_hs[((x * 5 + y) * 5 + xp) * 5 + ym] : 0.0;
-            double sp = 0.0;
-            if (sd + 3 <= smax) sp += l3 * (L->E_b01[ym] * outx[(size_t)(sd + 3) * lda + a + 1] + L->E_b10[xp] * outx[(size_t)(sd + 3) * lda + a + 2]);
-            if (sd + 4 <= smax) sp += l4 * (outx[(size_t)(sd + 4) * lda + a + 1] + L->E_11[xp * 5 + ym] * outx[(size_t)(sd + 4) * lda + a + 2] +
-                                            outx[(size_t)(sd + 4) * lda + a + 3]);
-            v = close + st + e_up * (sp + g);
-            vx = v * e_dn;      // as the downstream pair of an earlier loop
-        }
+        const double ends = (outside ? B.pw_out[which] : B.pw_in[which]) * e_ends;
+        const double sp = l3 * (e_b01 * o_01 + e_b10 * o_10) + l4 * (o_02 + e_11 * o_11 + o_20);
+        const double own = outside ? e_up : e_dn;      // this cell's factor of every loop term
+        v = ends + o_st * l2 * e_st + own * (sp + g);
+        vx = v * (outside ? e_dn : e_up);              // decorated as the other end of a later loop
     }
     if (a <= B.n1max + 1) {  // every column of the row is rewritten: stale values of other shapes never survive
         tab[(outside ? DL_OUT : DL_IN) * ts + at] = v;

@@ -42,6 +42,53 @@ __device__ __forceinline__ void block_map(int pin, int* sq, int* slot)
     *slot = pin ? blockIdx.y : blockIdx.x;
 }
 
+// (T+1)-tap filter over an LDS-resident row segment, fully unrolled: the weights are consecutive and
+// wave-uniform (wide scalar loads), every tap is one ds_read + one FMA and there is no loop control on the
+// scalar unit (a rolled loop costs ~5 SALU instructions per tap and the CU has ONE scalar ALU: measured
+// 2.4 SALU per VALU instruction before unrolling).
+template <int T>
+__device__ __forceinline__ double filt_fwd(const double* __restrict__ wt, const double* seg)
+{   // sum_l1 wt[l1] * seg[l1]
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int l1 = 0; l1 <= T; l1 += 2) {
+        s0 = fma(wt[l1], seg[l1], s0);
+        if (l1 + 1 <= T) s1 = fma(wt[l1 + 1], seg[l1 + 1], s1);
+    }
+    return s0 + s1;
+}
+template <int T>
+__device__ __forceinline__ double filt_rev(const double* __restrict__ wt, const double* seg)
+{   // sum_l1 wt[l1] * seg[T-l1]
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int l1 = 0; l1 <= T; l1 += 2) {
+        s0 = fma(wt[l1], seg[T - l1], s0);
+        if (l1 + 1 <= T) s1 = fma(wt[l1 + 1], seg[T - l1 - 1], s1);
+    }
+    return s0 + s1;
+}
+#define RH_T_CASES(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) \
+    X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30)
+__device__ __forceinline__ double filt_fwd_any(int t, const double* __restrict__ wt, const double* seg)
+{
+    switch (t) {
+#define X(T) case T: return filt_fwd<T>(wt, seg);
+        RH_T_CASES(X)
+#undef X
+    }
+    return 0.0;
+}
+__device__ __forceinline__ double filt_rev_any(int t, const double* __restrict__ wt, const double* seg)
+{
+    switch (t) {
+#define X(T) case T: return filt_rev<T>(wt, seg);
+        RH_T_CASES(X)
+#undef X
+    }
+    return 0.0;
+}
+
 }  // namespace
 
 enum LinTable { L_FC = 0, L_FCX, L_FCA, L_FM1, L_FM, L_FCO, L_FCOX, L_FM2O, L_FMO, L_FM1O,
@@ -68,7 +115,7 @@ template <int W, int BS>
 __global__ __launch_bounds__(64 * W) void lin_inside_diag(McBatch B, const LinModel* __restrict__ L, int d, double lam_d, int pin)
 {
     __shared__ double part[2][W][64];
-    __shared__ double gbuf[W][96];
+    __shared__ double gbuf[W][2 * ((kMaxSingle / 2 + W) / W)][96];
     int sq, slot;
     block_map(pin, &sq, &slot);
     if (sq >= B.ns) return;
@@ -82,7 +129,7 @@ __global__ __launch_bounds__(64 * W) void lin_inside_diag(McBatch B, const LinMo
     const size_t ts = B.tab_stride;
     const uint8_t* __restrict__ s = B.seq + (size_t)sq * B.lds;
     double* __restrict__ tab = B.tab + (size_t)sq * B.seq_stride;
-    double* __restrict__ f5i = B.f5i + (size_t)sq * ld;
+    double* __restrict__ f5i = B.f5i + sq * ld;
 
     if (slot == ngroup) {
         // F5i[jj] = F5i[jj-1]*ext_unpaired + sum_{k<=jj-2} F5i[k]*FCA[k+1,jj-1]*ext_paired   (ipp:3692-3717)
@@ -90,7 +137,7 @@ __global__ __launch_bounds__(64 * W) void lin_inside_diag(McBatch B, const LinMo
         const int jj = d + 1;
         const double* __restrict__ fca = tab + L_FCA * ts;
         double acc = 0.0;
-        for (int k = threadIdx.x; k <= jj - 2; k += 64 * W) acc = fma(f5i[k], fca[(size_t)(jj - 2 - k) * ld + (k + 1)], acc);
+        for (int k = threadIdx.x; k <= jj - 2; k += 64 * W) acc = fma(f5i[k], fca[(jj - 2 - k) * ld + (k + 1)], acc);
         acc = wsum(acc);
         if (lane == 0) part[0][w][0] = acc;
         __syncthreads();
@@ -110,7 +157,7 @@ __global__ __launch_bounds__(64 * W) void lin_inside_diag(McBatch B, const LinMo
     const bool pairable = valid && pairs(s_i, s_jp1);
 
     // epilogue operands (wave 0 only): issued now so that their latency hides behind the term loops
-    const size_t at = (size_t)d * ld + i;
+    const size_t at = d * ld + i;
     const int idx = 25 * (5 * s_i + s_ip1) + 5 * s_jp1 + s_j;       // (i,j)   as enclosing pair
     const int idd = 25 * (5 * s_jp1 + s_jp2) + 5 * s_i + s_im1;     // (j+1,i-1) as enclosed pair
     double e_tjb = 0, e_tja = 0, e_tst = 0, e_bp = 0, e_tjbd = 0, e_tjad = 0, e_n01 = 0, e_n10 = 0, e_n11 = 0;
@@ -121,15 +168,15 @@ __global__ __launch_bounds__(64 * W) void lin_inside_diag(McBatch B, const LinMo
         e_n01 = L->E_b01[s_j]; e_n10 = L->E_b10[s_ip1]; e_n11 = L->E_11[s_ip1 * 5 + s_j];
         if (d >= 3) {
             const double* __restrict__ fcx = tab + L_FCX * ts;
-            o_x01 = fcx[(size_t)(d - 3) * ld + i + 1];
-            o_x10 = fcx[(size_t)(d - 3) * ld + i + 2];
-            if (d >= 4) o_x11 = fcx[(size_t)(d - 4) * ld + i + 2];
+            o_x01 = fcx[(d - 3) * ld + i + 1];
+            o_x10 = fcx[(d - 3) * ld + i + 2];
+            if (d >= 4) o_x11 = fcx[(d - 4) * ld + i + 2];
         }
         if (d >= 2) {
-            o_fc = tab[L_FC * ts + (size_t)(d - 2) * ld + i + 1];
-            o_fca = tab[L_FCA * ts + (size_t)(d - 2) * ld + i + 1];
-            o_fm1 = tab[L_FM1 * ts + (size_t)(d - 1) * ld + i + 1];
-            o_fm = tab[L_FM * ts + (size_t)(d - 1) * ld + i];
+            o_fc = tab[L_FC * ts + (d - 2) * ld + i + 1];
+            o_fca = tab[L_FCA * ts + (d - 2) * ld + i + 1];
+            o_fm1 = tab[L_FM1 * ts + (d - 1) * ld + i + 1];
+            o_fm = tab[L_FM * ts + (d - 1) * ld + i];
         }
     }
 
@@ -159,14 +206,14 @@ __global__ __launch_bounds__(64 * W) void lin_inside_diag(McBatch B, const LinMo
                 for (int u = 0; u < UF; u++) {
                     const int mm = m + u * W, k = i + mm;
                     const bool ok = valid && mm <= hi && (k < kA || k >= kB);
-                    a[u] = ok ? fm1[(size_t)mm * ld] : 0.0;
-                    b[u] = ok ? fm[(size_t)(d - mm) * ld + mm] : 0.0;
+                    a[u] = ok ? fm1[mm * ld] : 0.0;
+                    b[u] = ok ? fm[(d - mm) * ld + mm] : 0.0;
                 }
 #pragma unroll
                 for (int u = 0; u < UF; u++) acc2 = fma(a[u], b[u], acc2);
             }
         }
-        if (BS > 0 && valid && kB > 0) acc2 += (w == 0) ? tab[L_FM2F * ts + (size_t)d * ld + i] : 0.0;
+        if (BS > 0 && valid && kB > 0) acc2 += (w == 0) ? tab[L_FM2F * ts + d * ld + i] : 0.0;
     }
 #endif
 
@@ -180,21 +227,26 @@ __global__ __launch_bounds__(64 * W) void lin_inside_diag(McBatch B, const LinMo
         const int tmax = d - 2 < kMaxSingle ? d - 2 : kMaxSingle;
         const int i0 = 1 + slot * 64;
         const double* __restrict__ fcx = tab + L_FCX * ts;
-        for (int g = w; g <= kMaxSingle / 2; g += W) {
+        // pass 1: stage every segment this wavefront filters (all row loads in flight at once)
+        constexpr int NSEG = 2 * ((kMaxSingle / 2 + W) / W);     // <= 4 for W = 8
+        int tseg[NSEG];
 #pragma unroll
-            for (int side = 0; side < 2; side++) {
-                const int t = side ? kMaxSingle - g : g;
-                if ((side && t == g) || t > tmax) continue;   // wave-uniform
+        for (int q = 0; q < NSEG; q++) {
+            const int g = w + (q >> 1) * W;
+            const int t = (q & 1) ? kMaxSingle - g : g;
+            const bool on = g <= kMaxSingle / 2 && !((q & 1) && t == g) && t <= tmax;   // wave-uniform
+            tseg[q] = on ? t : -1;
+            if (on) {
                 const int col0 = i0 + 1;                      // lane k of the segment = column col0+k of row d-2-t
-                const double* __restrict__ row = fcx + (size_t)(d - 2 - t) * ld + col0;
-                gbuf[w][lane] = col0 + lane < ld ? row[lane] : 0.0;
-                if (lane < 32) gbuf[w][64 + lane] = col0 + 64 + lane < ld ? row[64 + lane] : 0.0;
-                const double* __restrict__ wt = L->shape_w + t * (t + 1) / 2;
-                double sacc = 0.0;
-                for (int l1 = 0; l1 <= t; l1++) sacc = fma(wt[l1], gbuf[w][lane + l1], sacc);
-                accc += sacc;
+                const double* __restrict__ row = fcx + (d - 2 - t) * ld + col0;
+                gbuf[w][q][lane] = col0 + lane < ld ? row[lane] : 0.0;
+                if (lane < 32) gbuf[w][q][64 + lane] = col0 + 64 + lane < ld ? row[64 + lane] : 0.0;
             }
         }
+        // pass 2: the filters
+#pragma unroll
+        for (int q = 0; q < NSEG; q++)
+            if (tseg[q] >= 0) accc += filt_fwd_any(tseg[q], L->shape_w + tseg[q] * (tseg[q] + 1) / 2, &gbuf[w][q][lane]);
         if (!pairable) accc = 0.0;
     }
 #endif
@@ -232,7 +284,7 @@ template <int W, int BS>
 __global__ __launch_bounds__(64 * W) void lin_outside_diag(McBatch B, const LinModel* __restrict__ L, int d, int pin, int* __restrict__ bad)
 {
     __shared__ double part[3][W][64];
-    __shared__ double gbuf[W][96];
+    __shared__ double gbuf[W][2 * ((kMaxSingle / 2 + W) / W)][96];
     int sq, slot;
     block_map(pin, &sq, &slot);
     if (sq >= B.ns) return;
@@ -246,15 +298,15 @@ __global__ __launch_bounds__(64 * W) void lin_outside_diag(McBatch B, const LinM
     const size_t ts = B.tab_stride;
     const uint8_t* __restrict__ s = B.seq + (size_t)sq * B.lds;
     double* __restrict__ tab = B.tab + (size_t)sq * B.seq_stride;
-    const double* __restrict__ f5i = B.f5i + (size_t)sq * ld;
-    double* __restrict__ f5o = B.f5o + (size_t)sq * ld;
+    const double* __restrict__ f5i = B.f5i + sq * ld;
+    double* __restrict__ f5o = B.f5o + sq * ld;
 
     if (slot == ngroup) {
         // F5o[k] = F5o[k+1]*ext_unpaired + sum_{jj>=k+2} F5o[jj]*FCA[k+1,jj-1]*ext_paired   (ipp:3751-3780, pulled)
         const int k = d + 1;
         const double* __restrict__ fca = tab + L_FCA * ts + (k + 1);
         double acc = 0.0;
-        for (int jj = k + 2 + threadIdx.x; jj <= n; jj += 64 * W) acc = fma(f5o[jj], fca[(size_t)(jj - 2 - k) * ld], acc);
+        for (int jj = k + 2 + threadIdx.x; jj <= n; jj += 64 * W) acc = fma(f5o[jj], fca[(jj - 2 - k) * ld], acc);
         acc = wsum(acc);
         if (lane == 0) part[0][w][0] = acc;
         __syncthreads();
@@ -276,7 +328,7 @@ __global__ __launch_bounds__(64 * W) void lin_outside_diag(McBatch B, const LinM
     const bool guard_m = d >= 2;
 
     // epilogue operands (wave 0 only), issued ahead of the term loops
-    const size_t at = (size_t)d * ld + i;
+    const size_t at = d * ld + i;
     const bool up_ok = i - 1 >= 1 && j + 1 <= n - 1;  // the cell (i-1, j+1) is interior
     const int idx = 25 * (5 * s_i + s_ip1) + 5 * s_jp1 + s_j;
     const int idd = 25 * (5 * s_jp1 + s_jp2) + 5 * s_i + s_im1;
@@ -288,19 +340,19 @@ __global__ __launch_bounds__(64 * W) void lin_outside_diag(McBatch B, const LinM
         e_tst = L->TST[25 * (5 * s_im1 + s_i) + 5 * s_jp2 + s_jp1];
         e_n01 = L->E_b01[s_jp2]; e_n10 = L->E_b10[s_im1]; e_n11 = L->E_11[s_im1 * 5 + s_jp2];
         if (guard_m) {
-            if (j + 1 <= n - 1) o_fmo = tab[L_FMO * ts + (size_t)(d + 1) * ld + i];            // ipp:3806
-            if (i - 1 >= 1) o_fm1o = tab[L_FM1O * ts + (size_t)(d + 1) * ld + i - 1];            // ipp:3833
+            if (j + 1 <= n - 1) o_fmo = tab[L_FMO * ts + (d + 1) * ld + i];            // ipp:3806
+            if (i - 1 >= 1) o_fm1o = tab[L_FM1O * ts + (d + 1) * ld + i - 1];            // ipp:3833
         }
         o_f5o = f5o[j + 1]; o_f5i = f5i[i - 1]; o_z = f5i[n];
         o_fc = tab[L_FC * ts + at];
         const double* __restrict__ fcox = tab + L_FCOX * ts;
         if (up_ok) {
-            o_fm1o_up = tab[L_FM1O * ts + (size_t)(d + 2) * ld + i - 1];                         // ipp:3828
-            o_fco_up = tab[L_FCO * ts + (size_t)(d + 2) * ld + i - 1];
+            o_fm1o_up = tab[L_FM1O * ts + (d + 2) * ld + i - 1];                         // ipp:3828
+            o_fco_up = tab[L_FCO * ts + (d + 2) * ld + i - 1];
         }
-        if (i - 1 >= 1 && j + 2 <= n - 1) o_x01 = fcox[(size_t)(d + 3) * ld + i - 1];
-        if (i - 2 >= 1 && j + 1 <= n - 1) o_x10 = fcox[(size_t)(d + 3) * ld + i - 2];
-        if (i - 2 >= 1 && j + 2 <= n - 1) o_x11 = fcox[(size_t)(d + 4) * ld + i - 2];
+        if (i - 1 >= 1 && j + 2 <= n - 1) o_x01 = fcox[(d + 3) * ld + i - 1];
+        if (i - 2 >= 1 && j + 1 <= n - 1) o_x10 = fcox[(d + 3) * ld + i - 2];
+        if (i - 2 >= 1 && j + 2 <= n - 1) o_x11 = fcox[(d + 4) * ld + i - 2];
     }
 
     double accm = 0.0, acc1 = 0.0, accc = 0.0;
@@ -321,13 +373,13 @@ __global__ __launch_bounds__(64 * W) void lin_outside_diag(McBatch B, const LinM
                 for (int u = 0; u < UO; u++) {
                     const int ee = e + u * W;
                     const bool ok = ee <= mine;
-                    xv[u] = ok ? x[(size_t)(d + ee) * ld - ee] : 0.0;
-                    yv[u] = ok ? y[(size_t)ee * ld - ee] : 0.0;
+                    xv[u] = ok ? x[(d + ee) * ld - ee] : 0.0;
+                    yv[u] = ok ? y[ee * ld - ee] : 0.0;
                 }
 #pragma unroll
                 for (int u = 0; u < UO; u++) accm = fma(xv[u], yv[u], accm);
             }
-            if (BS > 0 && valid && w == 0) accm += tab[L_FMOF * ts + (size_t)d * ld + i];
+            if (BS > 0 && valid && w == 0) accm += tab[L_FMOF * ts + d * ld + i];
         }
         // FM1o[i,d] += FM2o[d+e][i] * FM[e][i+d], e = 1..n-1-j; blocks >= J+2 come from FM1OF
         {
@@ -343,45 +395,44 @@ __global__ __launch_bounds__(64 * W) void lin_outside_diag(McBatch B, const LinM
                 for (int u = 0; u < UO; u++) {
                     const int ee = e + u * W;
                     const bool ok = ee <= mine;
-                    xv[u] = ok ? x[(size_t)(d + ee) * ld] : 0.0;
-                    yv[u] = ok ? y[(size_t)ee * ld] : 0.0;
+                    xv[u] = ok ? x[(d + ee) * ld] : 0.0;
+                    yv[u] = ok ? y[ee * ld] : 0.0;
                 }
 #pragma unroll
                 for (int u = 0; u < UO; u++) acc1 = fma(xv[u], yv[u], acc1);
             }
-            if (BS > 0 && valid && w == 0) acc1 += tab[L_FM1OF * ts + (size_t)d * ld + i];
+            if (BS > 0 && valid && w == 0) acc1 += tab[L_FM1OF * ts + d * ld + i];
         }
     }
     {   // enclosing single-branch loops: sum_t sum_l1 w(l1,t-l1) * FCoX[d+2+t][i-1-l1]       (ipp:4004-4024, pulled)
         // same LDS-staged filter as the inside sweep; a tap is valid when its enclosing pair (i-1-l1, j+1+l2)
-        // is interior: column >= 1 (zero-filled while staging) and l2 = t-l1 <= n-2-j (per-lane mask)
+        // is interior, i.e. when its column lies in [1, n-1-row] of the source row: the segment is zero-filled
+        // outside that range while it is staged, so the taps themselves need no mask
         const int room = n - 4 - d;  // source span d+2+t <= n-2
         if (room >= 0) {
             const int tmax = room < kMaxSingle ? room : kMaxSingle;
             const double* __restrict__ fcox = tab + L_FCOX * ts;
-            const int l2cap = valid ? n - 2 - j : -1;
-            for (int g = w; g <= kMaxSingle / 2; g += W) {
+            constexpr int NSEG = 2 * ((kMaxSingle / 2 + W) / W);
+            int tseg[NSEG];
 #pragma unroll
-                for (int side = 0; side < 2; side++) {
-                    const int t = side ? kMaxSingle - g : g;
-                    if ((side && t == g) || t > tmax) continue;   // wave-uniform
+            for (int q = 0; q < NSEG; q++) {
+                const int g = w + (q >> 1) * W;
+                const int t = (q & 1) ? kMaxSingle - g : g;
+                const bool on = g <= kMaxSingle / 2 && !((q & 1) && t == g) && t <= tmax;   // wave-uniform
+                tseg[q] = on ? t : -1;
+                if (on) {
                     const int col0 = i0 - 1 - t;                  // segment column of lane k: col0+k; window of cell i: [i-1-t, i-1]
-                    const double* __restrict__ row = fcox + (size_t)(d + 2 + t) * ld;
-                    {
-                        const int c = col0 + lane;
-                        gbuf[w][lane] = (c >= 1 && c < ld) ? row[c] : 0.0;
-                        const int c2 = col0 + 64 + lane;
-                        if (lane < 32) gbuf[w][64 + lane] = (c2 >= 1 && c2 < ld) ? row[c2] : 0.0;
-                    }
-                    const double* __restrict__ wt = L->shape_w + t * (t + 1) / 2;
-                    double sacc = 0.0;
-                    for (int l1 = 0; l1 <= t; l1++) {
-                        const double v = gbuf[w][lane + t - l1];
-                        sacc = fma(wt[l1], (t - l1) <= l2cap ? v : 0.0, sacc);
-                    }
-                    accc += sacc;
+                    const double* __restrict__ row = fcox + (d + 2 + t) * ld;
+                    const int cmax = n - 1 - (d + 2 + t);         // last interior column of that row
+                    const int c = col0 + lane;
+                    gbuf[w][q][lane] = (c >= 1 && c <= cmax) ? row[c] : 0.0;
+                    const int c2 = col0 + 64 + lane;
+                    if (lane < 32) gbuf[w][q][64 + lane] = (c2 >= 1 && c2 <= cmax) ? row[c2] : 0.0;
                 }
             }
+#pragma unroll
+            for (int q = 0; q < NSEG; q++)
+                if (tseg[q] >= 0) accc += filt_rev_any(tseg[q], L->shape_w + tseg[q] * (tseg[q] + 1) / 2, &gbuf[w][q][lane]);
             if (!pairable) accc = 0.0;
         }
     }
