@@ -203,7 +203,7 @@ __global__ __launch_bounds__(1024) void dxl_logz(DxLinBatch B, const DxLinModel*
         zbar[pr] = z;
         // no complementary pair at all: the reference leaves logZ at its -2e20 sentinel and hp at zero
         if (!any) { logz[pr] = RH_NEG_INF; bad[pr] = 0; return; }
-        bad[pr] = (z > 1e-280 && z < 1e280) ? 0 : 1;
+        bad[pr] = (z > 1e-200 && z < 1e200) ? 0 : 1;
         logz[pr] = log(z) + L->s * (double)(L1 + L2 + 2);
     }
 }

@@ -148,6 +148,107 @@ __global__ __launch_bounds__(256) void lin_far_outside(McBatch B, int D)
     }
 }
 
+// ---------------------------------------------------------------------------------
+// f64-MFMA variant for BS = 16 (the dense-contraction recast of the multiloop term): one wavefront owns
+// one 16x16x16 operand-chunk product = 4 x v_mfma_f64_16x16x4_f64; the 4 wavefronts of a workgroup take
+// every 4th operand block of the tile (split-K), stage their chunks in private LDS (no workgroup barrier in
+// the K loop) and meet once at the end.  Lane layout of the instruction (cdna_hip_programming.md section 3):
+// A[l&15][l>>4], B[l>>4][l&15], D reg r -> row (l>>4)+4r, col l&15.
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+template <bool TR>
+__device__ __forceinline__ void load_chunk16_wave(double (*dst)[17], const double* __restrict__ T, int ld, int n, int x0, int y0)
+{
+    const int lane = threadIdx.x & 63;
+    const int u = lane & 15;
+#pragma unroll
+    for (int pass = 0; pass < 8; pass++) {
+        const int v = u + (lane >> 4) + 4 * pass - 15;
+        if (v >= 0 && v < 16) {
+            const double val = cellv(T, ld, n, x0 + u, y0 + v);
+            if (TR) dst[v][u] = val; else dst[u][v] = val;
+        }
+    }
+}
+
+__device__ __forceinline__ d4 mfma_chunk(const double (*A)[17], const double (*Bm)[17], d4 acc)
+{
+    const int lane = threadIdx.x & 63;
+    const int r = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int s = 0; s < 4; s++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[r][4 * s + q], Bm[4 * s + q][r], acc, 0, 0, 0);
+    return acc;
+}
+
+// sum the 4 wavefronts' accumulators and store the tile (wave 0)
+__device__ __forceinline__ void reduce_store(double (*red)[256], d4 acc, double* __restrict__ T, int ld, int n, int i0, int j0)
+{
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int r = 0; r < 4; r++) red[w][r * 64 + lane] = acc[r];
+    __syncthreads();
+    if (w != 0) return;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const double v = red[0][r * 64 + lane] + red[1][r * 64 + lane] + red[2][r * 64 + lane] + red[3][r * 64 + lane];
+        const int i = i0 + (lane >> 4) + 4 * r, j = j0 + (lane & 15);
+        if (i >= 1 && i <= j && j <= n - 1) T[(size_t)(j - i) * ld + i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void lin_far_inside_mfma(McBatch B, int D)
+{
+    __shared__ double A[4][16][17], Bm[4][16][17], red[4][256];
+    const int sq = blockIdx.y;
+    const int n = B.n[sq];
+    const int I = blockIdx.x, J = I + D;
+    if (J * 16 > n - 1) return;
+    const int w = threadIdx.x >> 6;
+    const int ld = B.ld;
+    double* __restrict__ tab = B.tab + (size_t)sq * B.seq_stride;
+    const double* __restrict__ fm1 = tab + (size_t)LF_FM1 * B.tab_stride;
+    const double* __restrict__ fm = tab + (size_t)LF_FM * B.tab_stride;
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+    for (int K = I + 2 + w; K <= J - 2; K += 4) {
+        load_chunk16_wave<false>(A[w], fm1, ld, n, I * 16, K * 16);
+        load_chunk16_wave<false>(Bm[w], fm, ld, n, K * 16, J * 16);
+        acc = mfma_chunk(A[w], Bm[w], acc);
+    }
+    reduce_store(red, acc, tab + (size_t)LF_FM2F * B.tab_stride, ld, n, I * 16, J * 16);
+}
+
+__global__ __launch_bounds__(256) void lin_far_outside_mfma(McBatch B, int D)
+{
+    __shared__ double A[4][16][17], Bm[4][16][17], red[4][256];
+    const int sq = blockIdx.y;
+    const int n = B.n[sq];
+    const int I = blockIdx.x, J = I + D;
+    if (J * 16 > n - 1) return;
+    const int w = threadIdx.x >> 6;
+    const int ld = B.ld;
+    double* __restrict__ tab = B.tab + (size_t)sq * B.seq_stride;
+    const double* __restrict__ fm1 = tab + (size_t)LF_FM1 * B.tab_stride;
+    const double* __restrict__ fm = tab + (size_t)LF_FM * B.tab_stride;
+    const double* __restrict__ fm2o = tab + (size_t)LF_FM2O * B.tab_stride;
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+    if (blockIdx.z == 0) {
+        for (int K = w; K <= I - 2; K += 4) {
+            load_chunk16_wave<true>(A[w], fm1, ld, n, K * 16, I * 16);     // A[r][kk]  = FM1 [k0+kk, i0+r]
+            load_chunk16_wave<false>(Bm[w], fm2o, ld, n, K * 16, J * 16);  // Bm[kk][c] = FM2o[k0+kk, j0+c]
+            acc = mfma_chunk(A[w], Bm[w], acc);
+        }
+        reduce_store(red, acc, tab + (size_t)LF_FMOF * B.tab_stride, ld, n, I * 16, J * 16);
+    } else {
+        const int last = (n - 1) / 16;
+        for (int K = J + 2 + w; K <= last; K += 4) {
+            load_chunk16_wave<false>(A[w], fm2o, ld, n, I * 16, K * 16);   // A[r][kk]  = FM2o[i0+r, k0+kk]
+            load_chunk16_wave<true>(Bm[w], fm, ld, n, J * 16, K * 16);     // Bm[kk][c] = FM  [j0+c, k0+kk]
+            acc = mfma_chunk(A[w], Bm[w], acc);
+        }
+        reduce_store(red, acc, tab + (size_t)LF_FM1OF * B.tab_stride, ld, n, I * 16, J * 16);
+    }
+}
+
 template __global__ void lin_far_inside<16>(McBatch, int);
 template __global__ void lin_far_inside<32>(McBatch, int);
 template __global__ void lin_far_outside<16>(McBatch, int);

@@ -479,7 +479,7 @@ __global__ void lin_finish(McBatch B, const LinModel* __restrict__ L, double* __
     const int n = B.n[sq];
     const double z = B.f5i[(size_t)sq * B.ld + n];
     const double zo = n >= 2 ? B.f5o[(size_t)sq * B.ld + 1] : 1.0;
-    if (!(z > 1e-280 && z < 1e280) || !(zo == zo) || zo > 1e300) atomicOr(&bad[sq], 1);
+    if (!(z > 1e-200 && z < 1e200) || !(zo > 1e-200 && zo < 1e200)) atomicOr(&bad[sq], 1);  // F5o~[1] ~ Z~ too
     logz[sq] = log(z) + L->s * (double)n;
 }
 

@@ -35,6 +35,8 @@ template <int W, int BS> __global__ void lin_inside_diag(McBatch B, const LinMod
 template <int W, int BS> __global__ void lin_outside_diag(McBatch B, const LinModel* __restrict__ L, int d, int pin, int* __restrict__ bad);
 template <int BS> __global__ void lin_far_inside(McBatch B, int D);
 template <int BS> __global__ void lin_far_outside(McBatch B, int D);
+__global__ void lin_far_inside_mfma(McBatch B, int D);
+__global__ void lin_far_outside_mfma(McBatch B, int D);
 __global__ void lin_finish(McBatch B, const LinModel* __restrict__ L, double* __restrict__ logz, int* __restrict__ bad);
 template <int W> __global__ void dxl_sweep(DxLinBatch B, const DxLinModel* __restrict__ L, int step, int groups);
 __global__ void dxl_logz(DxLinBatch B, const DxLinModel* __restrict__ L, double* __restrict__ zbar, double* __restrict__ logz, int* __restrict__ bad);
@@ -152,6 +154,7 @@ struct rh_ctx {
     size_t dxl_layout = 0;         // (lda, rows) signature of the zero-padded table image currently in HBM
     int dx_w = 4;                  // wavefronts per 64-cell group of the linear duplex kernel
     int last_dx_path = 0;
+    bool far_mfma = true;          // block products on v_mfma_f64_16x16x4_f64 (BS = 16); RH_FAR_MFMA=0: LDS/FMA kernel
     bool use_graphs = true;        // RH_NO_GRAPH=1 launches every kernel from the host instead
     GraphSlot g_in, g_out, g_dx;
     int mode = RH_MODE_AUTO;       // which McCaskill path rh_batch_compute takes
@@ -374,7 +377,10 @@ int launch_mc_lin(rh_ctx* c, int pin, int phase)
         if (BS > 0 && (d + 1) % BS == 0) {
             const int D = (d + 1) / BS + 1;
             if (D >= 4 && D <= last_block) {
-                hipLaunchKernelGGL(lin_far_inside<(BS > 0 ? BS : 16)>, dim3(last_block - D + 1, B.ns), dim3(256), 0, c->s_mc, B, D);
+                if (BS == 16 && c->far_mfma)
+                    hipLaunchKernelGGL(lin_far_inside_mfma, dim3(last_block - D + 1, B.ns), dim3(256), 0, c->s_mc, B, D);
+                else
+                    hipLaunchKernelGGL(lin_far_inside<(BS > 0 ? BS : 16)>, dim3(last_block - D + 1, B.ns), dim3(256), 0, c->s_mc, B, D);
                 c->n_launch[0]++;
             }
         }
@@ -382,13 +388,20 @@ int launch_mc_lin(rh_ctx* c, int pin, int phase)
     return RH_OK;
     }
     if (BS > 0)  // tiles whose first cell would come before the first outside diagonal: their far sums are empty
-        for (int D = last_block; D >= 0 && (D + 1) * BS - 1 > B.nmax - 2; D--)
-            hipLaunchKernelGGL(lin_far_outside<(BS > 0 ? BS : 16)>, dim3(last_block - D + 1, B.ns, 2), dim3(256), 0, c->s_mc, B, D);
+        for (int D = last_block; D >= 0 && (D + 1) * BS - 1 > B.nmax - 2; D--) {
+            if (BS == 16 && c->far_mfma)
+                hipLaunchKernelGGL(lin_far_outside_mfma, dim3(last_block - D + 1, B.ns, 2), dim3(256), 0, c->s_mc, B, D);
+            else
+                hipLaunchKernelGGL(lin_far_outside<(BS > 0 ? BS : 16)>, dim3(last_block - D + 1, B.ns, 2), dim3(256), 0, c->s_mc, B, D);
+        }
     for (int d = B.nmax - 2; d >= 0; d--) {
         if (BS > 0 && (d + 1) % BS == 0) {
             const int D = (d + 1) / BS - 1;
             if (D >= 0 && D <= last_block) {
-                hipLaunchKernelGGL(lin_far_outside<(BS > 0 ? BS : 16)>, dim3(last_block - D + 1, B.ns, 2), dim3(256), 0, c->s_mc, B, D);
+                if (BS == 16 && c->far_mfma)
+                    hipLaunchKernelGGL(lin_far_outside_mfma, dim3(last_block - D + 1, B.ns, 2), dim3(256), 0, c->s_mc, B, D);
+                else
+                    hipLaunchKernelGGL(lin_far_outside<(BS > 0 ? BS : 16)>, dim3(last_block - D + 1, B.ns, 2), dim3(256), 0, c->s_mc, B, D);
                 c->n_launch[1]++;
             }
         }
@@ -506,7 +519,7 @@ size_t shape_key(const rh_ctx* c, int which)
         const McBatch& B = c->mc;
         for (size_t v : {(size_t)B.ns, (size_t)B.nmax, (size_t)B.ld, (size_t)B.lds, (size_t)B.tab, (size_t)B.seq, (size_t)B.n,
                          (size_t)B.f5i, (size_t)B.bp, (size_t)B.up, (size_t)c->d_bad, (size_t)c->d_mclogz, (size_t)c->lin_w,
-                         (size_t)c->lin_bs, (size_t)B.tri_stride})
+                         (size_t)c->lin_bs, (size_t)B.tri_stride, (size_t)c->far_mfma})
             h = mix(h, v);
     } else {
         const DxLinBatch& X = c->dxl;
@@ -663,6 +676,7 @@ rh_ctx* rh_create(int device, int model, const char* param_file)
     if (const char* e = std::getenv("RH_LIN_W")) c->lin_w = std::atoi(e);
     if (const char* e = std::getenv("RH_LIN_BS")) c->lin_bs = std::atoi(e);
     if (const char* e = std::getenv("RH_NO_GRAPH")) c->use_graphs = std::atoi(e) == 0;
+    if (const char* e = std::getenv("RH_FAR_MFMA")) c->far_mfma = std::atoi(e) != 0;
     if (const char* e = std::getenv("RH_DX_W")) c->dx_w = std::atoi(e);
     bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&c->s_mc, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&c->s_dx, hipStreamNonBlocking) == hipSuccess &&
