@@ -62,6 +62,9 @@ def main():
     ap.add_argument("--seqlen", "--n", dest="n", type=int, default=500,
                     help="sequence length (BASELINE config 3: 500; config 4: 2000); use --seqlen under torch.distributed.run")
     ap.add_argument("--batch", type=int, default=0, help="pairs per GPU per step (0 = auto)")
+    ap.add_argument("--workload", default="pairs", choices=["pairs", "zscore"],
+                    help="pairs: synthetic random pairs of --seqlen (the headline metric); zscore: the DP stage of BASELINE "
+                         "config 5 -- OxyS vs fhlA, --zscore=12 --seed=1, --batch dinucleotide shuffles per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only for "
                     "rehearsing the multi-rank path on a one-GPU box, where all ranks share cuda:0)")
@@ -91,9 +94,18 @@ def main():
             dist.init_process_group(args.backend)
 
     n = args.n
-    batch = args.batch or (64 if n <= 600 else (16 if n <= 1200 else 4))
-    # every rank draws from ONE stream and keeps its own slice: distinct pairs per rank (weak scaling)
-    all_pairs = random_pairs(batch * world, n, seed=12345)
+    if args.workload == "zscore":
+        # bundled sequences of the reference (data/OxyS.fa, data/fhlA.fa), shuffled exactly as ractip.cpp:1636-1643 does
+        from ractip_amd import shard as _shard
+        fa = [l.strip() for l in open(os.path.join(ROOT, "ractip_amd", "data", "config5_OxyS_fhlA.fa")) if not l.startswith(">")]
+        oxys, fhla = fa[0], fa[1]
+        batch = args.batch or 1000
+        n = max(len(oxys), len(fhla))
+        all_pairs = _shard.zscore_shuffles(oxys, fhla, 12, batch * world, 1)
+    else:
+        batch = args.batch or (64 if n <= 600 else (16 if n <= 1200 else 4))
+        # every rank draws from ONE stream and keeps its own slice: distinct pairs per rank (weak scaling)
+        all_pairs = random_pairs(batch * world, n, seed=12345)
     pairs = all_pairs[rank * batch:(rank + 1) * batch]
 
     ctx = ractip_amd.Context(device=device_index)
@@ -156,7 +168,8 @@ def main():
             pass
         ach = phases[dom]["achieved_GBs"]
         line = {
-            "metric": "sequence-pairs/sec (incl. bp+hp+ap DP) at n=%d" % n,
+            "metric": ("sequence-pairs/sec (incl. bp+hp+ap DP) at n=%d" % n) if args.workload == "pairs"
+                      else "z-score DP stage: shuffled pairs/sec (OxyS/fhlA, bp+hp+ap DP per shuffle)",
             "value": total_pairs / dt,
             "unit": "pairs/s",
             "n_gpus": world,
@@ -168,8 +181,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "synthetic random pairs n=%d/%d, std::mt19937(12345) stream (BASELINE config %s)"
-                                   % (n, n, "3" if n == 500 else ("4" if n == 2000 else "-")),
+            "config": {"workload": ("synthetic random pairs n=%d/%d, std::mt19937(12345) stream (BASELINE config %s)"
+                                    % (n, n, "3" if n == 500 else ("4" if n == 2000 else "-"))) if args.workload == "pairs"
+                                   else "OxyS.fa (109) vs fhlA.fa (113), --zscore=12 --seed=1 dinucleotide shuffles (BASELINE config 5, DP stage)",
                        "pairs_per_gpu_per_step": batch, "model": None, "scoring": "CONTRAfold complementary (708 weights)"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS if ach else None, "traffic": traffic,
