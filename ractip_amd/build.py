@@ -32,13 +32,29 @@ def _stale(target, deps):
 
 
 def build_hot(force=False, verbose=True):
+    """Compile every source to an object in parallel (the kernel files are template-heavy), then link."""
+    from concurrent.futures import ThreadPoolExecutor
     srcs = [os.path.join(CSRC, s) for s in HOT_SOURCES]
-    deps = srcs + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
-    deps.append(os.path.join(ROOT, "include", "ractip_hot.h"))
-    if not force and not _stale(HOT_LIB, deps):
+    hdrs = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
+    hdrs.append(os.path.join(ROOT, "include", "ractip_hot.h"))
+    if not force and not _stale(HOT_LIB, srcs + hdrs):
         return HOT_LIB
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-           "-Wno-unused-function", "-o", HOT_LIB] + srcs + ["-ldl"]
+    objdir = os.path.join(PKG, "build")
+    os.makedirs(objdir, exist_ok=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+    def compile_one(src):
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        if force or _stale(obj, [src] + hdrs):
+            cmd = [_hipcc()] + flags + ["-c", src, "-o", obj]
+            if verbose:
+                print("[ractip_amd.build]", " ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(6, len(srcs))) as pool:
+        objs = list(pool.map(compile_one, srcs))
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HOT_LIB] + objs + ["-ldl"]
     if verbose:
         print("[ractip_amd.build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)

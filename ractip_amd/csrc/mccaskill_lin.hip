@@ -487,9 +487,9 @@ __global__ void lin_finish(McBatch B, const LinModel* __restrict__ L, double* __
 #define RH_INST(W, BS)                                                                             \
     template __global__ void lin_inside_diag<W, BS>(McBatch, const LinModel*, int, double, int);  \
     template __global__ void lin_outside_diag<W, BS>(McBatch, const LinModel*, int, int, int*);
-RH_INST(4, 0) RH_INST(8, 0) RH_INST(16, 0)
-RH_INST(4, 16) RH_INST(8, 16) RH_INST(16, 16)
-RH_INST(4, 32) RH_INST(8, 32) RH_INST(16, 32)
+RH_INST(8, 0) RH_INST(16, 0)
+RH_INST(8, 16) RH_INST(16, 16)
+RH_INST(8, 32) RH_INST(16, 32)
 #undef RH_INST
 
 }  // namespace rh

@@ -419,7 +419,6 @@ template <int BS>
 int launch_mc_lin_w(rh_ctx* c, int pin, int phase)
 {
     switch (c->lin_w) {
-        case 4: return launch_mc_lin<4, BS>(c, pin, phase);
         case 16: return launch_mc_lin<16, BS>(c, pin, phase);
         default: return launch_mc_lin<8, BS>(c, pin, phase);
     }
