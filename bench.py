@@ -194,6 +194,19 @@ def main():
                                         "frac": b["total"] / 1e9 / (ms_mean[3] / 1e3) / HBM_PEAK_GBS},
                          "phases": phases},
         }
+        if world == 1:
+            # PCIe-inclusive rates (never `value`): host strings in -> results on the host, for the record in DESIGN.md
+            t1 = time.perf_counter()
+            for _ in range(2):
+                ctx.batch_upload(pairs); ctx.batch_compute(); ctx.batch_results_all()
+            dense = 2 * batch / (time.perf_counter() - t1)
+            t1 = time.perf_counter()
+            for _ in range(2):
+                ctx.batch_upload(pairs); ctx.batch_compute()
+                for which, th in ((0, 0.5), (1, 0.5), (2, 0.1), (3, 0.003), (4, 0.003)):   # cmdline.c default thresholds
+                    ctx.batch_candidates_all(which, th)
+            sparse = 2 * batch / (time.perf_counter() - t1)
+            line["pcie_inclusive"] = {"dense_results_pairs_per_s": dense, "threshold_candidates_pairs_per_s": sparse}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(all_pairs, budget_s=12.0 if n <= 600 else 1.0)
         else:

@@ -112,6 +112,18 @@ typedef struct rh_cand {
  * entries in row-major scan order and returns the total number found (>= 0) or an error. */
 int rh_batch_candidates(rh_ctx* ctx, int p, int which, float threshold, rh_cand* out, int cap);
 
+/* The same scan for EVERY pair of the batch in two kernels and three copies (the z-score loop needs 5 scans
+ * for each of 1000 pairs): out holds the concatenated lists, pair p owns out[first[p] .. first[p+1]) (first has
+ * npairs+1 entries).  Returns the total number found (>= 0; only min(total, cap) entries are written) or an error. */
+int rh_batch_candidates_all(rh_ctx* ctx, int which, float threshold, rh_cand* out, int cap, int* first);
+
+/* Dense results of the whole batch in three copies, in the padded device layout described by rh_batch_layout:
+ *   bp [2*npairs][tri_stride]  (sequence 2p = s1 of pair p; each table in the reference's triangular layout for ITS n)
+ *   up [2*npairs][up_ld]       hp [npairs][hp_stride] with row pitch hp_ld       logz [3*npairs]
+ * Any pointer may be NULL. */
+int rh_batch_layout(rh_ctx* ctx, size_t* tri_stride, int* up_ld, size_t* hp_stride, int* hp_ld);
+int rh_batch_results_all(rh_ctx* ctx, double* bp, double* up, double* hp, double* logz);
+
 /* Device time (ms, HIP events on the context's streams) spent by the last
  * rh_batch_compute in: [0] McCaskill inside sweep, [1] McCaskill outside sweep
  * (+posterior), [2] duplex sweeps, [3] whole compute.  Launch counts in n_launch[0..2]. */

@@ -131,6 +131,66 @@ __global__ __launch_bounds__(256) void cand_write(const double* __restrict__ bas
     }
 }
 
+// ---- the same compaction for every pair of the batch at once: row index = p*rmax + r
+struct CandAll {
+    const double* bp; const double* hp; const double* up;
+    const int* n;            // [2*np]
+    size_t tri_stride, hp_stride;
+    int up_ld, hp_ld, which, rmax, np;
+};
+__device__ __forceinline__ RowSpan cand_row_all(const double* bp, const double* hp, const double* up, const int* __restrict__ nn,
+                                                size_t tri_stride, size_t hp_stride, int up_ld, int hp_ld, int which, int p, int r)
+{
+    if (which <= 1) {
+        const int sq = 2 * p + which;
+        return cand_row(bp + (size_t)sq * tri_stride, 0, nn[sq], 0, 0, r);
+    }
+    if (which == 2) return cand_row(hp + (size_t)p * hp_stride, 1, nn[2 * p], nn[2 * p + 1], hp_ld, r);
+    const int sq = 2 * p + (which - 3);
+    return cand_row(up + (size_t)sq * up_ld, 2, nn[sq], 0, 0, r);
+}
+__global__ __launch_bounds__(256) void cand_count_all(const double* __restrict__ bp, const double* __restrict__ hp, const double* __restrict__ up,
+                                                      const int* __restrict__ nn, size_t tri_stride, size_t hp_stride, int up_ld, int hp_ld,
+                                                      int which, int rmax, float th, int* __restrict__ counts)
+{
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, p = blockIdx.y;
+    if (r >= rmax) return;
+    const RowSpan rs = cand_row_all(bp, hp, up, nn, tri_stride, hp_stride, up_ld, hp_ld, which, p, r);
+    int c = 0;
+    if (rs.ok)
+        for (int j = rs.j0 + lane; j <= rs.j1; j += 64) c += ((float)rs.p[j] > th) ? 1 : 0;
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if (lane == 0) counts[(size_t)p * rmax + r] = c;
+}
+__global__ __launch_bounds__(256) void cand_write_all(const double* __restrict__ bp, const double* __restrict__ hp, const double* __restrict__ up,
+                                                      const int* __restrict__ nn, size_t tri_stride, size_t hp_stride, int up_ld, int hp_ld,
+                                                      int which, int rmax, float th, const int* __restrict__ offsets,
+                                                      rh_cand* __restrict__ out, int cap)
+{
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, p = blockIdx.y;
+    if (r >= rmax) return;
+    const RowSpan rs = cand_row_all(bp, hp, up, nn, tri_stride, hp_stride, up_ld, hp_ld, which, p, r);
+    if (!rs.ok) return;
+    int pos = offsets[(size_t)p * rmax + r];
+    for (int jb = rs.j0; jb <= rs.j1; jb += 64) {
+        const int j = jb + lane;
+        const float pf = j <= rs.j1 ? (float)rs.p[j] : 0.0f;
+        const bool hit = j <= rs.j1 && pf > th;
+        const unsigned long long m = __ballot(hit);
+        if (hit) {
+            const int k = pos + __popcll(m & ((1ull << lane) - 1ull));
+            if (k < cap) {
+                rh_cand e;
+                e.i = which >= 3 ? j : rs.i;
+                e.j = which >= 3 ? 0 : j;
+                e.p = pf;
+                out[k] = e;
+            }
+        }
+        pos += __popcll(m);
+    }
+}
+
 static thread_local std::string g_create_error;
 
 struct GraphSlot {   // one captured launch sequence (see run_graphed)
@@ -851,6 +911,68 @@ int rh_batch_candidates(rh_ctx* c, int p, int which, float threshold, rh_cand* o
         HIP_TRY(c, hipStreamSynchronize(c->s_mc));
     }
     return found;
+}
+
+int rh_batch_candidates_all(rh_ctx* c, int which, float threshold, rh_cand* out, int cap, int* first)
+{
+    if (!c) return RH_ERR_ARG;
+    if (!c->computed || !c->has_mc || !c->has_dx) return fail(c, RH_ERR_ARG, "no computed pair batch");
+    if (which < 0 || which > 4 || cap < 0 || (cap > 0 && !out) || !first) return fail(c, RH_ERR_ARG, "bad which/cap/first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int np = c->np;
+    const int rmax = which >= 3 ? 1 : (which == 2 ? c->dx.n1max : c->mc.nmax);
+    const size_t nrows = (size_t)np * rmax;
+    int rc;
+    if ((rc = ensure(c, &c->d_cnt, &c->cap_cnt, sizeof(int) * 2 * (nrows + 1), false))) return rc;
+    int* d_counts = (int*)c->d_cnt;
+    int* d_offsets = d_counts + (nrows + 1);
+    const dim3 grid((rmax + 3) / 4, np);
+    hipLaunchKernelGGL(cand_count_all, grid, dim3(256), 0, c->s_mc, (const double*)c->d_bp, (const double*)c->d_hp, (const double*)c->d_up,
+                       (const int*)c->d_n, c->mc.tri_stride, c->dx.tab_stride, c->mc.ld, c->dx.ldd, which, rmax, threshold, d_counts);
+    std::vector<int> counts(nrows), offsets(nrows);
+    HIP_TRY(c, hipMemcpyAsync(counts.data(), d_counts, sizeof(int) * nrows, hipMemcpyDeviceToHost, c->s_mc));
+    HIP_TRY(c, hipStreamSynchronize(c->s_mc));
+    int found = 0;
+    for (int p = 0; p < np; p++) {
+        first[p] = found;
+        for (int r = 0; r < rmax; r++) { offsets[(size_t)p * rmax + r] = found; found += counts[(size_t)p * rmax + r]; }
+    }
+    first[np] = found;
+    const int take = std::min(found, cap);
+    if (take > 0) {
+        if ((rc = ensure(c, &c->d_cand, &c->cap_cand, sizeof(rh_cand) * (size_t)take, false))) return rc;
+        HIP_TRY(c, hipMemcpyAsync(d_offsets, offsets.data(), sizeof(int) * nrows, hipMemcpyHostToDevice, c->s_mc));
+        hipLaunchKernelGGL(cand_write_all, grid, dim3(256), 0, c->s_mc, (const double*)c->d_bp, (const double*)c->d_hp, (const double*)c->d_up,
+                           (const int*)c->d_n, c->mc.tri_stride, c->dx.tab_stride, c->mc.ld, c->dx.ldd, which, rmax, threshold, d_offsets,
+                           (rh_cand*)c->d_cand, take);
+        HIP_TRY(c, hipMemcpyAsync(out, c->d_cand, sizeof(rh_cand) * (size_t)take, hipMemcpyDeviceToHost, c->s_mc));
+        HIP_TRY(c, hipStreamSynchronize(c->s_mc));
+    }
+    return found;
+}
+
+int rh_batch_layout(rh_ctx* c, size_t* tri_stride, int* up_ld, size_t* hp_stride, int* hp_ld)
+{
+    if (!c) return RH_ERR_ARG;
+    if (!c->has_mc || !c->has_dx) return fail(c, RH_ERR_ARG, "no pair batch");
+    if (tri_stride) *tri_stride = c->mc.tri_stride;
+    if (up_ld) *up_ld = c->mc.ld;
+    if (hp_stride) *hp_stride = c->dx.tab_stride;
+    if (hp_ld) *hp_ld = c->dx.ldd;
+    return RH_OK;
+}
+
+int rh_batch_results_all(rh_ctx* c, double* bp, double* up, double* hp, double* logz)
+{
+    if (!c) return RH_ERR_ARG;
+    if (!c->computed || !c->has_mc || !c->has_dx) return fail(c, RH_ERR_ARG, "no computed pair batch");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (bp) HIP_TRY(c, hipMemcpyAsync(bp, c->d_bp, sizeof(double) * c->mc.tri_stride * c->ns, hipMemcpyDeviceToHost, c->s_mc));
+    if (up) HIP_TRY(c, hipMemcpyAsync(up, c->d_up, sizeof(double) * c->mc.ld * c->ns, hipMemcpyDeviceToHost, c->s_mc));
+    if (hp) HIP_TRY(c, hipMemcpyAsync(hp, c->d_hp, sizeof(double) * c->dx.tab_stride * c->np, hipMemcpyDeviceToHost, c->s_mc));
+    HIP_TRY(c, hipStreamSynchronize(c->s_mc));
+    if (logz) return rh_batch_logz(c, logz);
+    return RH_OK;
 }
 
 int rh_set_mode(rh_ctx* c, int mode)

@@ -90,21 +90,30 @@ std::vector<PairProbabilities> ProbabilityEngine::solve_probabilities(
     }
     if (rh_batch_upload(ctx_, np, a.data(), na.data(), b.data(), nb.data()) != RH_OK) raise("solve_probabilities");
     if (rh_batch_compute(ctx_) != RH_OK) raise("solve_probabilities");
+    // three device-to-host copies for the whole batch, then unpack the padded layout on the host
+    size_t tri_stride = 0, hp_stride = 0;
+    int up_ld = 0, hp_ld = 0;
+    if (rh_batch_layout(ctx_, &tri_stride, &up_ld, &hp_stride, &hp_ld) != RH_OK) raise("solve_probabilities");
+    std::vector<double> bp((size_t)2 * np * tri_stride), up((size_t)2 * np * up_ld), hp((size_t)np * hp_stride), z((size_t)3 * np);
+    if (rh_batch_results_all(ctx_, bp.data(), up.data(), hp.data(), z.data()) != RH_OK) raise("solve_probabilities");
     for (int p = 0; p < np; ++p) {
         const uint n1 = na[p], n2 = nb[p];
-        std::vector<double> bp1((size_t)(n1 + 1) * (n1 + 2) / 2), bp2((size_t)(n2 + 1) * (n2 + 2) / 2), up1(n1), up2(n2),
-            hp((size_t)(n1 + 1) * (n2 + 1));
-        double z[3];
-        if (rh_batch_results(ctx_, p, bp1.data(), bp2.data(), up1.data(), up2.data(), hp.data(), z) != RH_OK)
-            raise("solve_probabilities");
         PairProbabilities& r = out[p];
-        narrow_bp(bp1, r.bp1); narrow_bp(bp2, r.bp2);
-        narrow_up(up1, r.up1); narrow_up(up2, r.up2);
+        const double* b1 = bp.data() + (size_t)(2 * p) * tri_stride;
+        const double* b2 = bp.data() + (size_t)(2 * p + 1) * tri_stride;
+        r.bp1.resize((size_t)(n1 + 1) * (n1 + 2) / 2);
+        r.bp2.resize((size_t)(n2 + 1) * (n2 + 2) / 2);
+        std::transform(b1, b1 + r.bp1.size(), r.bp1.begin(), [](double v) { return (float)v; });
+        std::transform(b2, b2 + r.bp2.size(), r.bp2.begin(), [](double v) { return (float)v; });
+        r.up1.assign(n1, VF(1)); r.up2.assign(n2, VF(1));
+        for (uint i = 0; i < n1; ++i) r.up1[i][0] = (float)up[(size_t)(2 * p) * up_ld + i];
+        for (uint i = 0; i < n2; ++i) r.up2[i][0] = (float)up[(size_t)(2 * p + 1) * up_ld + i];
         r.offset1 = make_offsets(n1); r.offset2 = make_offsets(n2);
         r.hp.assign(n1 + 1, VF(n2 + 1));
+        const double* h = hp.data() + (size_t)p * hp_stride;
         for (uint i = 0; i <= n1; ++i)
-            for (uint j = 0; j <= n2; ++j) r.hp[i][j] = (float)hp[(size_t)i * (n2 + 1) + j];
-        r.logZ1 = z[0]; r.logZ2 = z[1]; r.logZd = z[2];
+            for (uint j = 0; j <= n2; ++j) r.hp[i][j] = (float)h[(size_t)i * hp_ld + j];
+        r.logZ1 = z[3 * p]; r.logZ2 = z[3 * p + 1]; r.logZd = z[3 * p + 2];
     }
     return out;
 }

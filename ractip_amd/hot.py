@@ -17,7 +17,8 @@ RH_MODEL_VIENNA_BL = 1
 EXPORTS = [
     "rh_create", "rh_destroy", "rh_last_error", "rh_set_mode", "rh_last_path", "rh_bpp", "rh_unpaired", "rh_fold", "rh_duplex",
     "rh_batch_upload", "rh_batch_compute", "rh_batch_results", "rh_batch_candidates",
-    "rh_batch_timings", "rh_batch_device_views", "rh_batch_logz",
+    "rh_batch_timings", "rh_batch_device_views", "rh_batch_logz", "rh_batch_candidates_all", "rh_batch_layout",
+    "rh_batch_results_all",
 ]
 
 
@@ -60,11 +61,15 @@ def load_library():
     L.rh_batch_compute.argtypes = [vp]
     L.rh_batch_results.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp]
     L.rh_batch_candidates.argtypes = [vp, ci, ci, ctypes.c_float, vp, ci]
+    L.rh_batch_candidates_all.argtypes = [vp, ci, ctypes.c_float, vp, ci, vp]
+    L.rh_batch_layout.argtypes = [vp, vp, vp, vp, vp]
+    L.rh_batch_results_all.argtypes = [vp, vp, vp, vp, vp]
     L.rh_batch_timings.argtypes = [vp, vp, vp]
     L.rh_batch_logz.argtypes = [vp, vp]
     L.rh_batch_device_views.argtypes = [vp, vp, vp, vp, vp, vp]
     for f in ("rh_bpp", "rh_unpaired", "rh_fold", "rh_duplex", "rh_batch_upload", "rh_batch_compute", "rh_batch_results",
-              "rh_batch_candidates", "rh_batch_timings", "rh_batch_device_views", "rh_batch_logz"):
+              "rh_batch_candidates", "rh_batch_timings", "rh_batch_device_views", "rh_batch_logz", "rh_batch_candidates_all",
+              "rh_batch_layout", "rh_batch_results_all"):
         getattr(L, f).restype = ci
     _lib = L
     return L
@@ -170,6 +175,35 @@ class Context:
         k = self._check(self.L.rh_batch_candidates(self.h, p, which, ctypes.c_float(threshold), buf, cap))
         self.last_candidate_count = k
         return [(buf[t].i, buf[t].j, buf[t].p) for t in range(min(k, cap))]
+
+    CAND_DTYPE = np.dtype([("i", np.int32), ("j", np.int32), ("p", np.float32)])
+
+    def batch_candidates_all(self, which, threshold, cap=1 << 22):
+        """Candidates of every pair: (records, first) -- a structured array (i, j, p) and the np+1 offsets
+        such that pair k owns records[first[k]:first[k+1]].  No per-entry Python work."""
+        if getattr(self, "_cand_buf", None) is None or self._cand_buf.size < cap:
+            self._cand_buf = np.empty(cap, dtype=self.CAND_DTYPE)
+        first = np.empty(len(self._pairs) + 1, dtype=np.int32)
+        k = self._check(self.L.rh_batch_candidates_all(self.h, which, ctypes.c_float(threshold), self._cand_buf.ctypes.data,
+                                                       cap, first.ctypes.data))
+        if k > cap:
+            raise RhError("candidate buffer too small: %d > %d" % (k, cap))
+        return self._cand_buf[:k], first
+
+    def batch_results_all(self):
+        """Dense results of all pairs (three device-to-host copies), unpacked into per-pair dicts."""
+        ts, hs = ctypes.c_size_t(), ctypes.c_size_t()
+        uld, hld = ctypes.c_int(), ctypes.c_int()
+        self._check(self.L.rh_batch_layout(self.h, ctypes.byref(ts), ctypes.byref(uld), ctypes.byref(hs), ctypes.byref(hld)))
+        np_ = len(self._pairs)
+        bp = np.empty((2 * np_, ts.value)); up = np.empty((2 * np_, uld.value)); hp = np.empty((np_, hs.value)); z = np.empty((np_, 3))
+        self._check(self.L.rh_batch_results_all(self.h, bp.ctypes.data, up.ctypes.data, hp.ctypes.data, z.ctypes.data))
+        out = []
+        for p, (n1, n2) in enumerate(self._pairs):
+            h = hp[p][:(n1 + 1) * hld.value].reshape(n1 + 1, hld.value)[:, :n2 + 1]
+            out.append(dict(bp1=bp[2 * p][:tri_size(n1)], bp2=bp[2 * p + 1][:tri_size(n2)], up1=up[2 * p][:n1], up2=up[2 * p + 1][:n2],
+                            hp=h, logZ=z[p]))
+        return out
 
     def batch_timings(self):
         ms = (ctypes.c_double * 4)()

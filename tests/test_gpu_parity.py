@@ -201,6 +201,54 @@ def test_threshold_candidates_match_reference_scans(ctx, oracle, golden):
     assert len(ctx.batch_candidates(0, 2, float(th_hy), cap=5)) == 5      # cap truncates the copy, not the count
 
 
+def test_bulk_results_and_batched_candidates_equal_per_pair_calls(ctx):
+    rng = np.random.RandomState(31)
+    pairs = [(rnd(rng, a), rnd(rng, b)) for a, b in ((40, 70), (111, 90), (64, 64), (5, 130))]
+    ctx.batch_upload(pairs)
+    ctx.batch_compute()
+    bulk = ctx.batch_results_all()
+    for p in range(len(pairs)):
+        one = ctx.batch_results(p)
+        for k in ("bp1", "bp2", "up1", "up2", "hp", "logZ"):
+            assert np.array_equal(np.asarray(bulk[p][k]), np.asarray(one[k])), (p, k)
+    for which, th in ((0, 0.5), (1, 0.5), (2, 0.1), (3, 0.003), (4, 0.003)):
+        rec, first = ctx.batch_candidates_all(which, th)
+        assert first[0] == 0 and first[-1] == len(rec)
+        for p in range(len(pairs)):
+            mine = [tuple(r) for r in rec[first[p]:first[p + 1]].tolist()]
+            assert mine == ctx.batch_candidates(p, which, th), (which, p)
+
+
+def test_custom_parameter_file(hotlib, oracle, tmp_path):
+    """rh_create(param_file): a perturbed weight file must change the results exactly as it changes the oracle's."""
+    import ctypes
+    import ractip_amd
+    from _oracle import PARAMS
+    rng = np.random.RandomState(8)
+    lines = [l.split() for l in open(PARAMS)]
+    path = tmp_path / "perturbed.params"
+    rng.shuffle(lines)                                   # binding is by name: order must not matter
+    path.write_text("".join("%s %r\n" % (k, float(v) + 0.05 * rng.randn()) for k, v in lines))
+    m = oracle.L.cfo_load_params(str(path).encode())
+    assert m
+    seq, s2 = rnd(rng, 90), rnd(rng, 60)
+    n = len(seq)
+    post = np.zeros(tri_size(n))
+    z = oracle.L.cfo_inference(ctypes.c_void_p(m), seq.encode(), n, post.ctypes.data, None, None)
+    c = ractip_amd.Context(device=0, param_file=str(path))
+    bp, zg = c.bpp(seq)
+    assert abs(zg - z) < 1e-9
+    assert_prob_close(bp, post, rel=REL, what="perturbed weights")
+    S = (n + 1) * (len(s2) + 1)
+    hp_ref, z2 = np.zeros(S), np.zeros(2)
+    oracle.L.cfo_duplex(ctypes.c_void_p(m), seq.encode(), n, s2.encode(), len(s2), hp_ref.ctypes.data, None, None, z2.ctypes.data)
+    hp, zd = c.duplex(seq, s2)
+    assert abs(zd - z2[0]) < 1e-9
+    assert_prob_close(hp, hp_ref, rel=REL, what="perturbed duplex")
+    c.close()
+    assert abs(z - oracle.inference(seq)["logZ"]) > 1e-3   # the perturbation really changed the model
+
+
 def test_errors_are_reported_not_swallowed(ctx):
     import ractip_amd
     with pytest.raises(ractip_amd.RhError):
