@@ -29,7 +29,8 @@ typedef struct rh_ctx rh_ctx;
 
 /* scoring model selector */
 #define RH_MODEL_CONTRAFOLD 0 /* --contrafold path: src/ractip.cpp:195-246 */
-#define RH_MODEL_VIENNA_BL 1  /* default / --duplex path; parity unpinned; not built yet */
+#define RH_MODEL_VIENNA_BL 1  /* --duplex path: pf_duplex with BL* energies, ViennaRNA-1.8 semantics; rh_duplex only;
+                                 PARITY UNPINNED (ViennaRNA is absent and unversioned) */
 
 #define RH_OK 0
 #define RH_ERR_ARG (-1)
@@ -40,7 +41,9 @@ typedef struct rh_ctx rh_ctx;
 
 /* Create a context bound to HIP device `device`.  `param_file` = NULL loads the
  * bundled default weights (ractip_amd/data/contrafold_complementary.params, the
- * values of GetDefaultComplementaryValues, src/contrafold/Defaults.ipp:7-723).
+ * values of GetDefaultComplementaryValues, src/contrafold/Defaults.ipp:7-723; for
+ * RH_MODEL_VIENNA_BL ractip_amd/data/vienna_bl_star.params, the BL* tables of
+ * src/boltzmann_param.c).
  * Replaces the per-call engine construction of src/ractip.cpp:199-206, 229-234.
  * Returns NULL on failure; rh_last_error(NULL) then describes why. */
 rh_ctx* rh_create(int device, int model, const char* param_file);

@@ -21,6 +21,7 @@
 #include "batch.h"
 #include "score_model.h"
 #include "lin_model.h"
+#include "vienna_model.h"
 
 namespace rh {
 __global__ void mc_init(McBatch B);
@@ -41,6 +42,9 @@ __global__ void lin_finish(McBatch B, const LinModel* __restrict__ L, double* __
 template <int W> __global__ void dxl_sweep(DxLinBatch B, const DxLinModel* __restrict__ L, int step, int groups);
 __global__ void dxl_logz(DxLinBatch B, const DxLinModel* __restrict__ L, double* __restrict__ zbar, double* __restrict__ logz, int* __restrict__ bad);
 __global__ void dxl_posterior(DxLinBatch B, const double* __restrict__ zbar, int* __restrict__ bad);
+__global__ void dxv_sweep_diag(DxBatch B, const ViennaDx* __restrict__ V, int t);
+__global__ void dxv_logz(DxBatch B, const ViennaDx* __restrict__ V);
+__global__ void dxv_posterior(DxBatch B);
 }  // namespace rh
 
 using namespace rh;
@@ -208,6 +212,7 @@ struct rh_ctx {
     ScoreModel* d_model = nullptr;
     LinModel* d_lin = nullptr;
     LinModel h_lin;
+    ViennaDx* d_vienna = nullptr;  // RH_MODEL_VIENNA_BL only
     DxLinModel* d_dxlin = nullptr;
     DxLinModel h_dxlin;
     DxLinBatch dxl = {};
@@ -295,6 +300,17 @@ uint8_t nuc_code(char ch)
     }
 }
 
+uint8_t vienna_code(char ch)
+{  // ViennaRNA encode_char with energy_set 0: A,C,G,U -> 1..4 (T reads as U), anything else 0
+    switch (ch) {
+        case 'A': case 'a': return 1;
+        case 'C': case 'c': return 2;
+        case 'G': case 'g': return 3;
+        case 'U': case 'u': case 'T': case 't': return 4;
+        default: return 0;
+    }
+}
+
 std::string default_param_path()
 {
     Dl_info info;
@@ -302,9 +318,9 @@ std::string default_param_path()
         std::string p(info.dli_fname);
         size_t k = p.find_last_of('/');
         p = (k == std::string::npos) ? std::string(".") : p.substr(0, k);
-        return p + "/data/contrafold_complementary.params";
+        return p + "/data/";
     }
-    return "ractip_amd/data/contrafold_complementary.params";
+    return "ractip_amd/data/";
 }
 
 inline size_t tri_size(int n) { return (size_t)(n + 1) * (n + 2) / 2; }
@@ -328,9 +344,10 @@ int stage(rh_ctx* c, int ns, const char* const* seqs, const int* lens, bool with
     c->n.assign(lens, lens + ns);
 
     const int lds = (nmax + 3 + 15) & ~15;  // codes 0..n+2 readable
-    std::vector<uint8_t> codes((size_t)ns * lds, 4);
+    const bool vienna = c->model == RH_MODEL_VIENNA_BL;
+    std::vector<uint8_t> codes((size_t)ns * lds, vienna ? 0 : 4);   // sentinel = the model's "no nucleotide" code
     for (int k = 0; k < ns; k++)
-        for (int i = 0; i < lens[k]; i++) codes[(size_t)k * lds + 1 + i] = nuc_code(seqs[k][i]);
+        for (int i = 0; i < lens[k]; i++) codes[(size_t)k * lds + 1 + i] = vienna ? vienna_code(seqs[k][i]) : nuc_code(seqs[k][i]);
     int rc;
     if ((rc = ensure(c, &c->d_seq, &c->cap_seq, codes.size(), false))) return rc;
     if ((rc = ensure(c, &c->d_n, &c->cap_n, sizeof(int) * ns, false))) return rc;
@@ -364,7 +381,7 @@ int stage(rh_ctx* c, int ns, const char* const* seqs, const int* lens, bool with
         D.np = ns / 2; D.n1max = n1max; D.n2max = n2max; D.lds = lds;
         D.ldd = (n2max + 2 + 1) & ~1;
         D.tab_stride = (size_t)(n1max + 2) * D.ldd;
-        D.pair_stride = D.tab_stride * D_COUNT;
+        D.pair_stride = D.tab_stride * 6;   // 4 tables (CONTRAfold model) or 6 (Vienna model: IN/OUT + two decorated copies each)
         // the linear path keeps anti-diagonal-major tables in the same buffer (sequential use)
         DxLinBatch& X = c->dxl;
         X.np = D.np; X.n1max = n1max; X.n2max = n2max; X.lds = lds; X.ldd = D.ldd;
@@ -603,7 +620,18 @@ int compute(rh_ctx* c)
     const bool skip_dx = skip && !std::strcmp(skip, "dx"), skip_mc = skip && !std::strcmp(skip, "mc");
     HIP_TRY(c, hipEventRecord(c->ev[3], c->s_dx));
     bool dx_lin_launched = false;
-    if (c->has_dx && !skip_dx) {
+    if (c->has_dx && !skip_dx && c->model == RH_MODEL_VIENNA_BL) {
+        const DxBatch& D = c->dx;
+        const int steps = (D.n1max + D.n2max) / 2;
+        const int waves = 2 * std::min(D.n1max, D.n2max);
+        for (int t = 0; t < steps; t++) {
+            hipLaunchKernelGGL(dxv_sweep_diag, dim3((waves + 3) / 4, D.np, 2), dim3(256), 0, c->s_dx, D, c->d_vienna, t);
+            c->n_launch[2]++;
+        }
+        hipLaunchKernelGGL(dxv_logz, dim3(D.np), dim3(1024), 0, c->s_dx, D, c->d_vienna);
+        hipLaunchKernelGGL(dxv_posterior, dim3((D.n1max * D.n2max + 255) / 256, D.np), dim3(256), 0, c->s_dx, D);
+        c->last_dx_path = 2;
+    } else if (c->has_dx && !skip_dx) {
         if (c->mode != RH_MODE_LOG) {
             if ((rc = run_graphed(c, c->g_dx, shape_key(c, 2), c->s_dx, &c->n_launch[2], [&] { return launch_dx_lin_any(c); }))) return rc;
             dx_lin_launched = true;
@@ -703,8 +731,8 @@ extern "C" {
 
 rh_ctx* rh_create(int device, int model, const char* param_file)
 {
-    if (model != RH_MODEL_CONTRAFOLD) {
-        fail(nullptr, RH_ERR_UNSUPPORTED, "model %d is not built yet (only RH_MODEL_CONTRAFOLD)", model);
+    if (model != RH_MODEL_CONTRAFOLD && model != RH_MODEL_VIENNA_BL) {
+        fail(nullptr, RH_ERR_UNSUPPORTED, "unknown model %d", model);
         return nullptr;
     }
     int ndev = 0;
@@ -719,11 +747,23 @@ rh_ctx* rh_create(int device, int model, const char* param_file)
         return nullptr;
     }
     ScoreModel host_model;
+    ViennaDx* host_vienna = nullptr;
     char err[256];
-    const std::string path = param_file ? std::string(param_file) : default_param_path();
-    if (!load_score_model(path.c_str(), &host_model, err, sizeof err)) {
-        fail(nullptr, RH_ERR_PARAM, "%s", err);
-        return nullptr;
+    if (model == RH_MODEL_CONTRAFOLD) {
+        const std::string path = param_file ? std::string(param_file) : default_param_path() + "contrafold_complementary.params";
+        if (!load_score_model(path.c_str(), &host_model, err, sizeof err)) {
+            fail(nullptr, RH_ERR_PARAM, "%s", err);
+            return nullptr;
+        }
+    } else {
+        const std::string path = param_file ? std::string(param_file) : default_param_path() + "vienna_bl_star.params";
+        host_vienna = new ViennaDx;
+        if (!load_vienna_dx(path.c_str(), host_vienna, err, sizeof err)) {
+            delete host_vienna;
+            fail(nullptr, RH_ERR_PARAM, "%s", err);
+            return nullptr;
+        }
+        std::memset(&host_model, 0, sizeof host_model);
     }
     rh_ctx* c = new rh_ctx;
     c->device = device; c->model = model;
@@ -745,6 +785,10 @@ rh_ctx* rh_create(int device, int model, const char* param_file)
               hipMemcpy(c->d_lin, &c->h_lin, sizeof(LinModel), hipMemcpyHostToDevice) == hipSuccess &&
               hipMalloc((void**)&c->d_dxlin, sizeof(DxLinModel)) == hipSuccess &&
               hipMemcpy(c->d_dxlin, &c->h_dxlin, sizeof(DxLinModel), hipMemcpyHostToDevice) == hipSuccess;
+    if (ok && host_vienna)
+        ok = hipMalloc((void**)&c->d_vienna, sizeof(ViennaDx)) == hipSuccess &&
+             hipMemcpy(c->d_vienna, host_vienna, sizeof(ViennaDx), hipMemcpyHostToDevice) == hipSuccess;
+    delete host_vienna;
     for (int k = 0; ok && k < 6; k++) ok = hipEventCreate(&c->ev[k]) == hipSuccess;
     if (!ok) {
         fail(nullptr, RH_ERR_HIP, "context setup failed: %s", hipGetErrorString(hipGetLastError()));
@@ -758,7 +802,7 @@ void rh_destroy(rh_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    void* bufs[] = {c->d_seq, c->d_n, c->d_mctab, c->d_f5, c->d_bp, c->d_up, c->d_dxtab, c->d_hp, c->d_logz, c->d_scal, c->d_mclogz, c->d_bad, c->d_cnt, c->d_cand, c->d_dxbad, c->d_zbar, c->d_model, c->d_lin, c->d_dxlin};
+    void* bufs[] = {c->d_seq, c->d_n, c->d_mctab, c->d_f5, c->d_bp, c->d_up, c->d_dxtab, c->d_hp, c->d_logz, c->d_scal, c->d_mclogz, c->d_bad, c->d_cnt, c->d_cand, c->d_dxbad, c->d_zbar, c->d_model, c->d_lin, c->d_dxlin, c->d_vienna};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (GraphSlot* g : {&c->g_in, &c->g_out, &c->g_dx}) if (g->exec) (void)hipGraphExecDestroy(g->exec);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -772,6 +816,8 @@ const char* rh_last_error(const rh_ctx* c) { return c ? c->err.c_str() : g_creat
 int rh_bpp(rh_ctx* c, const char* seq, int n, const char* constraint, double* bp_tri, double* logZ)
 {
     if (!c) return RH_ERR_ARG;
+    if (c->model != RH_MODEL_CONTRAFOLD)
+        return fail(c, RH_ERR_UNSUPPORTED, "the Vienna-BL model currently provides rh_duplex only (pf_fold / pf_unstru equivalents: SURVEY 8f-1)");
     if (constraint) return fail(c, RH_ERR_UNSUPPORTED, "structure constraints are not supported yet");
     if (!seq || n < 0) return fail(c, RH_ERR_ARG, "bad sequence");
     if (n == 0) { if (bp_tri) bp_tri[0] = 0.0; if (logZ) *logZ = 0.0; return RH_OK; }
@@ -786,6 +832,8 @@ int rh_bpp(rh_ctx* c, const char* seq, int n, const char* constraint, double* bp
 int rh_unpaired(rh_ctx* c, const char* seq, int n, int max_w, double* up)
 {
     if (!c) return RH_ERR_ARG;
+    if (c->model != RH_MODEL_CONTRAFOLD)
+        return fail(c, RH_ERR_UNSUPPORTED, "the Vienna-BL model currently provides rh_duplex only (pf_fold / pf_unstru equivalents: SURVEY 8f-1)");
     if (max_w != 1) return fail(c, RH_ERR_UNSUPPORTED, "max_w=%d: only width-1 accessibility (CONTRAfold path) is built", max_w);
     if (!seq || n < 0 || !up) return fail(c, RH_ERR_ARG, "bad argument");
     if (n == 0) return RH_OK;
@@ -798,6 +846,8 @@ int rh_unpaired(rh_ctx* c, const char* seq, int n, int max_w, double* up)
 int rh_fold(rh_ctx* c, const char* seq, int n, double* bp_tri, double* up, double* logZ)
 {
     if (!c) return RH_ERR_ARG;
+    if (c->model != RH_MODEL_CONTRAFOLD)
+        return fail(c, RH_ERR_UNSUPPORTED, "the Vienna-BL model currently provides rh_duplex only (pf_fold / pf_unstru equivalents: SURVEY 8f-1)");
     if (!seq || n < 0) return fail(c, RH_ERR_ARG, "bad sequence");
     if (n == 0) { if (bp_tri) bp_tri[0] = 0.0; if (logZ) *logZ = 0.0; return RH_OK; }
     int rc;
@@ -824,6 +874,8 @@ int rh_duplex(rh_ctx* c, const char* s1, int n1, const char* s2, int n2, double*
 int rh_batch_upload(rh_ctx* c, int npairs, const char* const* s1, const int* n1, const char* const* s2, const int* n2)
 {
     if (!c) return RH_ERR_ARG;
+    if (c->model != RH_MODEL_CONTRAFOLD)
+        return fail(c, RH_ERR_UNSUPPORTED, "the Vienna-BL model currently provides rh_duplex only (pf_fold / pf_unstru equivalents: SURVEY 8f-1)");
     if (npairs < 1 || !s1 || !s2 || !n1 || !n2) return fail(c, RH_ERR_ARG, "bad batch");
     std::vector<const char*> seqs(2 * (size_t)npairs);
     std::vector<int> lens(2 * (size_t)npairs);

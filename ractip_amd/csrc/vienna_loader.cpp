@@ -1,0 +1,93 @@
+// vienna_loader.cpp -- read ractip_amd/data/vienna_bl_star.params and build rh::ViennaDx (see vienna_model.h).
+// The flat arrays keep the order of /root/reference/src/boltzmann_param.c; their index conventions are those of
+// its copy_* loops (:5908-5971): pair types 1..7 for stack/mismatch/int11/int21/int22, nucleotides 0..4 except
+// int22 (1..4), dangles 0..7 x 0..4.
+#include "vienna_model.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+namespace rh {
+
+bool load_vienna_dx(const char* path, ViennaDx* V, char* err, int errlen)
+{
+    std::ifstream f(path);
+    if (!f) { snprintf(err, errlen, "cannot open parameter file %s", path); return false; }
+    std::map<std::string, std::vector<int>> tab;
+    std::string line;
+    while (std::getline(f, line)) {
+        if (line.empty() || line[0] == '#') continue;
+        std::istringstream hs(line);
+        std::string name;
+        int count = 0;
+        if (!(hs >> name >> count) || count <= 0) { snprintf(err, errlen, "bad header '%s' in %s", line.c_str(), path); return false; }
+        std::vector<int>& v = tab[name];
+        v.resize(count);
+        for (int k = 0; k < count; k++)
+            if (!(f >> v[k])) { snprintf(err, errlen, "table %s truncated in %s", name.c_str(), path); return false; }
+        std::getline(f, line);  // rest of the last value line
+    }
+    const struct { const char* name; size_t n; } need[] = {{"stack37", 49}, {"mismatchI37", 175}, {"dangle5_37", 40}, {"dangle3_37", 40},
+        {"int11_37", 1225}, {"int21_37", 6125}, {"int22_37", 12544}, {"bulge37", 31}, {"internal_loop37", 31}, {"MLparams", 4}, {"ninio", 2}};
+    for (auto& t : need)
+        if (tab[t.name].size() != t.n) { snprintf(err, errlen, "table %s missing or of wrong size in %s", t.name, path); return false; }
+
+    std::memset(V, 0, sizeof(*V));
+    const double kT = (37.0 + 273.15) * 1.98717;   // (temperature+K0)*GASCONST, pf_duplex.c:73
+    auto w = [&](int E) { return -E * 10.0 / kT; };
+    const std::vector<int>&stack = tab["stack37"], &mmI = tab["mismatchI37"], &d5 = tab["dangle5_37"], &d3 = tab["dangle3_37"],
+                     &i11 = tab["int11_37"], &i21 = tab["int21_37"], &i22 = tab["int22_37"], &bulge = tab["bulge37"],
+                     &il = tab["internal_loop37"];
+    const int tau = tab["MLparams"][3], ninio = tab["ninio"][0], max_ninio = tab["ninio"][1];
+    int p = 0;
+    for (int i = 1; i <= 7; i++) for (int j = 1; j <= 7; j++) {
+        V->stack[i * 8 + j] = w(stack[p]);
+        V->bulge1[i * 8 + j] = w(bulge[1] + stack[p]);
+        p++;
+    }
+    p = 0;
+    for (int i = 1; i <= 7; i++) for (int a = 0; a < 5; a++) for (int b = 0; b < 5; b++) V->mmI[i * 25 + a * 5 + b] = w(mmI[p++]);
+    p = 0;
+    for (int i = 0; i <= 7; i++) for (int a = 0; a < 5; a++, p++) {
+        V->dangle5[i * 5 + a] = w(std::min(d5[p], 0));   // dangles are clipped to <= 0 by scale_parameters()
+        V->dangle3[i * 5 + a] = w(std::min(d3[p], 0));
+    }
+    p = 0;
+    for (int i = 1; i <= 7; i++) for (int j = 1; j <= 7; j++) for (int a = 0; a < 5; a++) for (int b = 0; b < 5; b++)
+        V->int11[(i * 8 + j) * 25 + a * 5 + b] = w(i11[p++]);
+    p = 0;
+    for (int i = 1; i <= 7; i++) for (int j = 1; j <= 7; j++) for (int a = 0; a < 5; a++) for (int b = 0; b < 5; b++) for (int c = 0; c < 5; c++)
+        V->int21[(i * 8 + j) * 125 + (a * 5 + b) * 5 + c] = w(i21[p++]);
+    p = 0;
+    for (int i = 1; i <= 7; i++) for (int j = 1; j <= 7; j++) for (int a = 1; a < 5; a++) for (int b = 1; b < 5; b++)
+        for (int c = 1; c < 5; c++) for (int d = 1; d < 5; d++)
+            V->int22[(i * 8 + j) * 625 + ((a * 5 + b) * 5 + c) * 5 + d] = w(i22[p++]);
+    V->tau = w(tau);
+    V->duplex_init = w(410);
+    // loop shapes, row-major (l1, l2); length-dependent part of LoopEnergy (ViennaRNA 1.8)
+    int k = 0;
+    for (int l1 = 0; l1 <= 30; l1++)
+        for (int l2 = 0; l1 + l2 <= 30; l2++, k++) {
+            const int nl = std::max(l1, l2), ns = std::min(l1, l2);
+            int kind, E = 0;
+            if (nl <= 2 && !(ns == 0 && nl == 2)) kind = 0;   // (0,0) (0,1) (1,0) (1,1) (1,2) (2,1) (2,2): explicit tables
+            else if (ns == 0) { kind = 2; E = bulge[nl]; }
+            else { kind = 1; E = il[l1 + l2] + std::min(max_ninio, (nl - ns) * ninio); }
+            V->shape[k] = Shape{w(E), l1, l2};
+            V->kind[k] = kind;
+        }
+    for (; k < kMcShapes; k++) { V->shape[k] = Shape{0.0, 1000, 1000}; V->kind[k] = 1; }
+    const int T[5][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 5}, {0, 0, 0, 1, 0}, {0, 0, 2, 0, 3}, {0, 6, 0, 4, 0}};
+    for (int a = 0; a < 5; a++) for (int b = 0; b < 5; b++) V->ptype[a * 5 + b] = T[a][b];
+    const int R[8] = {0, 2, 1, 4, 3, 6, 5, 7};
+    for (int t = 0; t < 8; t++) V->rtype[t] = R[t];
+    return true;
+}
+
+}  // namespace rh

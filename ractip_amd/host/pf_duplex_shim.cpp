@@ -9,10 +9,13 @@
 // pf_duplex allocates pr_duplex (rows 1..n1, each n2+1 doubles, row 0 NULL;
 // pf_duplex.c:94-95) and returns log Z; free_pf_duplex releases it (:119-126).
 //
-// Scoring: the original evaluates ViennaRNA loop energies (E_IntLoop/E_ExtLoop), which
-// are third-party and absent (parity unpinned).  Until the ViennaBL model
-// row (8f-1) exists this shim runs the same forward/backward sweeps with the CONTRAfold
-// duplex scores -- i.e. it returns what RactIP::contraduplex would.
+// Scoring: RH_MODEL_VIENNA_BL -- the BL* tables that RactIP installs by default
+// (src/boltzmann_param.c, copy_boltzmann_parameters at src/ractip.cpp:1566-1567) evaluated with
+// ViennaRNA-1.8 loop-energy semantics, i.e. the 1.8 branch of src/pf_duplex.c:209-433.  PARITY UNPINNED:
+// ViennaRNA itself is a third-party dependency that is absent and unversioned, and the
+// 2.x branch that the reference's CMake selects needs tables the repository does not hold.
+// RACTIP_AMD_DUPLEX_MODEL=contrafold selects the CONTRAfold duplex scores instead (what
+// RactIP::contraduplex computes, src/ractip.cpp:225-245).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -31,7 +34,9 @@ double pf_duplex(const char* s1, const char* s2)
     const int n1 = (int)std::strlen(s1), n2 = (int)std::strlen(s2);
     if (!g_ctx) {
         const char* dev = std::getenv("RACTIP_AMD_DEVICE");
-        g_ctx = rh_create(dev ? std::atoi(dev) : 0, RH_MODEL_CONTRAFOLD, nullptr);
+        const char* mdl = std::getenv("RACTIP_AMD_DUPLEX_MODEL");
+        const int model = (mdl && !std::strcmp(mdl, "contrafold")) ? RH_MODEL_CONTRAFOLD : RH_MODEL_VIENNA_BL;
+        g_ctx = rh_create(dev ? std::atoi(dev) : 0, model, nullptr);
         if (!g_ctx) {  // the original aborts inside ViennaRNA's space() on failure; do the same, loudly
             std::fprintf(stderr, "pf_duplex (ractip_amd): %s\n", rh_last_error(nullptr));
             std::abort();

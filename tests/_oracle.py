@@ -131,3 +131,34 @@ def assert_log_close(got, ref, tol=1e-9, what=""):
     if (~ri).any():
         d = np.abs(got[~ri] - ref[~ri])
         assert d.max() <= tol, "%s: max |dlog| %.3e" % (what, d.max())
+
+
+class ViennaOracle:
+    """BL*/ViennaRNA-1.8-semantics pf_duplex restatement (oracle/vienna_oracle.c) -- PARITY UNPINNED."""
+
+    def __init__(self):
+        so = os.path.join(ORACLE_DIR, "libvienna_oracle.so")
+        src = os.path.join(ORACLE_DIR, "vienna_oracle.c")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "oracle"])
+        L = ctypes.CDLL(so)
+        L.vo_load.restype = ctypes.c_void_p
+        L.vo_load.argtypes = [ctypes.c_char_p]
+        L.vo_pf_duplex.restype = ctypes.c_double
+        L.vo_pf_duplex.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int] + [ctypes.c_void_p] * 4
+        L.vo_bruteforce.restype = ctypes.c_double
+        L.vo_bruteforce.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p]
+        self.L = L
+        self.m = L.vo_load(os.path.join(ROOT, "ractip_amd", "data", "vienna_bl_star.params").encode())
+        assert self.m
+
+    def pf_duplex(self, s1, s2):
+        pr = np.zeros((len(s1) + 1, len(s2) + 1))
+        ebk = ctypes.c_double()
+        z = self.L.vo_pf_duplex(self.m, s1.encode(), len(s1), s2.encode(), len(s2), pr.ctypes.data, None, None, ctypes.byref(ebk))
+        return dict(logZ=z, logZ_bk=ebk.value, pr=pr)
+
+    def bruteforce(self, s1, s2):
+        pr = np.zeros((len(s1) + 1, len(s2) + 1))
+        z = self.L.vo_bruteforce(self.m, s1.encode(), len(s1), s2.encode(), len(s2), pr.ctypes.data)
+        return dict(logZ=z, pr=pr)

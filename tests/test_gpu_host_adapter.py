@@ -67,10 +67,27 @@ def test_contraduplex_threshold_and_rnaduplex(cli, oracle, golden):
     close32(np.where(edge, 0, hp_t), np.where(edge, 0, expect), "contraduplex hp")
 
 
+def run_env(cli, env, *args):
+    e = dict(os.environ)
+    e.update(env)
+    out = subprocess.run([cli] + list(args), check=True, capture_output=True, text=True, env=e).stdout.split("\n")
+    return [l for l in out if l]
+
+
 def test_pf_duplex_shim_surface(cli, oracle, golden):
+    """double pf_duplex(s1,s2); extern double** pr_duplex; void free_pf_duplex() -- src/pf_duplex.h:25-28."""
+    from _oracle import ViennaOracle
     s1, s2 = str(golden["mc/R1inv/seq"]), str(golden["mc/R2inv/seq"])
+    # default: BL* energies, ViennaRNA-1.8 semantics (parity unpinned; checked against our CPU restatement)
     lines = run(cli, "pfduplex", s1, s2)
     assert lines[0].startswith("logZ")
+    z = float(lines[0].split()[1])
+    hp, _ = take(lines, 1, "hp")
+    o = ViennaOracle().pf_duplex(s1, s2)
+    assert abs(z - o["logZ"]) < 1e-9 * max(1.0, abs(z))
+    assert np.abs(hp - o["pr"]).max() < 1e-9
+    # CONTRAfold duplex scores on request: pinned to the reference's DuplexEngine
+    lines = run_env(cli, {"RACTIP_AMD_DUPLEX_MODEL": "contrafold"}, "pfduplex", s1, s2)
     z = float(lines[0].split()[1])
     hp, _ = take(lines, 1, "hp")
     o = oracle.duplex(s1, s2)

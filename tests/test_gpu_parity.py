@@ -249,6 +249,32 @@ def test_custom_parameter_file(hotlib, oracle, tmp_path):
     assert abs(z - oracle.inference(seq)["logZ"]) > 1e-3   # the perturbation really changed the model
 
 
+def test_vienna_bl_duplex_vs_its_cpu_restatement(hotlib, golden):
+    """RH_MODEL_VIENNA_BL (pf_duplex with BL* energies, ViennaRNA-1.8 semantics): PARITY UNPINNED against the
+    reference; the HIP kernels are checked against oracle/vienna_oracle.c, which is itself checked against
+    brute-force enumeration (tests/test_vienna_oracle.py)."""
+    import ractip_amd
+    from _oracle import ViennaOracle
+    vo = ViennaOracle()
+    c = ractip_amd.Context(device=0, model=ractip_amd.hot.RH_MODEL_VIENNA_BL)
+    rng = np.random.RandomState(77)
+    cases = [(str(golden["mc/%s/seq" % a]), str(golden["mc/%s/seq" % b])) for a, b in
+             (("DIS", "DIS"), ("CopA", "CopT"), ("OxyS", "fhlA"), ("Tar", "Tarstar"), ("R1inv", "R2inv"))]
+    cases += [(rnd(rng, a), rnd(rng, b)) for a, b in ((1, 1), (3, 9), (40, 33), (120, 95), (64, 200))]
+    cases += [("GGGTTTNNNCCC", "GGGAAACCCUUU")]
+    for s1, s2 in cases:
+        hp, z = c.duplex(s1, s2)
+        o = vo.pf_duplex(s1, s2)
+        if not np.isfinite(o["logZ"]):
+            assert z < NEG / 2 and hp.max() == 0
+            continue
+        assert abs(z - o["logZ"]) < 1e-9 * max(1.0, abs(z)), (len(s1), len(s2))
+        assert_prob_close(hp, o["pr"], rel=REL, what="vienna duplex %d/%d" % (len(s1), len(s2)))
+    with pytest.raises(ractip_amd.RhError):
+        c.bpp("ACGU")          # pf_fold / pf_unstru equivalents are not built (SURVEY 8f-1)
+    c.close()
+
+
 def test_errors_are_reported_not_swallowed(ctx):
     import ractip_amd
     with pytest.raises(ractip_amd.RhError):

@@ -1,0 +1,46 @@
+"""CPU suite for the PARITY-UNPINNED Vienna-BL duplex restatement (oracle/vienna_oracle.c): no reference output
+exists for this path (ViennaRNA is absent and unversioned), so the checks are model-independent -- the DP equals
+brute-force enumeration of every duplex under the same energy function, and forward log Z == backward log Z."""
+import numpy as np
+import pytest
+
+from _oracle import ViennaOracle
+
+
+@pytest.fixture(scope="module")
+def vo():
+    return ViennaOracle()
+
+
+def test_dp_equals_bruteforce_enumeration(vo):
+    rng = np.random.RandomState(12)
+    for n1, n2 in ((1, 1), (2, 3), (4, 4), (5, 7), (8, 6), (9, 9)):
+        for _ in range(3):
+            s1 = "".join(rng.choice(list("ACGU"), n1))
+            s2 = "".join(rng.choice(list("ACGU"), n2))
+            a, b = vo.pf_duplex(s1, s2), vo.bruteforce(s1, s2)
+            if not np.isfinite(b["logZ"]):
+                assert not np.isfinite(a["logZ"]) and a["pr"].max() == 0
+                continue
+            assert abs(a["logZ"] - b["logZ"]) < 1e-10, (s1, s2)
+            assert np.abs(a["pr"] - b["pr"]).max() < 1e-10, (s1, s2)
+
+
+def test_forward_equals_backward_and_probabilities_are_sane(vo, golden):
+    for a, b in (("DIS", "DIS"), ("CopA", "CopT"), ("OxyS", "fhlA"), ("Tar", "Tarstar")):
+        s1, s2 = str(golden["mc/%s/seq" % a]), str(golden["mc/%s/seq" % b])
+        r = vo.pf_duplex(s1, s2)
+        assert abs(r["logZ"] - r["logZ_bk"]) < 1e-9 * max(1.0, abs(r["logZ"]))
+        pr = r["pr"]
+        assert pr.min() >= 0 and pr.max() <= 1 + 1e-12
+        assert pr.sum(axis=1).max() <= 1 + 1e-9 and pr.sum(axis=0).max() <= 1 + 1e-9
+    # CopA/CopT are fully complementary antisense RNAs: the model must find the full-length duplex
+    r = vo.pf_duplex(str(golden["mc/CopA/seq"]), str(golden["mc/CopT/seq"]))
+    assert r["pr"].max() > 0.99
+
+
+def test_t_reads_as_u_and_unknown_letters_do_not_pair(vo):
+    a = vo.pf_duplex("GGGAAACCC", "GGGTTTCCC")
+    b = vo.pf_duplex("GGGAAACCC", "GGGUUUCCC")
+    assert a["logZ"] == b["logZ"]
+    assert vo.pf_duplex("NNNN", "NNNN")["pr"].max() == 0
