@@ -87,6 +87,26 @@ out["mc1000/idx"] = idx.astype(np.int64)
 out["mc1000/val"] = post[idx]
 print("mc1000 logZ=%.9f sum=%.9f nnz=%d" % (z, post.sum(), idx.size))
 
+# n=2000 (BASELINE config 4): scalars + sparse posteriors of the mt19937(12345) pair; ~3 min of reference CPU time
+if os.environ.get("GOLDEN_SKIP_2000") != "1":
+    a2000, b2000 = random_pair(2000)
+    post = np.zeros(2001 * 2002 // 2)
+    z = lib.ref_inference(a2000.encode(), 0, post.ctypes.data, None, None)
+    out["mc2000/logZ"] = np.array(z)
+    out["mc2000/post_sum"] = np.array(post.sum())
+    idx = np.flatnonzero(post > 1e-3)
+    out["mc2000/idx"] = idx.astype(np.int64)
+    out["mc2000/val"] = post[idx]
+    print("mc2000 logZ=%.9f sum=%.9f nnz=%d" % (z, post.sum(), idx.size))
+    hp2000 = np.zeros(2001 * 2001); z2 = np.zeros(2)
+    lib.ref_duplex(a2000.encode(), b2000.encode(), 0, hp2000.ctypes.data, None, None, z2.ctypes.data)
+    out["dx2000/logZ2"] = z2
+    out["dx2000/post_sum"] = np.array(hp2000.sum())
+    idx = np.flatnonzero(hp2000 > 1e-4)
+    out["dx2000/idx"] = idx.astype(np.int64)
+    out["dx2000/val"] = hp2000[idx]
+    print("dx2000 logZ=%.9f sum=%.9f nnz=%d" % (z2[0], hp2000.sum(), idx.size))
+
 pairs = [("DIS", "DIS"), ("CopA", "CopT"), ("IncRNA54", "RepZ"), ("MicA", "ompA"), ("OxyS", "fhlA"),
          ("R1inv", "R2inv"), ("RyhB", "SodB"), ("Tar", "Tarstar"), ("rnd1", "rnd3"), ("rnd5", "rnd8"),
          ("rnd17", "rnd33"), ("rnd40", "rnd64"), ("rnd65", "rnd31"), ("mixedTN", "rnd17"), ("polyA", "polyA"),

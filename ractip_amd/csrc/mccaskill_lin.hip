@@ -182,7 +182,6 @@ __global__ __launch_bounds__(64 * W) void lin_inside_diag(McBatch B, const LinMo
 
     // ---- FM2[i,d] = sum_{m=1}^{d-1} FM1[m][i] * FM[d-m][i+m]          (ipp:3384-3411)
     double acc2 = 0.0;
-#ifndef RH_EXP_NOFM2
     {
         const double* __restrict__ fm1 = tab + L_FM1 * ts + i;
         const double* __restrict__ fm = tab + L_FM * ts + i;
@@ -215,14 +214,12 @@ __global__ __launch_bounds__(64 * W) void lin_inside_diag(McBatch B, const LinMo
         }
         if (BS > 0 && valid && kB > 0) acc2 += (w == 0) ? tab[L_FM2F * ts + d * ld + i] : 0.0;
     }
-#endif
 
     // ---- generic single-branch shapes of FC[i,d]: sum_t sum_l1 w(l1,t-l1) * FCX[d-2-t][i+1+l1]   (ipp:3597-3619)
     // For one t the 64 cells of the group read overlapping windows of ONE row: the segment is staged in LDS
     // once and each lane runs a (t+1)-tap filter over it; shape weights are wave-uniform (scalar loads).
     // t and 30-t go to the same wavefront so that every wavefront filters ~62 taps.
     double accc = 0.0;
-#ifndef RH_EXP_NOGATHER
     if (d >= 2) {
         const int tmax = d - 2 < kMaxSingle ? d - 2 : kMaxSingle;
         const int i0 = 1 + slot * 64;
@@ -249,7 +246,6 @@ __global__ __launch_bounds__(64 * W) void lin_inside_diag(McBatch B, const LinMo
             if (tseg[q] >= 0) accc += filt_fwd_any(tseg[q], L->shape_w + tseg[q] * (tseg[q] + 1) / 2, &gbuf[w][q][lane]);
         if (!pairable) accc = 0.0;
     }
-#endif
 
     part[0][w][lane] = acc2;
     part[1][w][lane] = accc;

@@ -615,7 +615,7 @@ int compute(rh_ctx* c)
     const int pin = (c->has_mc && c->mc.ns % 8 == 0) ? 1 : 0;
     int rc;
     // duplex first on its own stream: it is independent of the McCaskill sweeps and overlaps them
-    // RH_EXP_SKIP=dx|mc: timing experiments only (results of the skipped engine are stale)
+    // RH_EXP_SKIP=dx|mc (tools/exp_time.py): timing experiments only -- results of the skipped engine are stale
     const char* skip = std::getenv("RH_EXP_SKIP");
     const bool skip_dx = skip && !std::strcmp(skip, "dx"), skip_mc = skip && !std::strcmp(skip, "mc");
     HIP_TRY(c, hipEventRecord(c->ev[3], c->s_dx));

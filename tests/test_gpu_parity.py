@@ -159,6 +159,23 @@ def test_properties_full_size(ctx):
     assert abs(r["logZ"][0] - 258.796119) < 1e-5  # SURVEY 8c known answer, InferenceEngine<double>, n=2000
 
 
+def test_n2000_vs_golden(ctx, golden):
+    """BASELINE.json config 4 (n=2000/2000): reference logZ and sparse posteriors of the mt19937(12345) pair."""
+    if "mc2000/logZ" not in golden.files:
+        pytest.skip("n=2000 golden vectors not generated")
+    s1, s2 = random_pair(2000)
+    ctx.batch_upload([(s1, s2)])
+    ctx.batch_compute()
+    r = ctx.batch_results(0)
+    assert abs(r["logZ"][0] - float(golden["mc2000/logZ"])) < 1e-7
+    assert abs(r["bp1"].sum() - float(golden["mc2000/post_sum"])) < 1e-5
+    assert_prob_close(r["bp1"][golden["mc2000/idx"]], golden["mc2000/val"], rel=REL, what="bp n=2000")
+    assert abs(r["logZ"][2] - golden["dx2000/logZ2"][0]) < 1e-6
+    hp = r["hp"].ravel()
+    assert abs(hp.sum() - float(golden["dx2000/post_sum"])) < 1e-5
+    assert_prob_close(hp[golden["dx2000/idx"]], golden["dx2000/val"], rel=REL, what="hp n=2000")
+
+
 def test_linear_path_is_taken_and_falls_back_on_overflow(ctx, oracle):
     """Ordinary inputs run on the linear fast path; a long perfect GC helix drives the scaled
     partition function out of the double range, which must be detected and recomputed in log space."""

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Timing experiment helper: time rh_batch_compute phases with an alternative build of the library
-(results are NOT checked: experiment builds may skip work).  usage: exp_time.py lib.so n batch [mode]"""
+"""Timing helper: HIP-event phase times of rh_batch_compute for synthetic pairs (optionally with an alternative
+build of the library; RH_EXP_SKIP=dx|mc times one engine alone).  usage: exp_time.py default|lib.so n batch [mode]"""
 import ctypes, sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
