@@ -29,8 +29,9 @@ typedef struct rh_ctx rh_ctx;
 
 /* scoring model selector */
 #define RH_MODEL_CONTRAFOLD 0 /* --contrafold path: src/ractip.cpp:195-246 */
-#define RH_MODEL_VIENNA_BL 1  /* --duplex path: pf_duplex with BL* energies, ViennaRNA-1.8 semantics; rh_duplex only;
-                                 PARITY UNPINNED (ViennaRNA is absent and unversioned) */
+#define RH_MODEL_VIENNA_BL 1  /* default CLI path: pf_fold bp + pf_unstru up (src/ractip.cpp:248-382) and the --duplex
+                                 pf_duplex hp (src/ractip.cpp:390-398) with the BL* energies of src/boltzmann_param.c in
+                                 ViennaRNA-1.8 semantics; PARITY UNPINNED (ViennaRNA is absent and unversioned) */
 
 #define RH_OK 0
 #define RH_ERR_ARG (-1)
@@ -70,13 +71,20 @@ int rh_last_path(const rh_ctx* ctx);
 int rh_bpp(rh_ctx* ctx, const char* seq, int n, const char* constraint,
            double* bp_tri, double* logZ);
 
-/* Accessibility.  max_w == 1 replaces src/ractip.cpp:213-222
- * (up[i] = max(0, 1 - sum_j bp(i,j))); max_w > 1 (pf_unstru, src/ractip.cpp:370-375)
- * is RH_ERR_UNSUPPORTED until the Vienna model exists. */
+/* Accessibility, up[i*max_w+w] = P(letters i..i+w unpaired), n*max_w doubles.  RH_MODEL_CONTRAFOLD: max_w must be 1
+ * (src/ractip.cpp:213-222, up[i] = max(0, 1 - sum_j bp(i,j))).  RH_MODEL_VIENNA_BL: any 1 <= max_w <= 64; replaces
+ * pf_unstru and the H+I+M+E sum of src/ractip.cpp:370-375.  Sets the context's max_w (see rh_set_max_w). */
 int rh_unpaired(rh_ctx* ctx, const char* seq, int n, int max_w, double* up);
 
-/* Both of the above from ONE inside/outside pass -- the whole of RactIP::contrafold
- * (src/ractip.cpp:199-222).  bp_tri, up (n doubles, width 1) or logZ may be NULL. */
+/* Number of accessibility widths the batched / rh_fold forms compute (RactIP's --max-w, src/ractip.cpp:546-547:
+ * rnafold(..., std::max(1, max_w_))).  Default 1 for RH_MODEL_CONTRAFOLD (only value allowed), 15 for
+ * RH_MODEL_VIENNA_BL.  Takes effect at the next upload / single-sequence call. */
+int rh_set_max_w(rh_ctx* ctx, int max_w);
+int rh_get_max_w(const rh_ctx* ctx);
+
+/* Both of the above from ONE inside/outside pass -- the whole of RactIP::contrafold (src/ractip.cpp:199-222) or of
+ * the accessibility overload of RactIP::rnafold (src/ractip.cpp:308-382).  bp_tri, up (n*max_w doubles, max_w as set
+ * by rh_set_max_w) or logZ may be NULL. */
 int rh_fold(rh_ctx* ctx, const char* seq, int n, double* bp_tri, double* up, double* logZ);
 
 /* Hybridization probabilities of a pair.  Replaces RactIP::contraduplex
@@ -108,7 +116,7 @@ int rh_batch_results(rh_ctx* ctx, int p,
 int rh_batch_logz(rh_ctx* ctx, double* out);
 
 typedef struct rh_cand {
-    int i, j; /* 1-based letters; for `up`: i = 0-based position, j = width index */
+    int i, j; /* 1-based letters; for `up`: i = 0-based position, j = width index (region i..i+j, src/ractip.cpp:621-627) */
     float p;  /* probability narrowed to float exactly as the reference does (src/ractip.cpp:82-83) */
 } rh_cand;
 /* which: 0 = bp1 (p > th), 1 = bp2, 2 = hp, 3 = up1, 4 = up2.  Writes at most `cap`
@@ -122,7 +130,8 @@ int rh_batch_candidates_all(rh_ctx* ctx, int which, float threshold, rh_cand* ou
 
 /* Dense results of the whole batch in three copies, in the padded device layout described by rh_batch_layout:
  *   bp [2*npairs][tri_stride]  (sequence 2p = s1 of pair p; each table in the reference's triangular layout for ITS n)
- *   up [2*npairs][up_ld]       hp [npairs][hp_stride] with row pitch hp_ld       logz [3*npairs]
+ *   up [2*npairs][up_ld]       (n*max_w entries used, row-major position x width)
+ *   hp [npairs][hp_stride] with row pitch hp_ld       logz [3*npairs]
  * Any pointer may be NULL. */
 int rh_batch_layout(rh_ctx* ctx, size_t* tri_stride, int* up_ld, size_t* hp_stride, int* hp_ld);
 int rh_batch_results_all(rh_ctx* ctx, double* bp, double* up, double* hp, double* logz);

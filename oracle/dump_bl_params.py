@@ -28,4 +28,11 @@ with open(out, "w") as f:
         for k in range(0, len(vals), 20):
             f.write(" ".join(str(v) for v in vals[k:k + 20]) + "\n")
         print(name, len(vals))
+# tetraloop bonuses (boltzmann_param.c:5869-5906): closing pair + 4 loop letters, energy
+tl = re.findall(r'\{\s*"([ACGU]{6})"\s*,\s*(-?\d+)\s*\}', src)
+with open(out, "a") as f:
+    f.write("tetraloops %d\n" % len(tl))
+    for seq, e in tl:
+        f.write("%s %s\n" % (seq, e))
+print("tetraloops", len(tl))
 print("wrote", os.path.normpath(out))

@@ -32,6 +32,12 @@ typedef struct vo_model {
     int int22[NBP + 1][NBP + 1][5][5][5][5];
     int bulge[31], internal_loop[31];
     int TerminalAU, ninio, max_ninio, DuplexInit;
+    /* McCaskill part (pf_fold semantics) */
+    int hairpin[31], mismatchH[NBP + 1][5][5];
+    int ML_base, ML_closing, ML_intern;
+    int n_tetra; char tetra[64][8]; int tetra_e[64];
+    double d5x[NBP + 1][5], d3x[NBP + 1][5]; /* stem dangles (10 cal/mol, smoothed) with the end-of-sequence rule folded into code 0 */
+    double lxc;
     double kT; /* cal/mol */
 } vo_model;
 
@@ -53,6 +59,15 @@ static int read_table(FILE* f, const char* want, int* dst, int count)
         }
     }
     return -1;
+}
+
+static double vo_smooth(double X)
+{
+    const double x = X / 10.0;
+    if (x < -1.2283697) return 0.0;
+    if (x > 0.8660254) return X;
+    const double t = sin(x - 0.34242663) + 1.0;
+    return 10.0 * 0.38490018 * t * t;
 }
 
 vo_model* vo_load(const char* path)
@@ -82,17 +97,44 @@ vo_model* vo_load(const char* path)
         for (int q = 1; q < 5; q++) for (int r = 1; r < 5; r++) m->int22[i][j][k][l][q][r] = buf[p++];
     bad |= read_table(f, "bulge37", m->bulge, 31);
     bad |= read_table(f, "internal_loop37", m->internal_loop, 31);
+    bad |= read_table(f, "hairpin37", m->hairpin, 31);
+    bad |= read_table(f, "mismatchH37", buf, 175); p = 0;
+    for (int i = 1; i <= NBP; i++) for (int j = 0; j < 5; j++) for (int k = 0; k < 5; k++) m->mismatchH[i][j][k] = buf[p++];
     bad |= read_table(f, "MLparams", buf, 4);
+    m->ML_base = buf[0]; m->ML_closing = buf[1]; m->ML_intern = buf[2];   /* copy_MLparams, boltzmann_param.c:5973-5983 */
     m->TerminalAU = buf[3];
+    {   /* tetraloops: "SEQ energy" lines after the header */
+        rewind(f);
+        char line2[256], nm[64]; int cnt;
+        while (fgets(line2, sizeof line2, f))
+            if (sscanf(line2, "%63s %d", nm, &cnt) == 2 && strcmp(nm, "tetraloops") == 0) {
+                m->n_tetra = cnt;
+                for (int k = 0; k < cnt && k < 64; k++)
+                    if (fscanf(f, "%7s %d", m->tetra[k], &m->tetra_e[k]) != 2) bad = 1;
+                break;
+            }
+    }
+    m->lxc = 107.856;  /* lxc37, ViennaRNA constant (not overridden by BL*) */
     bad |= read_table(f, "ninio", buf, 2);
     m->ninio = buf[0]; m->max_ninio = buf[1];
     free(buf);
     fclose(f);
     if (bad) { free(m); return NULL; }
+    int raw5[NBP + 1][5], raw3[NBP + 1][5];
+    memcpy(raw5, m->dangle5, sizeof raw5); memcpy(raw3, m->dangle3, sizeof raw3);
     /* scale_parameters() at 37 C leaves the *37 tables unchanged except that dangles are clipped to <= 0 */
     for (int i = 0; i <= NBP; i++) for (int j = 0; j < 5; j++) {
         if (m->dangle5[i][j] > 0) m->dangle5[i][j] = 0;
         if (m->dangle3[i][j] > 0) m->dangle3[i][j] = 0;
+    }
+    /* stems of multi/exterior loops in pf_fold (1.8): dangles on both sides whenever the neighbour exists; TerminalAU is
+       folded into the 3' dangle, and at the 3' end of the sequence only TerminalAU remains.  Code 0 = no neighbour. */
+    /* part_func.c (1.8) does not clip the dangles: expdangle = exp(SMOOTH(-GT)*10/kT) with the C2-smooth ramp
+       SMOOTH(X) = 0 for X/10 < -1.2283697, X for X/10 > 0.8660254, else 10*0.38490018*(sin(X/10-0.34242663)+1)^2 */
+    for (int t = 0; t <= NBP; t++) for (int x = 0; x < 5; x++) {
+        const double tau = t > 2 ? m->TerminalAU : 0;
+        m->d5x[t][x] = x ? -vo_smooth(-(double)raw5[t][x]) : 0.0;
+        m->d3x[t][x] = (x ? -vo_smooth(-(double)raw3[t][x]) : 0.0) + tau;
     }
     m->DuplexInit = 410;
     m->kT = (37.0 + 273.15) * 1.98717; /* (temperature+K0)*GASCONST, pf_duplex.c:73, ractip.cpp:262 */
@@ -274,5 +316,310 @@ double vo_bruteforce(const vo_model* P, const char* s1, int n1, const char* s2, 
         for (size_t k = 0; k < (size_t)(n1 + 1) * (n2 + 1); k++) pr[k] = b.Z > 0 ? b.marg[k] / b.Z : 0.0;
     const double z = b.Z > 0 ? log(b.Z) : -INFINITY;
     free(b.marg); free(S1); free(S2);
+    return z;
+}
+
+
+/* ===================================================================================================
+ * McCaskill partition function with the same tables (pf_fold semantics of ViennaRNA 1.8 part_func.c: dangles on
+ * both sides of every multi/exterior stem, TerminalAU folded into the 3' dangle, smoothed dangles, tetraloop
+ * bonuses, hairpins > 30 extrapolated with lxc) -- PARITY UNPINNED like the duplex above: it is what
+ * /root/reference/src/ractip.cpp:288-304, 351-367 obtains from the third-party pf_fold()/export_bppm(), and
+ * what :370-375 obtains from pf_unstru() (P(i..i+w unpaired) = H+I+M+E).  Written with the gap-indexed tables of
+ * the CONTRAfold engine (cell (i,j): letters i and j+1 paired) so that the HIP kernels can be compared table by
+ * table, but NOT with its multiloop grammar: FM = FM2 | FM[i,j-1]+b | FM1 with FM2 = FM1 x FM
+ * (InferenceEngine.ipp:3384-3411, 3669-3688) derives a multiloop part with >= 2 branches and trailing unpaired
+ * letters in more than one way, which is what the reference computes for the CONTRAfold model but is not a
+ * partition function.  Here trailing unpaired letters belong to the LAST branch only (as qqm does in part_func.c):
+ *     FM1[i,j] = leading unpaired + one branch ending at j        FMS[i,j] = FM1[i,j] (+) FMS[i,j-1]+b
+ *     FM2[i,j] = (+)_k FM1[i,k] + FM[k,j]                        FM[i,j]  = FM2[i,j] (+) FMS[i,j]
+ * Validated independently by brute-force enumeration of all secondary structures.
+ * =================================================================================================== */
+typedef struct { const vo_model* P; const int* S; int n; double sc; } mc_t;
+
+static int tetra_bonus(const vo_model* P, const int* S, int a)
+{
+    static const char L[] = "_ACGU";
+    char key[7];
+    for (int k = 0; k < 6; k++) key[k] = L[S[a + k]];
+    key[6] = 0;
+    for (int k = 0; k < P->n_tetra; k++) if (strcmp(key, P->tetra[k]) == 0) return P->tetra_e[k];
+    return 0;
+}
+/* all energies below in 10 cal/mol; letters a < b paired */
+static double e_hairpin(const mc_t* c, int a, int b)
+{   /* part_func.c (1.8) expHairpinEnergy: exphairpin[u] (u > 30: hairpin[30] + lxc*log(u/30), not truncated),
+       tetraloop bonus, u == 3: TerminalAU only, else mismatchH */
+    const vo_model* P = c->P; const int* S = c->S;
+    const int u = b - a - 1, type = ptype(S[a], S[b]);
+    double E = u <= 30 ? (double)P->hairpin[u] : P->hairpin[30] + P->lxc * log(u / 30.0);
+    if (u == 4) E += tetra_bonus(P, S, a);
+    if (u == 3) { if (type > 2) E += P->TerminalAU; }
+    else E += P->mismatchH[type][S[a + 1]][S[b - 1]];
+    return E;
+}
+static double e_interior(const mc_t* c, int a, int b, int p, int q)
+{   /* outer pair (a,b), inner pair (p,q) */
+    const int* S = c->S;
+    return loop_energy(c->P, p - a - 1, b - q - 1, ptype(S[a], S[b]), RTYPE[ptype(S[p], S[q])], S[a + 1], S[b - 1], S[p - 1], S[q + 1]);
+}
+static double e_mlclose(const mc_t* c, int a, int b)
+{
+    const vo_model* P = c->P; const int* S = c->S;
+    const int tt = RTYPE[ptype(S[a], S[b])];
+    return P->ML_closing + P->ML_intern + P->d3x[tt][S[a + 1]] + P->d5x[tt][S[b - 1]];
+}
+static double e_stem(const mc_t* c, int p, int q)
+{   /* stem (p,q) in a multi or exterior loop, without ML_intern */
+    const vo_model* P = c->P; const int* S = c->S;
+    const int t = ptype(S[p], S[q]);
+    return P->d5x[t][S[p - 1]] + P->d3x[t][S[q + 1]];
+}
+
+/* post: T(n) triangular (reference layout) or NULL; up: n*max_w row-major, up[i*max_w+w] = P(letters i+1..i+1+w
+ * unpaired) (0 where the region runs off the end) or NULL; tabs: 8*T log-space tables FCi,FMi,FM1i,FCo,FMo,FM1o,
+ * FMSi,FMSo + f5: 2*(n+1) (F5i, F5o) or NULL.  Returns log Z (inside); *logz_out = outside log Z. */
+double vo_mccaskill(const vo_model* P, const char* seq, int n, double* post, double* logz_out,
+                    double* up, int max_w, double* tabs, double* f5)
+{
+    const int L = n;
+    const long T = (long)(L + 1) * (L + 2) / 2;
+    int* S = (int*)calloc(L + 3, sizeof(int));
+    for (int i = 1; i <= L; i++) S[i] = vcode(seq[i - 1]);
+    long* off = (long*)malloc(sizeof(long) * (L + 2));
+    for (int i = 0; i <= L; i++) off[i] = (long)i * (2 * (L + 1) - i - 1) / 2;
+    double* buf = (double*)malloc(sizeof(double) * (8 * T + 2 * (L + 1)));
+    double *FCi = buf, *FMi = buf + T, *FM1i = buf + 2 * T, *FCo = buf + 3 * T, *FMo = buf + 4 * T, *FM1o = buf + 5 * T,
+           *FMSi = buf + 6 * T, *FMSo = buf + 7 * T, *F5i = buf + 8 * T, *F5o = buf + 8 * T + (L + 1);
+    for (long k = 0; k < 8 * T + 2 * (L + 1); k++) buf[k] = -INFINITY;
+    mc_t c = {P, S, L, 10.0 / P->kT};
+    const double sc = c.sc, mlb = -P->ML_base * sc, mli = -P->ML_intern * sc;
+#define PAIR(a, b) ((a) >= 1 && (b) <= L && ptype(S[a], S[b]))
+    /* inside */
+    for (int i = L; i >= 0; i--)
+        for (int j = i; j <= L; j++) {
+            double fm2 = -INFINITY;
+            for (int k = i + 1; k < j; k++) fm2 = logadd(fm2, FM1i[off[i] + k] + FMi[off[k] + j]);
+            if (0 < i && j < L && PAIR(i, j + 1)) {
+                double acc = -INFINITY;
+                if (j - i >= 3) acc = logadd(acc, -e_hairpin(&c, i, j + 1) * sc);
+                for (int p = i; p <= (i + MAXLOOP < j ? i + MAXLOOP : j); p++) {
+                    int qmin = p + 2 > p - i + j - MAXLOOP ? p + 2 : p - i + j - MAXLOOP;
+                    for (int q = j; q >= qmin; q--) {
+                        if (!PAIR(p + 1, q)) continue;
+                        acc = logadd(acc, FCi[off[p + 1] + q - 1] - e_interior(&c, i, j + 1, p + 1, q) * sc);
+                    }
+                }
+                acc = logadd(acc, fm2 - e_mlclose(&c, i, j + 1) * sc);
+                FCi[off[i] + j] = acc;
+            }
+            if (0 < i && i + 2 <= j && j < L) {
+                double acc = -INFINITY;
+                if (PAIR(i + 1, j)) acc = logadd(acc, FCi[off[i + 1] + j - 1] + mli - e_stem(&c, i + 1, j) * sc);
+                acc = logadd(acc, FM1i[off[i + 1] + j] + mlb);
+                FM1i[off[i] + j] = acc;
+                const double fms = logadd(acc, FMSi[off[i] + j - 1] + mlb);
+                FMSi[off[i] + j] = fms;
+                FMi[off[i] + j] = logadd(fm2, fms);
+            }
+        }
+    F5i[0] = 0.0;
+    for (int j = 1; j <= L; j++) {
+        double acc = F5i[j - 1];
+        for (int k = 0; k < j; k++)
+            if (PAIR(k + 1, j)) acc = logadd(acc, F5i[k] + FCi[off[k + 1] + j - 1] - e_stem(&c, k + 1, j) * sc);
+        F5i[j] = acc;
+    }
+    const double Z = F5i[L];
+    /* outside, push form */
+    F5o[L] = 0.0;
+    for (int j = L; j >= 1; j--) {
+        F5o[j - 1] = logadd(F5o[j - 1], F5o[j]);
+        for (int k = 0; k < j; k++) {
+            if (!PAIR(k + 1, j)) continue;
+            const double t = F5o[j] - e_stem(&c, k + 1, j) * sc;
+            F5o[k] = logadd(F5o[k], t + FCi[off[k + 1] + j - 1]);
+            FCo[off[k + 1] + j - 1] = logadd(FCo[off[k + 1] + j - 1], t + F5i[k]);
+        }
+    }
+    for (int i = 0; i <= L; i++)
+        for (int j = L; j >= i; j--) {
+            double fm2o = -INFINITY;
+            if (0 < i && i + 2 <= j && j < L) {
+                fm2o = logadd(fm2o, FMo[off[i] + j]);
+                FMSo[off[i] + j] = logadd(FMSo[off[i] + j], FMo[off[i] + j]);
+                FMSo[off[i] + j - 1] = logadd(FMSo[off[i] + j - 1], FMSo[off[i] + j] + mlb);
+                FM1o[off[i] + j] = logadd(FM1o[off[i] + j], FMSo[off[i] + j]);
+                if (PAIR(i + 1, j))
+                    FCo[off[i + 1] + j - 1] = logadd(FCo[off[i + 1] + j - 1], FM1o[off[i] + j] + mli - e_stem(&c, i + 1, j) * sc);
+                FM1o[off[i + 1] + j] = logadd(FM1o[off[i + 1] + j], FM1o[off[i] + j] + mlb);
+            }
+            if (0 < i && j < L && PAIR(i, j + 1)) {
+                const double fco = FCo[off[i] + j];
+                for (int p = i; p <= (i + MAXLOOP < j ? i + MAXLOOP : j); p++) {
+                    int qmin = p + 2 > p - i + j - MAXLOOP ? p + 2 : p - i + j - MAXLOOP;
+                    for (int q = j; q >= qmin; q--) {
+                        if (!PAIR(p + 1, q)) continue;
+                        FCo[off[p + 1] + q - 1] = logadd(FCo[off[p + 1] + q - 1], fco - e_interior(&c, i, j + 1, p + 1, q) * sc);
+                    }
+                }
+                fm2o = logadd(fm2o, fco - e_mlclose(&c, i, j + 1) * sc);
+            }
+            for (int k = i + 1; k < j; k++) {
+                FM1o[off[i] + k] = logadd(FM1o[off[i] + k], fm2o + FMi[off[k] + j]);
+                FMo[off[k] + j] = logadd(FMo[off[k] + j], fm2o + FM1i[off[i] + k]);
+            }
+        }
+    if (post) {
+        for (long k = 0; k < T; k++) post[k] = 0.0;
+        for (int i = 1; i <= L; i++)
+            for (int j = i; j < L; j++)
+                if (PAIR(i, j + 1)) {
+                    const double e = FCo[off[i] + j] + FCi[off[i] + j] - Z;
+                    post[off[i] + j + 1] = e > -INFINITY ? exp(e) : 0.0;
+                }
+    }
+    if (up && max_w > 0) {
+        /* P(letters a..b unpaired) by the loop that holds the run (the H, I, M, E split of pf_unstru):
+         *  E: F5i[a-1] * F5o[b]                                   H: sum_{p<a, q>b} FCo(p,q) * hairpin(p,q)
+         *  I: sum over loops (p,q;k,l) with the run in the left gap (p<a, b<k) or the right gap (l<a, b<q)
+         *  M: leading run of a branch  FM1[a-1,j] -> ... -> FM1[b,j]   : sum_j FM1o[a-1,j] * mlb^len * FM1i[b,j]
+         *     trailing run            FMS[i,b]  -> ... -> FMS[i,a-1]  : sum_i FMSo[i,b]   * mlb^len * FMSi[i,a-1]
+         * probabilities are summed in linear space. */
+        double* Hs = (double*)calloc((size_t)(L + 2) * (L + 2), sizeof(double));   /* Hs[a][b] = sum_{p<a,q>b} */
+        double* GL = (double*)calloc((size_t)(L + 2) * (MAXLOOP + 2), sizeof(double)); /* GL[p][l1]: left gap p+1..p+l1 */
+        double* GR = (double*)calloc((size_t)(L + 2) * (MAXLOOP + 2), sizeof(double)); /* GR[q][l2]: right gap q-l2..q-1 */
+#define HS(a, b) Hs[(size_t)(a) * (L + 2) + (b)]
+        for (int p = 1; p <= L; p++)
+            for (int q = p + 4; q <= L; q++)
+                if (PAIR(p, q)) {
+                    const double e = FCo[off[p] + q - 1] - e_hairpin(&c, p, q) * sc - Z;
+                    if (e > -INFINITY) HS(p + 1, q - 1) += exp(e);   /* counted at its own corner, swept below */
+                    const double fco = FCo[off[p] + q - 1];
+                    if (!(fco > -INFINITY)) continue;
+                    for (int k = p + 1; k <= p + MAXLOOP + 1 && k < q; k++)
+                        for (int l = q - 1; l > k && (k - p - 1) + (q - l - 1) <= MAXLOOP; l--) {
+                            if (!PAIR(k, l)) continue;
+                            const double t = fco - e_interior(&c, p, q, k, l) * sc + FCi[off[k] + l - 1] - Z;
+                            if (!(t > -INFINITY)) continue;
+                            GL[(size_t)p * (MAXLOOP + 2) + (k - p - 1)] += exp(t);
+                            GR[(size_t)q * (MAXLOOP + 2) + (q - l - 1)] += exp(t);
+                        }
+                }
+        /* dominance sums: Hs[a][b] = sum_{p+1<=a, q-1>=b} h(p+1,q-1) */
+        for (int a = 1; a <= L; a++)
+            for (int b = L; b >= 1; b--)
+                HS(a, b) += HS(a - 1, b) + HS(a, b + 1) - HS(a - 1, b + 1);
+        for (int a = 1; a <= L; a++)
+            for (int w = 0; w < max_w; w++) {
+                const int b = a + w, len = w + 1;
+                double pu = 0.0;
+                if (b <= L) {
+                    pu += exp(F5i[a - 1] + F5o[b] - Z);
+                    pu += HS(a, b);
+                    for (int p = a - 1; p >= 1 && p >= b - MAXLOOP; p--)       /* left gaps p+1..p+l1 covering a..b */
+                        for (int l1 = b - p; l1 <= MAXLOOP; l1++) pu += GL[(size_t)p * (MAXLOOP + 2) + l1];
+                    for (int q = b + 1; q <= L && q <= a + MAXLOOP; q++)
+                        for (int l2 = q - a; l2 <= MAXLOOP; l2++) pu += GR[(size_t)q * (MAXLOOP + 2) + l2];
+                    if (a >= 2)
+                        for (int j = b + 2; j < L; j++) {
+                            const double t = FM1o[off[a - 1] + j] + len * mlb + FM1i[off[b] + j] - Z;
+                            if (t > -INFINITY) pu += exp(t);
+                        }
+                    for (int i = 1; i + 2 <= a - 1; i++)
+                        if (b < L) {
+                            const double t = FMSo[off[i] + b] + len * mlb + FMSi[off[i] + a - 1] - Z;
+                            if (t > -INFINITY) pu += exp(t);
+                        }
+                }
+                up[(size_t)(a - 1) * max_w + w] = pu;
+            }
+#undef HS
+        free(Hs); free(GL); free(GR);
+    }
+#undef PAIR
+    if (logz_out) *logz_out = F5o[0];
+    if (tabs) memcpy(tabs, buf, sizeof(double) * 8 * T);
+    if (f5) memcpy(f5, F5i, sizeof(double) * 2 * (L + 1));
+    free(buf); free(off); free(S);
+    return Z;
+}
+
+/* ---- brute force over all secondary structures (hairpins >= 3, every loop decomposed explicitly) */
+typedef struct { mc_t c; int* pt; double Z; double* marg; double* up; int max_w; } sbf_t;
+
+static double loop_logw(const sbf_t* b, int a, int bb)
+{   /* log weight of the loop closed by (a,bb) and of everything nested in it */
+    const mc_t* c = &b->c;
+    int stems = 0, unpaired = 0, sp[64], sq[64];
+    for (int x = a + 1; x < bb;) {
+        if (b->pt[x] > x) { sp[stems] = x; sq[stems] = b->pt[x]; stems++; x = b->pt[x] + 1; }
+        else { unpaired++; x++; }
+    }
+    double lw = 0.0;
+    if (stems == 0) lw = -e_hairpin(c, a, bb) * c->sc;
+    else if (stems == 1) {
+        if (unpaired > MAXLOOP) return -INFINITY;
+        lw = -e_interior(c, a, bb, sp[0], sq[0]) * c->sc;
+    } else {
+        lw = -(e_mlclose(c, a, bb) + c->P->ML_base * unpaired) * c->sc;
+        for (int k = 0; k < stems; k++) lw += -(c->P->ML_intern + e_stem(c, sp[k], sq[k])) * c->sc;
+    }
+    for (int k = 0; k < stems; k++) lw += loop_logw(b, sp[k], sq[k]);
+    return lw;
+}
+static void sbf_finish(sbf_t* b)
+{
+    const int n = b->c.n;
+    double lw = 0.0;
+    for (int x = 1; x <= n;) {
+        if (b->pt[x] > x) { lw += -e_stem(&b->c, x, b->pt[x]) * b->c.sc + loop_logw(b, x, b->pt[x]); x = b->pt[x] + 1; }
+        else x++;
+    }
+    if (lw == -INFINITY) return;
+    const double w = exp(lw);
+    b->Z += w;
+    for (int x = 1; x <= n; x++)
+        if (b->pt[x] > x) b->marg[(long)x * (2 * (n + 1) - x - 1) / 2 + b->pt[x]] += w;
+    if (b->up)
+        for (int a = 1; a <= n; a++)
+            for (int e = a; e <= n && e - a < b->max_w && b->pt[e] < 0; e++) b->up[(size_t)(a - 1) * b->max_w + (e - a)] += w;
+}
+static void sbf_rec(sbf_t* b, int pos)
+{   /* decide position pos: unpaired (-1), or paired with a later free position q; everything strictly between must
+       still be undecided, which keeps the structures non-crossing (only openers left of pos can own a closer there) */
+    const int n = b->c.n;
+    while (pos <= n && b->pt[pos] != 0) pos++;
+    if (pos > n) { sbf_finish(b); return; }
+    b->pt[pos] = -1;
+    sbf_rec(b, pos + 1);
+    for (int q = pos + 4; q <= n; q++) {
+        if (b->pt[q] != 0 || !ptype(b->c.S[pos], b->c.S[q])) continue;
+        int ok = 1;
+        for (int x = pos + 1; x < q && ok; x++) if (b->pt[x] > 0) ok = 0;
+        if (!ok) continue;
+        b->pt[pos] = q; b->pt[q] = pos;
+        sbf_rec(b, pos + 1);
+        b->pt[q] = 0;
+    }
+    b->pt[pos] = 0;
+}
+double vo_fold_bruteforce(const vo_model* P, const char* seq, int n, double* post, double* up, int max_w)
+{
+    int* S = (int*)calloc(n + 3, sizeof(int));
+    for (int i = 1; i <= n; i++) S[i] = vcode(seq[i - 1]);
+    sbf_t b;
+    b.c.P = P; b.c.S = S; b.c.n = n; b.c.sc = 10.0 / P->kT;
+    b.pt = (int*)calloc(n + 2, sizeof(int));
+    b.Z = 0.0;
+    const long T = (long)(n + 1) * (n + 2) / 2;
+    b.marg = (double*)calloc(T, sizeof(double));
+    b.up = up; b.max_w = max_w;
+    if (up) for (long k = 0; k < (long)n * max_w; k++) up[k] = 0.0;
+    sbf_rec(&b, 1);
+    if (post) for (long k = 0; k < T; k++) post[k] = b.marg[k] / b.Z;
+    if (up) for (long k = 0; k < (long)n * max_w; k++) up[k] /= b.Z;
+    const double z = log(b.Z);
+    free(b.marg); free(b.pt); free(S);
     return z;
 }

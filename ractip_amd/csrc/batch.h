@@ -35,6 +35,8 @@ enum McTable {
     T_COUNT
 };
 
+constexpr int kViennaMcTables = 15;   // VmTable of mccaskill_vienna.hip (own enum, same square layout)
+
 struct McBatch {
     const uint8_t* seq;  // [NS][lds] nucleotide codes, seq[0] = seq[n+1] = 4
     const int* n;        // [NS]
@@ -42,7 +44,7 @@ struct McBatch {
     double* f5i;         // [NS][ld]  F5i[0..n]
     double* f5o;         // [NS][ld]  F5o[0..n]
     double* bp;          // [NS][tri_stride] posterior, reference triangular layout
-    double* up;          // [NS][ld]  width-1 unpaired probability, 0-based
+    double* up;          // [NS][ld*max_w]  up[i*max_w+w] = P(letters i+1..i+1+w unpaired); max_w = 1 for the CONTRAfold model
     int ns, nmax, ld, lds;
     size_t tab_stride;   // doubles per table  (ld*ld)
     size_t seq_stride;   // doubles per sequence (T_COUNT*ld*ld)

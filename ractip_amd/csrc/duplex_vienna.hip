@@ -16,18 +16,6 @@ namespace rh {
 enum DxvTable { V_IN = 0, V_INMM, V_INTAU, V_OUT, V_OUTMM, V_OUTTAU, V_COUNT };
 
 namespace {
-// LoopEnergy for the explicit shapes: type = pair type of the upstream pair (k,l), type_2 = rtype of the downstream
-// pair (i,j); si1 = S1[k+1], sj1 = S2[l-1], sp1 = S1[i-1], sq1 = S2[j+1]
-__device__ __forceinline__ double small_loop(const ViennaDx* V, int l1, int l2, int t1, int t2, int si1, int sj1, int sp1, int sq1)
-{
-    const int tt = t1 * 8 + t2;
-    if (l1 == 0 && l2 == 0) return V->stack[tt];
-    if (l1 + l2 == 1) return V->bulge1[tt];
-    if (l1 == 1 && l2 == 1) return V->int11[tt * 25 + si1 * 5 + sj1];
-    if (l1 == 1 && l2 == 2) return V->int21[tt * 125 + (si1 * 5 + sq1) * 5 + sj1];
-    if (l1 == 2 && l2 == 1) return V->int21[(t2 * 8 + t1) * 125 + (sq1 * 5 + si1) * 5 + sp1];
-    return V->int22[tt * 625 + ((si1 * 5 + sp1) * 5 + sq1) * 5 + sj1];
-}
 __device__ __forceinline__ bool diag_cell_v(int w, int s0, int L1, int L2, int* i, int* j)
 {
 #pragma unroll
@@ -89,7 +77,7 @@ __global__ __launch_bounds__(256) void dxv_sweep_diag(DxBatch B, const ViennaDx*
                 else if (kind == 2) xs[u] = tab[V_INTAU * ts + kl] + sh.score + tau_here;
                 else {
                     const int t2 = V->ptype[s1[k] * 5 + s2[l]];
-                    if (t2) xs[u] = tab[V_IN * ts + kl] + small_loop(V, sh.l1, sh.l2, t2, rt, s1[k + 1], s2[l - 1], xm, yp);
+                    if (t2) xs[u] = tab[V_IN * ts + kl] + vienna_small_loop(V, sh.l1, sh.l2, t2, rt, s1[k + 1], s2[l - 1], xm, yp);
                 }
             }
         }
@@ -112,7 +100,7 @@ __global__ __launch_bounds__(256) void dxv_sweep_diag(DxBatch B, const ViennaDx*
                 else if (kind == 2) xs[u] = tab[V_OUTTAU * ts + kl] + sh.score + tau_here;
                 else {
                     const int t2 = V->ptype[s1[ii] * 5 + s2[jj]];
-                    if (t2) xs[u] = tab[V_OUT * ts + kl] + small_loop(V, sh.l1, sh.l2, type, V->rtype[t2], xp, ym, s1[ii - 1], s2[jj + 1]);
+                    if (t2) xs[u] = tab[V_OUT * ts + kl] + vienna_small_loop(V, sh.l1, sh.l2, type, V->rtype[t2], xp, ym, s1[ii - 1], s2[jj + 1]);
                 }
             }
         }

@@ -45,6 +45,14 @@ __global__ void dxl_posterior(DxLinBatch B, const double* __restrict__ zbar, int
 __global__ void dxv_sweep_diag(DxBatch B, const ViennaDx* __restrict__ V, int t);
 __global__ void dxv_logz(DxBatch B, const ViennaDx* __restrict__ V);
 __global__ void dxv_posterior(DxBatch B);
+__global__ void mcv_init(McBatch B);
+__global__ void mcv_inside_diag(McBatch B, const ViennaDx* __restrict__ V, int d, int pin);
+__global__ void mcv_outside_diag(McBatch B, const ViennaDx* __restrict__ V, int d, int pin);
+__global__ void mcv_acc_prep(McBatch B, const ViennaDx* __restrict__ V);
+__global__ void mcv_acc_hscan(McBatch B);
+__global__ void mcv_acc_gaps(McBatch B, const ViennaDx* __restrict__ V, double* __restrict__ gaps);
+__global__ void mcv_acc_final(McBatch B, const ViennaDx* __restrict__ V, const double* __restrict__ gaps, int max_w);
+__global__ void mcv_finish(McBatch B, double* __restrict__ logz);
 }  // namespace rh
 
 using namespace rh;
@@ -79,6 +87,7 @@ struct RowSpan {
     int i, j0, j1;
     bool ok;
 };
+// kind 2 (up): n2 = max_w, the row is the whole n x max_w matrix, entry j = position*max_w + width index
 __device__ __forceinline__ RowSpan cand_row(const double* base, int kind, int n, int n2, int ld, int row)
 {
     RowSpan r;
@@ -91,7 +100,7 @@ __device__ __forceinline__ RowSpan cand_row(const double* base, int kind, int n,
         r.p = base + (size_t)r.i * (size_t)ld;
         r.ok = r.i <= n;
     } else {
-        r.i = 0; r.j0 = 0; r.j1 = n - 1; r.p = base;
+        r.i = 0; r.j0 = 0; r.j1 = n * n2 - 1; r.p = base;
         r.ok = row == 0;
     }
     return r;
@@ -125,8 +134,8 @@ __global__ __launch_bounds__(256) void cand_write(const double* __restrict__ bas
             const int k = pos + __popcll(m & ((1ull << lane) - 1ull));
             if (k < cap) {
                 rh_cand e;
-                e.i = kind == 2 ? j : r.i;
-                e.j = kind == 2 ? 0 : j;
+                e.i = kind == 2 ? j / n2 : r.i;
+                e.j = kind == 2 ? j % n2 : j;
                 e.p = pf;
                 out[k] = e;
             }
@@ -151,7 +160,7 @@ __device__ __forceinline__ RowSpan cand_row_all(const double* bp, const double* 
     }
     if (which == 2) return cand_row(hp + (size_t)p * hp_stride, 1, nn[2 * p], nn[2 * p + 1], hp_ld, r);
     const int sq = 2 * p + (which - 3);
-    return cand_row(up + (size_t)sq * up_ld, 2, nn[sq], 0, 0, r);
+    return cand_row(up + (size_t)sq * up_ld, 2, nn[sq], hp_ld /* = max_w for the up scans */, 0, r);
 }
 __global__ __launch_bounds__(256) void cand_count_all(const double* __restrict__ bp, const double* __restrict__ hp, const double* __restrict__ up,
                                                       const int* __restrict__ nn, size_t tri_stride, size_t hp_stride, int up_ld, int hp_ld,
@@ -185,8 +194,8 @@ __global__ __launch_bounds__(256) void cand_write_all(const double* __restrict__
             const int k = pos + __popcll(m & ((1ull << lane) - 1ull));
             if (k < cap) {
                 rh_cand e;
-                e.i = which >= 3 ? j : rs.i;
-                e.j = which >= 3 ? 0 : j;
+                e.i = which >= 3 ? j / hp_ld : rs.i;
+                e.j = which >= 3 ? j % hp_ld : j;
                 e.p = pf;
                 out[k] = e;
             }
@@ -226,6 +235,7 @@ struct rh_ctx {
     int lin_w = 8;                 // wavefronts per 64-cell group of the linear kernels
     int lin_bs = 16;               // block size of the far/near split of the O(n^3) terms (0 = off)
     int last_path = 0;             // 1 = linear, 2 = log-space, 3 = linear then log-space fallback
+    int max_w = 1;                 // accessibility widths 1..max_w (src/ractip.cpp:370-375); the CONTRAfold path has width 1 only
 
     // current batch (host mirror)
     int np = 0, ns = 0;
@@ -250,6 +260,7 @@ struct rh_ctx {
     void* d_dxbad = nullptr; size_t cap_dxbad = 0;
     void* d_zbar = nullptr;  size_t cap_zbar = 0;
     void* d_cand = nullptr;  size_t cap_cand = 0;
+    void* d_gaps = nullptr;  size_t cap_gaps = 0;
     double ms[4] = {0, 0, 0, 0};
     int n_launch[3] = {0, 0, 0};
 };
@@ -360,11 +371,12 @@ int stage(rh_ctx* c, int ns, const char* const* seqs, const int* lens, bool with
         B.ns = ns; B.nmax = nmax; B.lds = lds;
         B.ld = (nmax + 2 + 1) & ~1;
         B.tab_stride = (size_t)B.ld * B.ld;
-        B.seq_stride = B.tab_stride * T_COUNT;
+        B.seq_stride = B.tab_stride * (vienna ? (int)kViennaMcTables : (int)T_COUNT);
         B.tri_stride = (tri_size(nmax) + 1) & ~(size_t)1;
         if ((rc = ensure(c, &c->d_mctab, &c->cap_mctab, sizeof(double) * B.seq_stride * ns, false))) return rc;
         if ((rc = ensure(c, &c->d_f5, &c->cap_f5, sizeof(double) * 2 * B.ld * ns, false))) return rc;
-        if ((rc = ensure(c, &c->d_up, &c->cap_up, sizeof(double) * B.ld * ns, false))) return rc;
+        if ((rc = ensure(c, &c->d_up, &c->cap_up, sizeof(double) * B.ld * c->max_w * ns, false))) return rc;
+        if (vienna && (rc = ensure(c, &c->d_gaps, &c->cap_gaps, sizeof(double) * 2 * 32 * B.ld * ns, false))) return rc;
         if ((rc = ensure(c, &c->d_mclogz, &c->cap_mclogz, sizeof(double) * ns, false))) return rc;
         if ((rc = ensure(c, &c->d_bad, &c->cap_bad, sizeof(int) * ns, false))) return rc;
         // bp entries outside 1<=i<j<=n are never written by the sweep: keep them zero
@@ -431,6 +443,35 @@ int launch_mc_log(rh_ctx* c, int pin)
     }
     hipLaunchKernelGGL(log_finish, dim3((B.ns + 63) / 64), dim3(64), 0, c->s_mc, B, (double*)c->d_mclogz);
     hipLaunchKernelGGL(mc_unpaired, dim3((B.nmax + 3) / 4, B.ns), dim3(256), 0, c->s_mc, B);
+    return RH_OK;
+}
+
+// ---- McCaskill sweeps + accessibility, Vienna-BL model (log space; mccaskill_vienna.hip)
+int launch_mc_vienna(rh_ctx* c, int pin)
+{
+    const McBatch& B = c->mc;
+    hipLaunchKernelGGL(mcv_init, dim3((B.ns + 63) / 64), dim3(64), 0, c->s_mc, B);
+    for (int d = 0; d <= B.nmax - 1; d++) {
+        const int waves = std::max(B.nmax - 1 - d, 0) + 1;
+        hipLaunchKernelGGL(mcv_inside_diag, pin ? dim3(B.ns, (waves + 3) / 4) : dim3((waves + 3) / 4, B.ns), dim3(256), 0,
+                           c->s_mc, B, c->d_vienna, d, pin);
+        c->n_launch[0]++;
+    }
+    HIP_TRY(c, hipEventRecord(c->ev[1], c->s_mc));
+    for (int d = B.nmax - 2; d >= 0; d--) {
+        const int waves = (B.nmax - 1 - d) + 1;
+        hipLaunchKernelGGL(mcv_outside_diag, pin ? dim3(B.ns, (waves + 3) / 4) : dim3((waves + 3) / 4, B.ns), dim3(256), 0,
+                           c->s_mc, B, c->d_vienna, d, pin);
+        c->n_launch[1]++;
+    }
+    hipLaunchKernelGGL(mcv_finish, dim3((B.ns + 63) / 64), dim3(64), 0, c->s_mc, B, (double*)c->d_mclogz);
+    // accessibility P(i..i+w unpaired), w < max_w, from the finished tables
+    const int tiles = (B.ld + 31) / 32;
+    hipLaunchKernelGGL(mcv_acc_prep, dim3(tiles * tiles, B.ns, 3), dim3(256), 0, c->s_mc, B, c->d_vienna);
+    hipLaunchKernelGGL(mcv_acc_hscan, dim3((B.nmax + 1 + 255) / 256, B.ns), dim3(256), 0, c->s_mc, B);
+    hipLaunchKernelGGL(mcv_acc_gaps, dim3((B.nmax * 30 + 3) / 4, B.ns, 2), dim3(256), 0, c->s_mc, B, c->d_vienna, (double*)c->d_gaps);
+    hipLaunchKernelGGL(mcv_acc_final, dim3((B.nmax + 3) / 4, B.ns), dim3(256), 0, c->s_mc, B, c->d_vienna, (const double*)c->d_gaps, c->max_w);
+    c->n_launch[1] += 4;
     return RH_OK;
 }
 
@@ -643,8 +684,11 @@ int compute(rh_ctx* c)
     HIP_TRY(c, hipEventRecord(c->ev[4], c->s_dx));
 
     HIP_TRY(c, hipEventRecord(c->ev[0], c->s_mc));
-    bool need_log = c->has_mc && c->mode == RH_MODE_LOG && !skip_mc;
-    if (c->has_mc && c->mode != RH_MODE_LOG && !skip_mc) {
+    bool need_log = c->has_mc && c->mode == RH_MODE_LOG && !skip_mc && c->model != RH_MODEL_VIENNA_BL;
+    if (c->has_mc && c->model == RH_MODEL_VIENNA_BL && !skip_mc) {
+        if ((rc = launch_mc_vienna(c, pin))) return rc;
+        c->last_path = 2;
+    } else if (c->has_mc && c->mode != RH_MODE_LOG && !skip_mc) {
         if ((rc = run_graphed(c, c->g_in, shape_key(c, 0), c->s_mc, &c->n_launch[0], [&] { return launch_mc_lin_any(c, pin, 0); }))) return rc;
         HIP_TRY(c, hipEventRecord(c->ev[1], c->s_mc));
         if ((rc = run_graphed(c, c->g_out, shape_key(c, 1), c->s_mc, &c->n_launch[1], [&] { return launch_mc_lin_any(c, pin, 1); }))) return rc;
@@ -707,7 +751,8 @@ int fetch_bp(rh_ctx* c, int sq, double* out)
 }
 int fetch_up(rh_ctx* c, int sq, double* out)
 {
-    HIP_TRY(c, hipMemcpy(out, (const double*)c->d_up + (size_t)sq * c->mc.ld, sizeof(double) * c->n[sq], hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(out, (const double*)c->d_up + (size_t)sq * c->mc.ld * c->max_w, sizeof(double) * c->n[sq] * c->max_w,
+                         hipMemcpyDeviceToHost));
     return RH_OK;
 }
 int fetch_logz(rh_ctx* c, int sq, double* out)
@@ -767,6 +812,7 @@ rh_ctx* rh_create(int device, int model, const char* param_file)
     }
     rh_ctx* c = new rh_ctx;
     c->device = device; c->model = model;
+    c->max_w = model == RH_MODEL_VIENNA_BL ? 15 : 1;   // RactIP's default --max-w (src/cmdline.c:151-186) / contrafold's width 1
     // scale exponent of the linear fast path: log Z per nucleotide of typical sequences under this model
     // (random ACGU: 0.107..0.129 for n = 200..2000); deviations only cost dynamic range, never accuracy
     build_lin_model(host_model, 0.12, &c->h_lin);
@@ -802,7 +848,7 @@ void rh_destroy(rh_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    void* bufs[] = {c->d_seq, c->d_n, c->d_mctab, c->d_f5, c->d_bp, c->d_up, c->d_dxtab, c->d_hp, c->d_logz, c->d_scal, c->d_mclogz, c->d_bad, c->d_cnt, c->d_cand, c->d_dxbad, c->d_zbar, c->d_model, c->d_lin, c->d_dxlin, c->d_vienna};
+    void* bufs[] = {c->d_seq, c->d_n, c->d_mctab, c->d_f5, c->d_bp, c->d_up, c->d_dxtab, c->d_hp, c->d_logz, c->d_scal, c->d_mclogz, c->d_bad, c->d_cnt, c->d_cand, c->d_dxbad, c->d_zbar, c->d_gaps, c->d_model, c->d_lin, c->d_dxlin, c->d_vienna};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (GraphSlot* g : {&c->g_in, &c->g_out, &c->g_dx}) if (g->exec) (void)hipGraphExecDestroy(g->exec);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -816,8 +862,6 @@ const char* rh_last_error(const rh_ctx* c) { return c ? c->err.c_str() : g_creat
 int rh_bpp(rh_ctx* c, const char* seq, int n, const char* constraint, double* bp_tri, double* logZ)
 {
     if (!c) return RH_ERR_ARG;
-    if (c->model != RH_MODEL_CONTRAFOLD)
-        return fail(c, RH_ERR_UNSUPPORTED, "the Vienna-BL model currently provides rh_duplex only (pf_fold / pf_unstru equivalents: SURVEY 8f-1)");
     if (constraint) return fail(c, RH_ERR_UNSUPPORTED, "structure constraints are not supported yet");
     if (!seq || n < 0) return fail(c, RH_ERR_ARG, "bad sequence");
     if (n == 0) { if (bp_tri) bp_tri[0] = 0.0; if (logZ) *logZ = 0.0; return RH_OK; }
@@ -832,12 +876,10 @@ int rh_bpp(rh_ctx* c, const char* seq, int n, const char* constraint, double* bp
 int rh_unpaired(rh_ctx* c, const char* seq, int n, int max_w, double* up)
 {
     if (!c) return RH_ERR_ARG;
-    if (c->model != RH_MODEL_CONTRAFOLD)
-        return fail(c, RH_ERR_UNSUPPORTED, "the Vienna-BL model currently provides rh_duplex only (pf_fold / pf_unstru equivalents: SURVEY 8f-1)");
-    if (max_w != 1) return fail(c, RH_ERR_UNSUPPORTED, "max_w=%d: only width-1 accessibility (CONTRAfold path) is built", max_w);
     if (!seq || n < 0 || !up) return fail(c, RH_ERR_ARG, "bad argument");
     if (n == 0) return RH_OK;
     int rc;
+    if ((rc = rh_set_max_w(c, max_w))) return rc;
     if ((rc = stage(c, 1, &seq, &n, true, false))) return rc;
     if ((rc = compute(c))) return rc;
     return fetch_up(c, 0, up);
@@ -846,8 +888,6 @@ int rh_unpaired(rh_ctx* c, const char* seq, int n, int max_w, double* up)
 int rh_fold(rh_ctx* c, const char* seq, int n, double* bp_tri, double* up, double* logZ)
 {
     if (!c) return RH_ERR_ARG;
-    if (c->model != RH_MODEL_CONTRAFOLD)
-        return fail(c, RH_ERR_UNSUPPORTED, "the Vienna-BL model currently provides rh_duplex only (pf_fold / pf_unstru equivalents: SURVEY 8f-1)");
     if (!seq || n < 0) return fail(c, RH_ERR_ARG, "bad sequence");
     if (n == 0) { if (bp_tri) bp_tri[0] = 0.0; if (logZ) *logZ = 0.0; return RH_OK; }
     int rc;
@@ -874,8 +914,6 @@ int rh_duplex(rh_ctx* c, const char* s1, int n1, const char* s2, int n2, double*
 int rh_batch_upload(rh_ctx* c, int npairs, const char* const* s1, const int* n1, const char* const* s2, const int* n2)
 {
     if (!c) return RH_ERR_ARG;
-    if (c->model != RH_MODEL_CONTRAFOLD)
-        return fail(c, RH_ERR_UNSUPPORTED, "the Vienna-BL model currently provides rh_duplex only (pf_fold / pf_unstru equivalents: SURVEY 8f-1)");
     if (npairs < 1 || !s1 || !s2 || !n1 || !n2) return fail(c, RH_ERR_ARG, "bad batch");
     std::vector<const char*> seqs(2 * (size_t)npairs);
     std::vector<int> lens(2 * (size_t)npairs);
@@ -940,7 +978,7 @@ int rh_batch_candidates(rh_ctx* c, int p, int which, float threshold, rh_cand* o
         nrows = c->n[2 * p];
     } else {
         const int sq = 2 * p + (which - 3);
-        v = CandView{(const double*)c->d_up + (size_t)sq * c->mc.ld, 2, c->n[sq], 0, 0};
+        v = CandView{(const double*)c->d_up + (size_t)sq * c->mc.ld * c->max_w, 2, c->n[sq], c->max_w, 0};
         nrows = 1;
     }
     int rc;
@@ -980,7 +1018,7 @@ int rh_batch_candidates_all(rh_ctx* c, int which, float threshold, rh_cand* out,
     int* d_offsets = d_counts + (nrows + 1);
     const dim3 grid((rmax + 3) / 4, np);
     hipLaunchKernelGGL(cand_count_all, grid, dim3(256), 0, c->s_mc, (const double*)c->d_bp, (const double*)c->d_hp, (const double*)c->d_up,
-                       (const int*)c->d_n, c->mc.tri_stride, c->dx.tab_stride, c->mc.ld, c->dx.ldd, which, rmax, threshold, d_counts);
+                       (const int*)c->d_n, c->mc.tri_stride, c->dx.tab_stride, c->mc.ld * c->max_w, which >= 3 ? c->max_w : c->dx.ldd, which, rmax, threshold, d_counts);
     std::vector<int> counts(nrows), offsets(nrows);
     HIP_TRY(c, hipMemcpyAsync(counts.data(), d_counts, sizeof(int) * nrows, hipMemcpyDeviceToHost, c->s_mc));
     HIP_TRY(c, hipStreamSynchronize(c->s_mc));
@@ -995,7 +1033,7 @@ int rh_batch_candidates_all(rh_ctx* c, int which, float threshold, rh_cand* out,
         if ((rc = ensure(c, &c->d_cand, &c->cap_cand, sizeof(rh_cand) * (size_t)take, false))) return rc;
         HIP_TRY(c, hipMemcpyAsync(d_offsets, offsets.data(), sizeof(int) * nrows, hipMemcpyHostToDevice, c->s_mc));
         hipLaunchKernelGGL(cand_write_all, grid, dim3(256), 0, c->s_mc, (const double*)c->d_bp, (const double*)c->d_hp, (const double*)c->d_up,
-                           (const int*)c->d_n, c->mc.tri_stride, c->dx.tab_stride, c->mc.ld, c->dx.ldd, which, rmax, threshold, d_offsets,
+                           (const int*)c->d_n, c->mc.tri_stride, c->dx.tab_stride, c->mc.ld * c->max_w, which >= 3 ? c->max_w : c->dx.ldd, which, rmax, threshold, d_offsets,
                            (rh_cand*)c->d_cand, take);
         HIP_TRY(c, hipMemcpyAsync(out, c->d_cand, sizeof(rh_cand) * (size_t)take, hipMemcpyDeviceToHost, c->s_mc));
         HIP_TRY(c, hipStreamSynchronize(c->s_mc));
@@ -1008,7 +1046,7 @@ int rh_batch_layout(rh_ctx* c, size_t* tri_stride, int* up_ld, size_t* hp_stride
     if (!c) return RH_ERR_ARG;
     if (!c->has_mc || !c->has_dx) return fail(c, RH_ERR_ARG, "no pair batch");
     if (tri_stride) *tri_stride = c->mc.tri_stride;
-    if (up_ld) *up_ld = c->mc.ld;
+    if (up_ld) *up_ld = c->mc.ld * c->max_w;
     if (hp_stride) *hp_stride = c->dx.tab_stride;
     if (hp_ld) *hp_ld = c->dx.ldd;
     return RH_OK;
@@ -1020,12 +1058,23 @@ int rh_batch_results_all(rh_ctx* c, double* bp, double* up, double* hp, double* 
     if (!c->computed || !c->has_mc || !c->has_dx) return fail(c, RH_ERR_ARG, "no computed pair batch");
     HIP_TRY(c, hipSetDevice(c->device));
     if (bp) HIP_TRY(c, hipMemcpyAsync(bp, c->d_bp, sizeof(double) * c->mc.tri_stride * c->ns, hipMemcpyDeviceToHost, c->s_mc));
-    if (up) HIP_TRY(c, hipMemcpyAsync(up, c->d_up, sizeof(double) * c->mc.ld * c->ns, hipMemcpyDeviceToHost, c->s_mc));
+    if (up) HIP_TRY(c, hipMemcpyAsync(up, c->d_up, sizeof(double) * c->mc.ld * c->max_w * c->ns, hipMemcpyDeviceToHost, c->s_mc));
     if (hp) HIP_TRY(c, hipMemcpyAsync(hp, c->d_hp, sizeof(double) * c->dx.tab_stride * c->np, hipMemcpyDeviceToHost, c->s_mc));
     HIP_TRY(c, hipStreamSynchronize(c->s_mc));
     if (logz) return rh_batch_logz(c, logz);
     return RH_OK;
 }
+
+int rh_set_max_w(rh_ctx* c, int max_w)
+{
+    if (!c) return RH_ERR_ARG;
+    if (max_w < 1 || max_w > 64) return fail(c, RH_ERR_ARG, "max_w=%d out of range [1,64]", max_w);
+    if (c->model == RH_MODEL_CONTRAFOLD && max_w != 1)
+        return fail(c, RH_ERR_UNSUPPORTED, "max_w=%d: the CONTRAfold path has width-1 accessibility only (src/ractip.cpp:213-222)", max_w);
+    if (max_w != c->max_w) { c->max_w = max_w; c->computed = false; c->ns = 0; }   // buffers are sized at upload
+    return RH_OK;
+}
+int rh_get_max_w(const rh_ctx* c) { return c ? c->max_w : RH_ERR_ARG; }
 
 int rh_set_mode(rh_ctx* c, int mode)
 {

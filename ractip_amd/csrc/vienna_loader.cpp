@@ -20,6 +20,7 @@ bool load_vienna_dx(const char* path, ViennaDx* V, char* err, int errlen)
     std::ifstream f(path);
     if (!f) { snprintf(err, errlen, "cannot open parameter file %s", path); return false; }
     std::map<std::string, std::vector<int>> tab;
+    std::vector<std::pair<std::string, int>> tetra;
     std::string line;
     while (std::getline(f, line)) {
         if (line.empty() || line[0] == '#') continue;
@@ -27,6 +28,15 @@ bool load_vienna_dx(const char* path, ViennaDx* V, char* err, int errlen)
         std::string name;
         int count = 0;
         if (!(hs >> name >> count) || count <= 0) { snprintf(err, errlen, "bad header '%s' in %s", line.c_str(), path); return false; }
+        if (name == "tetraloops") {   // `count` lines "CGAAAG -160": closing pair + 4 loop letters, bonus energy
+            for (int k = 0; k < count; k++) {
+                std::string sq; int e;
+                if (!(f >> sq >> e) || sq.size() != 6) { snprintf(err, errlen, "tetraloop list truncated in %s", path); return false; }
+                tetra.emplace_back(sq, e);
+            }
+            std::getline(f, line);
+            continue;
+        }
         std::vector<int>& v = tab[name];
         v.resize(count);
         for (int k = 0; k < count; k++)
@@ -34,7 +44,8 @@ bool load_vienna_dx(const char* path, ViennaDx* V, char* err, int errlen)
         std::getline(f, line);  // rest of the last value line
     }
     const struct { const char* name; size_t n; } need[] = {{"stack37", 49}, {"mismatchI37", 175}, {"dangle5_37", 40}, {"dangle3_37", 40},
-        {"int11_37", 1225}, {"int21_37", 6125}, {"int22_37", 12544}, {"bulge37", 31}, {"internal_loop37", 31}, {"MLparams", 4}, {"ninio", 2}};
+        {"int11_37", 1225}, {"int21_37", 6125}, {"int22_37", 12544}, {"bulge37", 31}, {"internal_loop37", 31}, {"MLparams", 4}, {"ninio", 2},
+        {"hairpin37", 31}, {"mismatchH37", 175}};
     for (auto& t : need)
         if (tab[t.name].size() != t.n) { snprintf(err, errlen, "table %s missing or of wrong size in %s", t.name, path); return false; }
 
@@ -87,6 +98,42 @@ bool load_vienna_dx(const char* path, ViennaDx* V, char* err, int errlen)
     for (int a = 0; a < 5; a++) for (int b = 0; b < 5; b++) V->ptype[a * 5 + b] = T[a][b];
     const int R[8] = {0, 2, 1, 4, 3, 6, 5, 7};
     for (int t = 0; t < 8; t++) V->rtype[t] = R[t];
+
+    // ---- McCaskill part (part_func.c of ViennaRNA 1.8: scale_pf_params / expHairpinEnergy / the qm, qqm, q recurrences)
+    const std::vector<int>&hp = tab["hairpin37"], &mmH = tab["mismatchH37"], &ml = tab["MLparams"];
+    p = 0;
+    for (int i = 1; i <= 7; i++) for (int a = 0; a < 5; a++) for (int b = 0; b < 5; b++) V->mmH[i * 25 + a * 5 + b] = w(mmH[p++]);
+    for (int u = 0; u <= 30; u++) V->hairpin[u] = w(hp[u]);
+    V->hairpin30 = w(hp[30]);
+    V->lxc = 107.856 * 10.0 / kT;   // lxc37 (ViennaRNA constant, not overridden by BL*)
+    for (auto& t : tetra) {
+        int code = 0;
+        bool ok = true;
+        for (char ch : t.first) {
+            const char* q = std::strchr("ACGU", ch);
+            if (!q) { ok = false; break; }
+            code = code * 4 + (int)(q - "ACGU");
+        }
+        if (ok) V->tetra[code] = w(t.second);
+    }
+    // stems of exterior / multi loops: dangles on both sides whenever the neighbour exists, not clipped but smoothed
+    // (SMOOTH of part_func.c), TerminalAU folded into the 3' dangle; nucleotide code 0 = no neighbour
+    auto smooth = [](double X) {
+        const double x = X / 10.0;
+        if (x < -1.2283697) return 0.0;
+        if (x > 0.8660254) return X;
+        const double t = std::sin(x - 0.34242663) + 1.0;
+        return 10.0 * 0.38490018 * t * t;
+    };
+    p = 0;
+    for (int i = 0; i <= 7; i++) for (int a = 0; a < 5; a++, p++) {
+        const double tau_e = i > 2 ? (double)tau : 0.0;
+        V->d5x[i * 5 + a] = a ? smooth(-(double)d5[p]) * 10.0 / kT : 0.0;
+        V->d3x[i * 5 + a] = (a ? smooth(-(double)d3[p]) * 10.0 / kT : 0.0) - tau_e * 10.0 / kT;
+    }
+    V->ml_close = w(ml[1] + ml[2]);
+    V->mli = w(ml[2]);
+    V->mlb = w(ml[0]);
     return true;
 }
 

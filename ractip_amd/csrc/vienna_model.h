@@ -6,6 +6,7 @@
 // unversioned, and the reference holds no output for this path, so results are validated by invariants and by
 // brute-force enumeration only.  All entries are log Boltzmann weights  -E*10/kT  (E in 10 cal/mol).
 #pragma once
+#include <hip/hip_runtime.h>
 #include "score_model.h"
 
 namespace rh {
@@ -25,7 +26,29 @@ struct ViennaDx {
     int kind[kMcShapes];     // 0 = explicit small loop, 1 = generic interior loop, 2 = bulge of length >= 2
     int ptype[25];           // pair type of two nucleotide codes (A,C,G,U = 1..4, other 0): CG=1 GC=2 GU=3 UG=4 AU=5 UA=6
     int rtype[8];
+    // ---- McCaskill part: pf_fold semantics of ViennaRNA-1.8 part_func.c (what src/ractip.cpp:288-304, 351-375 calls)
+    double mmH[8 * 25];      // mismatchH[t][a][b]
+    double hairpin[32];      // hairpin[u], u <= 30
+    double hairpin30, lxc;   // u > 30: hairpin30 - lxc*log(u/30)   (lxc already scaled by 10/kT)
+    double tetra[4096];      // tetraloop bonus by 6-letter code (closing pair + 4 loop letters, base 4), 0 elsewhere
+    double d5x[8 * 5], d3x[8 * 5];   // smoothed stem dangles; TerminalAU folded into d3x, code 0 = no neighbour
+    double ml_close;         // -(ML_closing + ML_intern)
+    double mli, mlb;         // -ML_intern, -ML_base
 };
+
+// LoopEnergy for the seven shapes with joint tables (stack, 1-bulges, int11, int21, int22): type = pair type of the
+// pair that closes the loop seen from outside, type_2 = rtype of the other pair; si1/sj1 = the unpaired letters next
+// to the first pair inside the loop (5' side / 3' side), sp1/sq1 = those next to the second pair
+__host__ __device__ inline double vienna_small_loop(const ViennaDx* V, int l1, int l2, int t1, int t2, int si1, int sj1, int sp1, int sq1)
+{
+    const int tt = t1 * 8 + t2;
+    if (l1 == 0 && l2 == 0) return V->stack[tt];
+    if (l1 + l2 == 1) return V->bulge1[tt];
+    if (l1 == 1 && l2 == 1) return V->int11[tt * 25 + si1 * 5 + sj1];
+    if (l1 == 1 && l2 == 2) return V->int21[tt * 125 + (si1 * 5 + sq1) * 5 + sj1];
+    if (l1 == 2 && l2 == 1) return V->int21[(t2 * 8 + t1) * 125 + (sq1 * 5 + si1) * 5 + sp1];
+    return V->int22[tt * 625 + ((si1 * 5 + sp1) * 5 + sq1) * 5 + sj1];
+}
 
 bool load_vienna_dx(const char* path, ViennaDx* out, char* err, int errlen);
 

@@ -1,7 +1,7 @@
 // prob_cli.cpp -- drives the C++ adapters exactly as RactIP::solve does
 // (/root/reference/src/ractip.cpp:536-548) and prints the float matrices it would
 // hand to the ILP, one value per line, for tests/test_gpu_host_adapter.py.
-//   prob_cli contrafold SEQ | contraduplex S1 S2 TH | rnaduplex S1 S2 | pfduplex S1 S2 | solve S1 S2 [S1 S2 ...]
+//   prob_cli contrafold SEQ | rnafold SEQ MAX_W | contraduplex S1 S2 TH | rnaduplex S1 S2 | pfduplex S1 S2 | solve S1 S2 [S1 S2 ...]
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -52,6 +52,16 @@ int main(int argc, char** argv)
             VF bp; VI off; VVF up;
             en.contrafold(argv[2], bp, off, up);
             dump_bp(bp, off, up);
+        } else if (mode == "rnafold") {   // rnafold SEQ MAX_W
+            VF bp; VI off; VVF up;
+            const unsigned mw = argc > 3 ? (unsigned)std::atoi(argv[3]) : 1u;
+            en.rnafold(argv[2], bp, off, up, mw);
+            std::printf("offset %zu\n", off.size());
+            for (int o : off) std::printf("%d\n", o);
+            std::printf("bp %zu\n", bp.size());
+            for (float v : bp) std::printf("%.9g\n", v);
+            std::printf("up %zu\n", up.size() * mw);
+            for (const VF& r : up) for (float v : r) std::printf("%.9g\n", v);
         } else if (mode == "contraduplex") {
             VVF hp; en.contraduplex(argv[2], argv[3], hp); dump_hp(hp);
         } else if (mode == "rnaduplex") {

@@ -15,12 +15,21 @@ VI make_offsets(uint L)
 }
 
 ProbabilityEngine::ProbabilityEngine(int device, float th_hy, const char* param_file)
-    : ctx_(rh_create(device, RH_MODEL_CONTRAFOLD, param_file)), th_hy_(th_hy)
+    : ctx_(rh_create(device, RH_MODEL_CONTRAFOLD, param_file)), device_(device), th_hy_(th_hy)
 {
     if (!ctx_) throw std::logic_error(std::string("ractip_amd: ") + rh_last_error(nullptr));
 }
 
-ProbabilityEngine::~ProbabilityEngine() { rh_destroy(ctx_); }
+ProbabilityEngine::~ProbabilityEngine() { rh_destroy(ctx_); rh_destroy(vctx_); }
+
+rh_ctx* ProbabilityEngine::vienna() const
+{
+    if (!vctx_) {
+        vctx_ = rh_create(device_, RH_MODEL_VIENNA_BL, nullptr);
+        if (!vctx_) throw std::logic_error(std::string("ractip_amd: ") + rh_last_error(nullptr));
+    }
+    return vctx_;
+}
 
 void ProbabilityEngine::raise(const char* where) const
 {
@@ -49,6 +58,31 @@ void ProbabilityEngine::contrafold(const std::string& seq, VF& bp, VI& offset, V
     if (L > 0 && rh_fold(ctx_, seq.c_str(), (int)L, dbp.data(), dup.data(), nullptr) != RH_OK) raise("contrafold");
     narrow_bp(dbp, bp);
     narrow_up(dup, up);
+}
+
+void ProbabilityEngine::rnafold(const std::string& seq, VF& bp, VI& offset) const
+{
+    const uint L = seq.size();
+    std::vector<double> dbp((size_t)(L + 1) * (L + 2) / 2, 0.0);
+    offset = make_offsets(L);
+    rh_ctx* v = vienna();
+    if (L > 0 && rh_bpp(v, seq.c_str(), (int)L, nullptr, dbp.data(), nullptr) != RH_OK)
+        throw std::logic_error(std::string("ractip_amd::rnafold: ") + rh_last_error(v));
+    narrow_bp(dbp, bp);
+}
+
+void ProbabilityEngine::rnafold(const std::string& seq, VF& bp, VI& offset, VVF& up, uint max_w) const
+{
+    const uint L = seq.size();
+    std::vector<double> dbp((size_t)(L + 1) * (L + 2) / 2, 0.0), dup((size_t)L * max_w, 0.0);
+    offset = make_offsets(L);
+    rh_ctx* v = vienna();
+    if (L > 0 && (rh_set_max_w(v, (int)max_w) != RH_OK || rh_fold(v, seq.c_str(), (int)L, dbp.data(), dup.data(), nullptr) != RH_OK))
+        throw std::logic_error(std::string("ractip_amd::rnafold: ") + rh_last_error(v));
+    narrow_bp(dbp, bp);
+    up.assign(L, VF(max_w));   // up.resize(L, VF(max_w)), :370
+    for (uint i = 0; i < L; ++i)
+        for (uint w = 0; w < max_w; ++w) up[i][w] = (float)dup[(size_t)i * max_w + w];
 }
 
 void ProbabilityEngine::contraduplex(const std::string& seq1, const std::string& seq2, VVF& hp) const

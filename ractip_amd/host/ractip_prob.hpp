@@ -5,6 +5,8 @@
 //   void contrafold(const std::string& seq, VF& bp, VI& offset, VVF& up) const;   // :195-223
 //   void contraduplex(const std::string& s1, const std::string& s2, VVF& hp) const; // :225-245
 //   void rnaduplex(const std::string& s1, const std::string& s2, VVF& hp) const;  // :384-399 (--duplex branch)
+//   void rnafold(const std::string& seq, VF& bp, VI& offset) const;                // :248-306  (Fasta::seq() of the original)
+//   void rnafold(const std::string& seq, VF& bp, VI& offset, VVF& up, uint max_w) const;  // :308-382
 //
 // so that RactIP::solve (:536-548) can call them unchanged; see INTEGRATION.md for the
 // two-line patch.  Failures surface as std::logic_error, which RactIP's main() already
@@ -44,6 +46,13 @@ public:
     // the --duplex branch of RactIP::rnaduplex: pf_duplex() + pr_duplex copy (:390-398)
     void rnaduplex(const std::string& seq1, const std::string& seq2, VVF& hp) const;
 
+    // the default CLI path: pf_fold + export_bppm (:288-304, 351-367) and pf_unstru's H+I+M+E (:370-375) with the BL*
+    // energies, ViennaRNA-1.8 semantics -- PARITY UNPINNED (ViennaRNA is absent and unversioned); structure
+    // constraints (use_constraint_, :271-291) are not supported.  A second context (RH_MODEL_VIENNA_BL) is created on
+    // first use.
+    void rnafold(const std::string& seq, VF& bp, VI& offset) const;
+    void rnafold(const std::string& seq, VF& bp, VI& offset, VVF& up, uint max_w) const;
+
     // batched form for the z-score loop (:1638-1657): all DPs of all pairs in one device pass
     std::vector<PairProbabilities> solve_probabilities(const std::vector<std::pair<std::string, std::string>>& pairs) const;
 
@@ -51,7 +60,10 @@ public:
 
 private:
     [[noreturn]] void raise(const char* where) const;
+    rh_ctx* vienna() const;
     rh_ctx* ctx_;
+    mutable rh_ctx* vctx_ = nullptr;
+    int device_;
     float th_hy_;
 };
 

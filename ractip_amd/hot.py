@@ -18,7 +18,7 @@ EXPORTS = [
     "rh_create", "rh_destroy", "rh_last_error", "rh_set_mode", "rh_last_path", "rh_bpp", "rh_unpaired", "rh_fold", "rh_duplex",
     "rh_batch_upload", "rh_batch_compute", "rh_batch_results", "rh_batch_candidates",
     "rh_batch_timings", "rh_batch_device_views", "rh_batch_logz", "rh_batch_candidates_all", "rh_batch_layout",
-    "rh_batch_results_all",
+    "rh_batch_results_all", "rh_set_max_w", "rh_get_max_w",
 ]
 
 
@@ -52,6 +52,10 @@ def load_library():
     L.rh_set_mode.argtypes = [vp, ci]
     L.rh_set_mode.restype = ci
     L.rh_last_path.argtypes = [vp]
+    L.rh_set_max_w.argtypes = [vp, ci]
+    L.rh_set_max_w.restype = ci
+    L.rh_get_max_w.argtypes = [vp]
+    L.rh_get_max_w.restype = ci
     L.rh_last_path.restype = ci
     L.rh_bpp.argtypes = [vp, cp, ci, cp, vp, vp]
     L.rh_unpaired.argtypes = [vp, cp, ci, ci, vp]
@@ -116,6 +120,13 @@ class Context:
     def last_path(self):
         return self.L.rh_last_path(self.h)
 
+    def set_max_w(self, max_w):
+        self._check(self.L.rh_set_max_w(self.h, max_w))
+
+    @property
+    def max_w(self):
+        return self.L.rh_get_max_w(self.h)
+
     # ---- single-problem calls
     def bpp(self, seq):
         n = len(seq)
@@ -132,9 +143,10 @@ class Context:
 
     def fold(self, seq):
         n = len(seq)
-        bp, up, z = np.zeros(tri_size(n)), np.zeros(n), ctypes.c_double()
+        w = self.max_w
+        bp, up, z = np.zeros(tri_size(n)), np.zeros(n * w), ctypes.c_double()
         self._check(self.L.rh_fold(self.h, seq.encode(), n, bp.ctypes.data, up.ctypes.data, ctypes.addressof(z)))
-        return bp, up, z.value
+        return bp, (up if w == 1 else up.reshape(n, w)), z.value
 
     def duplex(self, s1, s2):
         hp = np.zeros((len(s1) + 1, len(s2) + 1))
@@ -158,11 +170,14 @@ class Context:
     def batch_results(self, p):
         n1, n2 = self._pairs[p]
         bp1, bp2 = np.zeros(tri_size(n1)), np.zeros(tri_size(n2))
-        up1, up2 = np.zeros(n1), np.zeros(n2)
+        w = self.max_w
+        up1, up2 = np.zeros(n1 * w), np.zeros(n2 * w)
         hp = np.zeros((n1 + 1, n2 + 1))
         z3 = np.zeros(3)
         self._check(self.L.rh_batch_results(self.h, p, bp1.ctypes.data, bp2.ctypes.data, up1.ctypes.data,
                                             up2.ctypes.data, hp.ctypes.data, z3.ctypes.data))
+        if w > 1:
+            up1, up2 = up1.reshape(n1, w), up2.reshape(n2, w)
         return dict(bp1=bp1, bp2=bp2, up1=up1, up2=up2, hp=hp, logZ=z3)
 
     def batch_logz(self):
@@ -199,10 +214,13 @@ class Context:
         bp = np.empty((2 * np_, ts.value)); up = np.empty((2 * np_, uld.value)); hp = np.empty((np_, hs.value)); z = np.empty((np_, 3))
         self._check(self.L.rh_batch_results_all(self.h, bp.ctypes.data, up.ctypes.data, hp.ctypes.data, z.ctypes.data))
         out = []
+        w = self.max_w
         for p, (n1, n2) in enumerate(self._pairs):
             h = hp[p][:(n1 + 1) * hld.value].reshape(n1 + 1, hld.value)[:, :n2 + 1]
-            out.append(dict(bp1=bp[2 * p][:tri_size(n1)], bp2=bp[2 * p + 1][:tri_size(n2)], up1=up[2 * p][:n1], up2=up[2 * p + 1][:n2],
-                            hp=h, logZ=z[p]))
+            u1, u2 = up[2 * p][:n1 * w], up[2 * p + 1][:n2 * w]
+            if w > 1:
+                u1, u2 = u1.reshape(n1, w), u2.reshape(n2, w)
+            out.append(dict(bp1=bp[2 * p][:tri_size(n1)], bp2=bp[2 * p + 1][:tri_size(n2)], up1=u1, up2=u2, hp=h, logZ=z[p]))
         return out
 
     def batch_timings(self):

@@ -148,9 +148,34 @@ class ViennaOracle:
         L.vo_pf_duplex.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int] + [ctypes.c_void_p] * 4
         L.vo_bruteforce.restype = ctypes.c_double
         L.vo_bruteforce.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p]
+        L.vo_mccaskill.restype = ctypes.c_double
+        L.vo_mccaskill.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                   ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        L.vo_fold_bruteforce.restype = ctypes.c_double
+        L.vo_fold_bruteforce.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         self.L = L
         self.m = L.vo_load(os.path.join(ROOT, "ractip_amd", "data", "vienna_bl_star.params").encode())
         assert self.m
+
+    def mccaskill(self, seq, max_w=0, tables=False):
+        """pf_fold / pf_unstru semantics: logZ, bp (triangular, reference layout), up[n][max_w]."""
+        n = len(seq)
+        post = np.zeros(tri_size(n))
+        zo = ctypes.c_double()
+        up = np.zeros((n, max_w)) if max_w else None
+        tabs = np.zeros(8 * tri_size(n)) if tables else None
+        f5 = np.zeros(2 * (n + 1)) if tables else None
+        z = self.L.vo_mccaskill(self.m, seq.encode(), n, post.ctypes.data, ctypes.byref(zo),
+                                up.ctypes.data if max_w else None, max_w,
+                                tabs.ctypes.data if tables else None, f5.ctypes.data if tables else None)
+        return dict(logZ=z, logZ_out=zo.value, post=post, up=up, tables=tabs, f5=f5)
+
+    def fold_bruteforce(self, seq, max_w=0):
+        n = len(seq)
+        post = np.zeros(tri_size(n))
+        up = np.zeros((n, max_w)) if max_w else None
+        z = self.L.vo_fold_bruteforce(self.m, seq.encode(), n, post.ctypes.data, up.ctypes.data if max_w else None, max_w)
+        return dict(logZ=z, post=post, up=up)
 
     def pf_duplex(self, s1, s2):
         pr = np.zeros((len(s1) + 1, len(s2) + 1))

@@ -287,14 +287,80 @@ def test_vienna_bl_duplex_vs_its_cpu_restatement(hotlib, golden):
             continue
         assert abs(z - o["logZ"]) < 1e-9 * max(1.0, abs(z)), (len(s1), len(s2))
         assert_prob_close(hp, o["pr"], rel=REL, what="vienna duplex %d/%d" % (len(s1), len(s2)))
-    with pytest.raises(ractip_amd.RhError):
-        c.bpp("ACGU")          # pf_fold / pf_unstru equivalents are not built
     c.close()
+
+
+@pytest.fixture(scope="module")
+def vctx(hotlib):
+    import ractip_amd
+    c = ractip_amd.Context(device=0, model=ractip_amd.hot.RH_MODEL_VIENNA_BL)
+    yield c
+    c.close()
+
+
+def test_vienna_bl_mccaskill_and_accessibility_vs_cpu_restatement(vctx, golden):
+    """RH_MODEL_VIENNA_BL rnafold path (pf_fold bp + pf_unstru up, src/ractip.cpp:248-382): PARITY UNPINNED against
+    the reference (ViennaRNA absent); HIP kernels == oracle/vienna_oracle.c, which == brute-force enumeration of all
+    structures (tests/test_vienna_oracle.py)."""
+    from _oracle import ViennaOracle
+    vo = ViennaOracle()
+    rng = np.random.RandomState(91)
+    seqs = [str(golden["mc/%s/seq" % a]) for a in ("DIS", "CopA", "CopT", "OxyS", "fhlA", "Tar")]
+    seqs += ["GGGAAACCCAGGGAAACCCA", "GGAAACCCAGGGAAACCC", "GGCGAAAGCCAAGGCGAAAGCCAA", "GGGTTTNNNCCCAAAGGG", "A", "GC", "GAAAC", "GGAAACC"]
+    seqs += [rnd(rng, n) for n in (6, 17, 63, 64, 65, 130, 200)]
+    for s in seqs:
+        n = len(s)
+        o = vo.mccaskill(s, max_w=15)
+        bp, up, z = vctx.fold(s)
+        assert vctx.max_w == 15 and up.shape == (n, 15)
+        assert abs(z - o["logZ"]) < 1e-9 * max(1.0, abs(z)), n
+        assert_prob_close(bp, o["post"], rel=REL, what="vienna bp n=%d" % n)
+        assert_prob_close(up, o["up"], rel=REL, abs_floor=1e-11, what="vienna up n=%d" % n)
+        bp2, z2 = vctx.bpp(s)
+        assert np.array_equal(bp, bp2) and z == z2
+    # another width through rh_unpaired
+    s = seqs[1]
+    assert_prob_close(vctx.unpaired(s, max_w=4), vo.mccaskill(s, max_w=4)["up"], rel=REL, abs_floor=1e-11, what="up w=4")
+    vctx.set_max_w(15)
+
+
+def test_vienna_bl_pair_batch(vctx, golden):
+    """Batched form under the Vienna-BL model: everything RactIP::solve consumes on its default path with --duplex
+    (bp1, bp2, up1, up2 at width 15, hp), ragged lengths, plus the on-device threshold scans of up."""
+    from _oracle import ViennaOracle
+    vo = ViennaOracle()
+    rng = np.random.RandomState(92)
+    pairs = [(str(golden["mc/CopA/seq"]), str(golden["mc/CopT/seq"])), (str(golden["mc/OxyS/seq"]), str(golden["mc/fhlA/seq"])),
+             (rnd(rng, 150), rnd(rng, 90)), (rnd(rng, 31), rnd(rng, 160))]
+    vctx.batch_upload(pairs)
+    vctx.batch_compute()
+    allr = vctx.batch_results_all()
+    for p, (s1, s2) in enumerate(pairs):
+        r = vctx.batch_results(p)
+        o1, o2, od = vo.mccaskill(s1, max_w=15), vo.mccaskill(s2, max_w=15), vo.pf_duplex(s1, s2)
+        assert_prob_close(r["bp1"], o1["post"], rel=REL, what="bp1")
+        assert_prob_close(r["bp2"], o2["post"], rel=REL, what="bp2")
+        assert_prob_close(r["up1"], o1["up"], rel=REL, abs_floor=1e-11, what="up1")
+        assert_prob_close(r["up2"], o2["up"], rel=REL, abs_floor=1e-11, what="up2")
+        assert_prob_close(r["hp"], od["pr"], rel=REL, what="hp")
+        assert np.abs(r["logZ"] - np.array([o1["logZ"], o2["logZ"], od["logZ"]])).max() < 1e-8
+        for k in ("bp1", "bp2", "up1", "up2", "hp"):
+            assert np.array_equal(np.asarray(allr[p][k]), r[k]), k
+        # accessible regions (src/ractip.cpp:621-627): up[i][j] > th_ac, region (i, i+j)
+        th = np.float32(0.003)
+        want = [(i, j) for i in range(len(s1)) for j in range(15) if np.float32(r["up1"][i, j]) > th]
+        got = [(i, j) for i, j, _ in vctx.batch_candidates(p, 3, float(th))]
+        assert got == want
+    recs, first = vctx.batch_candidates_all(4, 0.003)
+    for p, (s1, s2) in enumerate(pairs):
+        mine = recs[first[p]:first[p + 1]]
+        single = vctx.batch_candidates(p, 4, 0.003)
+        assert [(int(a), int(b)) for a, b in zip(mine["i"], mine["j"])] == [(i, j) for i, j, _ in single]
 
 
 def test_errors_are_reported_not_swallowed(ctx):
     import ractip_amd
     with pytest.raises(ractip_amd.RhError):
-        ctx.unpaired("ACGU", max_w=5)
+        ctx.unpaired("ACGU", max_w=5)      # the CONTRAfold path has width-1 accessibility only
     with pytest.raises(ractip_amd.RhError):
         ctx.batch_upload([("ACGU", "")])

@@ -44,3 +44,48 @@ def test_t_reads_as_u_and_unknown_letters_do_not_pair(vo):
     b = vo.pf_duplex("GGGAAACCC", "GGGUUUCCC")
     assert a["logZ"] == b["logZ"]
     assert vo.pf_duplex("NNNN", "NNNN")["pr"].max() == 0
+
+
+# ---- McCaskill / accessibility restatement (pf_fold + pf_unstru semantics, PARITY UNPINNED) ---------------------
+MULTILOOP_SEQS = [
+    "GGGAAACCCAGGGAAACCCA",            # two hairpins, multiloop (1,19)
+    "GGAAACCCAGGGAAACCC",              # three-branch multiloop with a trailing unpaired letter
+    "GGCGAAAGCCAAGGCGAAAGCCAA",        # tetraloop bonus CGAAAG
+    "GGGGACGAAAGUCCUUGGGAGACUCCC",
+    "GCGCGAAAGCAUGCGAAAGCAGCAAGC",
+]
+
+
+def test_mccaskill_equals_bruteforce_enumeration(vo):
+    """bp, log Z and P(region unpaired) of the DP == explicit enumeration of every secondary structure (exact
+    marginals of the Boltzmann ensemble are what pf_fold/pf_unstru define)."""
+    rng = np.random.RandomState(3)
+    seqs = list(MULTILOOP_SEQS)
+    seqs += ["".join(rng.choice(list("ACGU"), n, p=[.15, .35, .35, .15])) for n in (1, 4, 5, 9, 14, 18, 20, 22, 24, 26)]
+    for s in seqs:
+        a, b = vo.mccaskill(s, max_w=10), vo.fold_bruteforce(s, max_w=10)
+        assert abs(a["logZ"] - b["logZ"]) < 1e-11, s
+        assert abs(a["logZ"] - a["logZ_out"]) < 1e-11, s
+        assert np.abs(a["post"] - b["post"]).max() < 1e-11, s
+        assert np.abs(a["up"] - b["up"]).max() < 1e-11, s
+
+
+def test_mccaskill_invariants_on_bundled_sequences(vo, golden):
+    for name in ("DIS", "CopA", "CopT", "OxyS", "fhlA"):
+        s = str(golden["mc/%s/seq" % name])
+        n = len(s)
+        r = vo.mccaskill(s, max_w=15)
+        assert abs(r["logZ"] - r["logZ_out"]) < 1e-9 * max(1.0, abs(r["logZ"]))
+        bp, up = r["post"], r["up"]
+        assert bp.min() >= 0 and bp.max() <= 1 + 1e-12
+        # width-1 accessibility + pairing probabilities of a letter sum to one
+        paired = np.zeros(n + 1)
+        for i in range(1, n + 1):
+            off = i * (2 * (n + 1) - i - 1) // 2
+            for j in range(i + 1, n + 1):
+                paired[i] += bp[off + j]
+                paired[j] += bp[off + j]
+        assert np.abs(paired[1:] + up[:, 0] - 1).max() < 1e-9
+        # wider regions are less accessible; regions running off the end are 0
+        assert (np.diff(up, axis=1) <= 1e-12).all()
+        assert up[n - 1, 1] == 0 and up[n - 3, 3] == 0
