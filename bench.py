@@ -27,6 +27,25 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def cpu_baseline_vienna(pairs, budget_s=12.0):
+    """Vienna-BL workload: our CPU restatement (oracle/vienna_oracle.c, kind "port"; ViennaRNA itself is absent), 1 thread."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _oracle import ViennaOracle
+    eng = ViennaOracle()
+    done, t0 = 0, time.perf_counter()
+    for s1, s2 in pairs:
+        eng.mccaskill(s1, max_w=15)
+        eng.mccaskill(s2, max_w=15)
+        eng.pf_duplex(s1, s2)
+        done += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "pairs/s", "cores": 1, "kind": "port",
+            "sample": "%d pair(s) of n=%d/%d, %.1f s, oracle/vienna_oracle.c (McCaskill + accessibility w<=15 + pf_duplex), 1 thread" % (
+                done, len(pairs[0][0]), len(pairs[0][1]), dt)}
+
+
 def cpu_baseline(pairs, budget_s=20.0):
     """Time the CPU path on a bounded sample of the same workload (rank 0, N=1 only).
 
@@ -65,6 +84,9 @@ def main():
     ap.add_argument("--workload", default="pairs", choices=["pairs", "zscore"],
                     help="pairs: synthetic random pairs of --seqlen (the headline metric); zscore: the DP stage of BASELINE "
                          "config 5 -- OxyS vs fhlA, --zscore=12 --seed=1, --batch dinucleotide shuffles per GPU per step")
+    ap.add_argument("--model", default="contrafold", choices=["contrafold", "vienna"],
+                    help="contrafold: the pinned --contrafold path (headline); vienna: the default-CLI path with --duplex "
+                         "(pf_fold bp + pf_unstru up at width 15 + pf_duplex hp, BL* energies, parity unpinned)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only for "
                     "rehearsing the multi-rank path on a one-GPU box, where all ranks share cuda:0)")
@@ -104,11 +126,14 @@ def main():
         all_pairs = _shard.zscore_shuffles(oxys, fhla, 12, batch * world, 1)
     else:
         batch = args.batch or (64 if n <= 600 else (16 if n <= 1200 else 4))
+        if args.model == "vienna" and not args.batch:
+            batch = max(1, batch // 2)
         # every rank draws from ONE stream and keeps its own slice: distinct pairs per rank (weak scaling)
         all_pairs = random_pairs(batch * world, n, seed=12345)
     pairs = all_pairs[rank * batch:(rank + 1) * batch]
 
-    ctx = ractip_amd.Context(device=device_index)
+    vienna = args.model == "vienna"
+    ctx = ractip_amd.Context(device=device_index, model=ractip_amd.hot.RH_MODEL_VIENNA_BL if vienna else ractip_amd.hot.RH_MODEL_CONTRAFOLD)
     ctx.batch_upload(pairs)  # sequences -> HBM, tables allocated: outside the timed region
 
     from ractip_amd import shard
@@ -140,6 +165,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # isolated phase timings (outside the timed region): the duplex sweeps, the McCaskill inside sweep and the outside sweep
+    # run one after the other, each bracketed by HIP events on its own stream, with nothing else on the device --
+    # the per-kernel durations a kernel trace of this command reports (profiles/*_kernel_stats.txt)
+    ctx.set_overlap(False)
+    iso_ms = np.zeros(4)
+    ISO = 3
+    for _ in range(ISO):
+        ctx.batch_compute()
+        iso_ms += np.array(ctx.batch_timings()[0]) / ISO
+    ctx.set_overlap(True)
+    kernel_names = ctx.batch_kernels()
+
     if rank == 0:
         total_pairs = batch * world * args.steps
         # algorithmic bytes of rank 0's batch, split by kernel (ractip_amd/balg.py)
@@ -150,23 +187,52 @@ def main():
                 b[k] += pb[k]
         ms_mean = ms_acc / args.steps  # HIP-event ms per step: inside sweep, outside sweep, duplex, whole
         phases = {}
-        for key, bytes_, ms_k, launches in (("mc_inside_diag", b["mc_inside"], ms_mean[0], nl[0]),
-                                            ("mc_outside_diag", b["mc_outside"], ms_mean[1], nl[1]),
-                                            ("dx_sweep_diag", b["duplex"], ms_mean[2], nl[2])):
+        for key, bytes_, ms_k, launches in (("mccaskill_inside_phase", b["mc_inside"], ms_mean[0], nl[0]),
+                                            ("mccaskill_outside_phase", b["mc_outside"], ms_mean[1], nl[1]),
+                                            ("duplex_phase", b["duplex"], ms_mean[2], nl[2])):
             phases[key] = {"alg_GB_per_step": bytes_ / 1e9, "ms_per_step": float(ms_k), "launches": int(launches),
                            "avg_launch_us": float(ms_k) * 1e3 / max(1, launches),
                            "achieved_GBs": bytes_ / 1e9 / (ms_k / 1e3) if ms_k > 0 else None}
-        dom = max(("mc_inside_diag", "mc_outside_diag"), key=lambda k: phases[k]["ms_per_step"])
-        # HBM-side traffic per launch of that phase: measured separately with rocprofv3 PMC passes
-        # (profiles/pmc_traffic.json holds bytes per step); null for configurations that were not profiled
+        # roofline of the dominant sweep: the phase with the largest isolated device time.  Its launches are the
+        # per-diagonal kernel plus (fast path) the block-product kernel that takes the far k-terms of the same sums;
+        # algorithmic bytes per launch = B_alg of the sweep / its launches, duration = isolated sweep time / its launches
+        bk = {"inside": 0, "inside_far": 0, "outside": 0, "outside_far": 0, "duplex": 0}
+        far_on = kernel_names[0][2] > 0
+        for s1, s2 in pairs:
+            pk = balg.pair_bytes_by_kernel(s1, s2, bs=16 if far_on else 0)
+            for k in bk:
+                bk[k] += pk[k]
+        kernels = {}
+        for idx, (pname, bytes_) in enumerate((("mccaskill_inside_phase", b["mc_inside"]), ("mccaskill_outside_phase", b["mc_outside"]),
+                                               ("duplex_phase", b["duplex"]))):
+            fine, far, n_far = kernel_names[idx]
+            launches = int(nl[idx])
+            if not fine or launches == 0 or iso_ms[idx] <= 0:
+                continue
+            avg_us = iso_ms[idx] * 1e3 / launches
+            kernels[fine] = {"phase": pname, "launches_per_step": launches, "of_which_block_product": n_far,
+                             "block_product_kernel": far or None, "isolated_ms_per_step": float(iso_ms[idx]),
+                             "avg_launch_us": avg_us, "alg_bytes_per_launch": bytes_ / launches,
+                             "achieved_GBs": bytes_ / 1e9 / (iso_ms[idx] / 1e3),
+                             "alg_GB_fine_vs_block_product": [bk[("inside", "outside", "duplex")[idx]] / 1e9,
+                                                              bk.get(("inside_far", "outside_far", "none")[idx], 0) / 1e9]}
+        dom = max(kernels, key=lambda k: kernels[k]["isolated_ms_per_step"])
+        # HBM-side traffic per launch of that sweep: rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, gfx950 correction),
+        # collected separately (profiles/pmc_traffic.json, bytes per dispatch by kernel name); null if not profiled
         traffic = None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            per_step = tj.get("n%d_b%d" % (n, batch), {}).get(dom)
-            traffic = per_step / max(1, phases[dom]["launches"]) if per_step else None
+            tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("%s_n%d_b%d" % (args.model, n, batch), {})
+            kd = kernels[dom]
+            def per_dispatch(name):
+                hits = [v for k2, v in tj.items() if name and name.split("<")[0] in k2 and ("mfma" in name) == ("mfma" in k2)]
+                return hits[0] if hits else None
+            tf, tb = per_dispatch(dom), per_dispatch(kd["block_product_kernel"])
+            if tf is not None and (tb is not None or not kd["of_which_block_product"]):
+                nfine = kd["launches_per_step"] - kd["of_which_block_product"]
+                traffic = (tf * nfine + (tb or 0.0) * kd["of_which_block_product"]) / kd["launches_per_step"]
         except (OSError, ValueError):
             pass
-        ach = phases[dom]["achieved_GBs"]
+        ach = kernels[dom]["achieved_GBs"]
         line = {
             "metric": ("sequence-pairs/sec (incl. bp+hp+ap DP) at n=%d" % n) if args.workload == "pairs"
                       else "z-score DP stage: shuffled pairs/sec (OxyS/fhlA, bp+hp+ap DP per shuffle)",
@@ -184,11 +250,17 @@ def main():
             "config": {"workload": ("synthetic random pairs n=%d/%d, std::mt19937(12345) stream (BASELINE config %s)"
                                     % (n, n, "3" if n == 500 else ("4" if n == 2000 else "-"))) if args.workload == "pairs"
                                    else "OxyS.fa (109) vs fhlA.fa (113), --zscore=12 --seed=1 dinucleotide shuffles (BASELINE config 5, DP stage)",
-                       "pairs_per_gpu_per_step": batch, "model": None, "scoring": "CONTRAfold complementary (708 weights)"},
+                       "pairs_per_gpu_per_step": batch, "model": None,
+                       "scoring": "Vienna-BL (BL* tables, ViennaRNA-1.8 semantics, up width 15; parity unpinned)" if vienna
+                                  else "CONTRAfold complementary (708 weights)"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS if ach else None, "traffic": traffic,
-                         "alg_bytes_per_launch": phases[dom]["alg_GB_per_step"] * 1e9 / max(1, phases[dom]["launches"]),
-                         "avg_launch_us": phases[dom]["avg_launch_us"],
+                         "alg_bytes_per_launch": kernels[dom]["alg_bytes_per_launch"],
+                         "avg_launch_us": kernels[dom]["avg_launch_us"],
+                         "timing": "HIP events around the whole sweep on its own stream, sweeps run one after the other "
+                                   "(3 passes after the timed region); 'phases' below = the same events inside the timed region, "
+                                   "where the duplex stream overlaps the McCaskill stream",
+                         "kernels": kernels,
                          "whole_path": {"alg_GB_per_pair": b["total"] / 1e9 / batch,
                                         "achieved_GBs": b["total"] / 1e9 / (ms_mean[3] / 1e3),
                                         "frac": b["total"] / 1e9 / (ms_mean[3] / 1e3) / HBM_PEAK_GBS},
@@ -208,7 +280,7 @@ def main():
             sparse = 2 * batch / (time.perf_counter() - t1)
             line["pcie_inclusive"] = {"dense_results_pairs_per_s": dense, "threshold_candidates_pairs_per_s": sparse}
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(all_pairs, budget_s=12.0 if n <= 600 else 1.0)
+            line["cpu_baseline"] = (cpu_baseline_vienna if vienna else cpu_baseline)(all_pairs, budget_s=12.0 if n <= 600 else 1.0)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)

@@ -141,6 +141,17 @@ int rh_batch_results_all(rh_ctx* ctx, double* bp, double* up, double* hp, double
  * (+posterior), [2] duplex sweeps, [3] whole compute.  Launch counts in n_launch[0..2]. */
 int rh_batch_timings(rh_ctx* ctx, double ms[4], int n_launch[3]);
 
+/* Names (as a kernel trace prints them) of the sweep kernels the last rh_batch_compute launched, per phase
+ * [0] McCaskill inside, [1] outside (+posterior), [2] duplex: the per-diagonal kernel, the block-product kernel ("" if
+ * none) and how many of the phase's n_launch were block-product launches. */
+int rh_batch_kernels(rh_ctx* ctx, const char* fine[3], const char* far[3], int n_far[3]);
+
+/* Measurement aid: rh_set_overlap(ctx, 0) makes rh_batch_compute run the duplex sweeps, the McCaskill inside sweep and
+ * the outside sweep one after the other instead of overlapping the duplex stream with the McCaskill stream, so that
+ * rh_batch_timings returns each phase's device time with nothing else on the GPU (what a kernel trace reports per
+ * kernel).  Results are unchanged.  Default: overlap on. */
+int rh_set_overlap(rh_ctx* ctx, int on);
+
 /* Device pointers of the last batch (for callers that keep results on the GPU):
  * bp tables [2*npairs][tri_stride] (sequence 2p = s1 of pair p, 2p+1 = s2),
  * hp tables [npairs][hp_stride]. */

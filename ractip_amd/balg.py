@@ -93,6 +93,40 @@ def duplex_counts(s1, s2):
     return dict(inside=(n_in, n_p), outside=(n_p + n_in, n_p + n_in), posterior=(2 * n_p, n_p))
 
 
+def far_terms(n, bs=16):
+    """How many k-terms of the O(n^3) sums the block-product kernels (mccaskill_far.hip) take over from the
+    per-diagonal kernels, for one sequence of length n and block size bs: (inside FM2 terms, outside FMo terms,
+    outside FM1o terms).  Mirrors the near/far split of lin_inside_diag / lin_outside_diag exactly: cell (i,j),
+    I = i//bs, J = j//bs; inside: k in [(I+2)bs, (J-1)bs) when J-I >= 4; outside: FMo sources i' < (I-1)bs,
+    FM1o sources j' >= (J+2)bs (cells with j-i >= 2 only)."""
+    if n < 3 or bs <= 0:
+        return 0, 0, 0
+    i = np.arange(1, n)[:, None]
+    j = np.arange(1, n)[None, :]
+    valid = j >= i
+    I, J = i // bs, j // bs
+    k_in = np.where(valid & (J - I >= 4), (J - I - 3) * bs, 0).sum()
+    gm = valid & (j - i >= 2)
+    k_fmo = np.where(gm, np.maximum((I - 1) * bs - 1, 0), 0).sum()
+    k_fm1o = np.where(gm, np.maximum(n - (J + 2) * bs, 0), 0).sum()
+    return int(k_in), int(k_fmo), int(k_fm1o)
+
+
+def pair_bytes_by_kernel(s1, s2, bs=16):
+    """B_alg of one pair split by the kernel class that executes the accesses (rh_batch_kernel_times order):
+    inside fine diagonals, inside block products, outside fine, outside block products, duplex sweep.  A k-term of
+    the reference costs 2 table accesses in the inside sweep (InferenceEngine.ipp:3396-3403) and 6 in the outside
+    sweep (two read-modify-writes and two operand loads, :4046-4064), 3 per updated table."""
+    b = pair_bytes(s1, s2)
+    far_in = far_out = 0
+    for s in (s1, s2):
+        k_in, k_fmo, k_fm1o = far_terms(len(s), bs)
+        far_in += 8 * 2 * k_in
+        far_out += 8 * 3 * (k_fmo + k_fm1o)
+    return dict(inside=b["mc_inside"] - far_in, inside_far=far_in, outside=b["mc_outside"] - far_out, outside_far=far_out,
+                duplex=b["duplex"], total=b["total"])
+
+
 def pair_bytes(s1, s2):
     """B_alg of one (s1,s2) pair split by GPU kernel: inside sweep, outside sweep (+posterior), duplex."""
     tot = dict(mc_inside=0, mc_outside=0, duplex=0)

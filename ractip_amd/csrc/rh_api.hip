@@ -209,7 +209,7 @@ static thread_local std::string g_create_error;
 struct GraphSlot {   // one captured launch sequence (see run_graphed)
     hipGraphExec_t exec = nullptr;
     size_t key = 0;
-    int launches = 0;
+    int launches = 0, far = 0;
 };
 
 struct rh_ctx {
@@ -263,6 +263,8 @@ struct rh_ctx {
     void* d_gaps = nullptr;  size_t cap_gaps = 0;
     double ms[4] = {0, 0, 0, 0};
     int n_launch[3] = {0, 0, 0};
+    int n_far[3] = {0, 0, 0};      // of which block-product launches (mccaskill_far.hip)
+    bool overlap = true;           // false: duplex, inside and outside sweeps run one after the other (isolated phase timings)
 };
 
 namespace {
@@ -285,6 +287,9 @@ int fail(rh_ctx* c, int code, const char* fmt, ...)
             return fail(c, e_ == hipErrorOutOfMemory ? RH_ERR_OOM : RH_ERR_HIP, "%s failed: %s", \
                         #call, hipGetErrorString(e_));                                           \
     } while (0)
+
+// launch of one sweep kernel (class = 0 inside, 1 inside block products, 2 outside, 3 outside block products, 4 duplex)
+#define KLAUNCH(c, cls, kern, grid, block, stream, ...) hipLaunchKernelGGL(kern, grid, block, 0, stream, __VA_ARGS__)
 
 // grow-only device buffer
 int ensure(rh_ctx* c, void** p, size_t* cap, size_t bytes, bool zero)
@@ -430,15 +435,13 @@ int launch_mc_log(rh_ctx* c, int pin)
     hipLaunchKernelGGL(mc_init, dim3((B.ns + 63) / 64), dim3(64), 0, c->s_mc, B);
     for (int d = 0; d <= B.nmax - 1; d++) {
         const int waves = std::max(B.nmax - 1 - d, 0) + 1;
-        hipLaunchKernelGGL(mc_inside_diag, pin ? dim3(B.ns, (waves + 3) / 4) : dim3((waves + 3) / 4, B.ns), dim3(256), 0,
-                           c->s_mc, B, c->d_model, d, pin);
+        KLAUNCH(c, 0, mc_inside_diag, pin ? dim3(B.ns, (waves + 3) / 4) : dim3((waves + 3) / 4, B.ns), dim3(256), c->s_mc, B, c->d_model, d, pin);
         c->n_launch[0]++;
     }
     HIP_TRY(c, hipEventRecord(c->ev[1], c->s_mc));
     for (int d = B.nmax - 2; d >= 0; d--) {
         const int waves = (B.nmax - 1 - d) + 1;
-        hipLaunchKernelGGL(mc_outside_diag, pin ? dim3(B.ns, (waves + 3) / 4) : dim3((waves + 3) / 4, B.ns), dim3(256), 0,
-                           c->s_mc, B, c->d_model, d, pin);
+        KLAUNCH(c, 2, mc_outside_diag, pin ? dim3(B.ns, (waves + 3) / 4) : dim3((waves + 3) / 4, B.ns), dim3(256), c->s_mc, B, c->d_model, d, pin);
         c->n_launch[1]++;
     }
     hipLaunchKernelGGL(log_finish, dim3((B.ns + 63) / 64), dim3(64), 0, c->s_mc, B, (double*)c->d_mclogz);
@@ -453,15 +456,13 @@ int launch_mc_vienna(rh_ctx* c, int pin)
     hipLaunchKernelGGL(mcv_init, dim3((B.ns + 63) / 64), dim3(64), 0, c->s_mc, B);
     for (int d = 0; d <= B.nmax - 1; d++) {
         const int waves = std::max(B.nmax - 1 - d, 0) + 1;
-        hipLaunchKernelGGL(mcv_inside_diag, pin ? dim3(B.ns, (waves + 3) / 4) : dim3((waves + 3) / 4, B.ns), dim3(256), 0,
-                           c->s_mc, B, c->d_vienna, d, pin);
+        KLAUNCH(c, 0, mcv_inside_diag, pin ? dim3(B.ns, (waves + 3) / 4) : dim3((waves + 3) / 4, B.ns), dim3(256), c->s_mc, B, c->d_vienna, d, pin);
         c->n_launch[0]++;
     }
     HIP_TRY(c, hipEventRecord(c->ev[1], c->s_mc));
     for (int d = B.nmax - 2; d >= 0; d--) {
         const int waves = (B.nmax - 1 - d) + 1;
-        hipLaunchKernelGGL(mcv_outside_diag, pin ? dim3(B.ns, (waves + 3) / 4) : dim3((waves + 3) / 4, B.ns), dim3(256), 0,
-                           c->s_mc, B, c->d_vienna, d, pin);
+        KLAUNCH(c, 2, mcv_outside_diag, pin ? dim3(B.ns, (waves + 3) / 4) : dim3((waves + 3) / 4, B.ns), dim3(256), c->s_mc, B, c->d_vienna, d, pin);
         c->n_launch[1]++;
     }
     hipLaunchKernelGGL(mcv_finish, dim3((B.ns + 63) / 64), dim3(64), 0, c->s_mc, B, (double*)c->d_mclogz);
@@ -489,17 +490,17 @@ int launch_mc_lin(rh_ctx* c, int pin, int phase)
     hipLaunchKernelGGL(lin_init, dim3((B.ns + 63) / 64), dim3(64), 0, c->s_mc, B, bad);
     for (int d = 0; d <= B.nmax - 1; d++) {
         const int groups = (std::max(B.nmax - 1 - d, 0) + 63) / 64 + 1;
-        hipLaunchKernelGGL((lin_inside_diag<W, BS>), pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(64 * W), 0, c->s_mc, B,
+        KLAUNCH(c, 0, (lin_inside_diag<W, BS>), pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(64 * W), c->s_mc, B,
                            c->d_lin, d, std::exp(-c->h_lin.s * d), pin);
         c->n_launch[0]++;
         if (BS > 0 && (d + 1) % BS == 0) {
             const int D = (d + 1) / BS + 1;
             if (D >= 4 && D <= last_block) {
                 if (BS == 16 && c->far_mfma)
-                    hipLaunchKernelGGL(lin_far_inside_mfma, dim3(last_block - D + 1, B.ns), dim3(256), 0, c->s_mc, B, D);
+                    KLAUNCH(c, 1, lin_far_inside_mfma, dim3(last_block - D + 1, B.ns), dim3(256), c->s_mc, B, D);
                 else
-                    hipLaunchKernelGGL(lin_far_inside<(BS > 0 ? BS : 16)>, dim3(last_block - D + 1, B.ns), dim3(256), 0, c->s_mc, B, D);
-                c->n_launch[0]++;
+                    KLAUNCH(c, 1, lin_far_inside<(BS > 0 ? BS : 16)>, dim3(last_block - D + 1, B.ns), dim3(256), c->s_mc, B, D);
+                c->n_launch[0]++; c->n_far[0]++;
             }
         }
     }
@@ -508,23 +509,24 @@ int launch_mc_lin(rh_ctx* c, int pin, int phase)
     if (BS > 0)  // tiles whose first cell would come before the first outside diagonal: their far sums are empty
         for (int D = last_block; D >= 0 && (D + 1) * BS - 1 > B.nmax - 2; D--) {
             if (BS == 16 && c->far_mfma)
-                hipLaunchKernelGGL(lin_far_outside_mfma, dim3(last_block - D + 1, B.ns, 2), dim3(256), 0, c->s_mc, B, D);
+                KLAUNCH(c, 3, lin_far_outside_mfma, dim3(last_block - D + 1, B.ns, 2), dim3(256), c->s_mc, B, D);
             else
-                hipLaunchKernelGGL(lin_far_outside<(BS > 0 ? BS : 16)>, dim3(last_block - D + 1, B.ns, 2), dim3(256), 0, c->s_mc, B, D);
+                KLAUNCH(c, 3, lin_far_outside<(BS > 0 ? BS : 16)>, dim3(last_block - D + 1, B.ns, 2), dim3(256), c->s_mc, B, D);
+            c->n_launch[1]++; c->n_far[1]++;
         }
     for (int d = B.nmax - 2; d >= 0; d--) {
         if (BS > 0 && (d + 1) % BS == 0) {
             const int D = (d + 1) / BS - 1;
             if (D >= 0 && D <= last_block) {
                 if (BS == 16 && c->far_mfma)
-                    hipLaunchKernelGGL(lin_far_outside_mfma, dim3(last_block - D + 1, B.ns, 2), dim3(256), 0, c->s_mc, B, D);
+                    KLAUNCH(c, 3, lin_far_outside_mfma, dim3(last_block - D + 1, B.ns, 2), dim3(256), c->s_mc, B, D);
                 else
-                    hipLaunchKernelGGL(lin_far_outside<(BS > 0 ? BS : 16)>, dim3(last_block - D + 1, B.ns, 2), dim3(256), 0, c->s_mc, B, D);
-                c->n_launch[1]++;
+                    KLAUNCH(c, 3, lin_far_outside<(BS > 0 ? BS : 16)>, dim3(last_block - D + 1, B.ns, 2), dim3(256), c->s_mc, B, D);
+                c->n_launch[1]++; c->n_far[1]++;
             }
         }
         const int groups = (B.nmax - 1 - d + 63) / 64 + 1;
-        hipLaunchKernelGGL((lin_outside_diag<W, BS>), pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(64 * W), 0, c->s_mc, B,
+        KLAUNCH(c, 2, (lin_outside_diag<W, BS>), pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(64 * W), c->s_mc, B,
                            c->d_lin, d, pin, bad);
         c->n_launch[1]++;
     }
@@ -556,13 +558,13 @@ int launch_mc_lin_any(rh_ctx* c, int pin, int phase)
 size_t shape_key(const rh_ctx* c, int which);
 
 template <class F>
-int run_graphed(rh_ctx* c, GraphSlot& g, size_t key, hipStream_t stream, int* launch_counter, F&& launch)
+int run_graphed(rh_ctx* c, GraphSlot& g, size_t key, hipStream_t stream, int* launch_counter, int* far_counter, F&& launch)
 {
     if (!c->use_graphs) return launch();
     if (!g.exec || g.key != key) {
         if (g.exec) { HIP_TRY(c, hipGraphExecDestroy(g.exec)); g.exec = nullptr; }
         hipGraph_t graph = nullptr;
-        const int before = *launch_counter;
+        const int before = *launch_counter, far_before = *far_counter;
         HIP_TRY(c, hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
         const int rc = launch();
         hipError_t e = hipStreamEndCapture(stream, &graph);
@@ -572,10 +574,13 @@ int run_graphed(rh_ctx* c, GraphSlot& g, size_t key, hipStream_t stream, int* la
         HIP_TRY(c, hipGraphDestroy(graph));
         g.key = key;
         g.launches = *launch_counter - before;
+        g.far = *far_counter - far_before;
         *launch_counter = before;
+        *far_counter = far_before;
     }
     HIP_TRY(c, hipGraphLaunch(g.exec, stream));
     *launch_counter += g.launches;
+    *far_counter += g.far;
     return RH_OK;
 }
 
@@ -587,7 +592,7 @@ int launch_dx_log(rh_ctx* c)
     const int steps = smax / 2;
     const int waves = 2 * std::min(D.n1max, D.n2max);
     for (int t = 0; t < steps; t++) {
-        hipLaunchKernelGGL(dx_sweep_diag, dim3((waves + 3) / 4, D.np, 2), dim3(256), 0, c->s_dx, D, c->d_model, t);
+        KLAUNCH(c, 4, dx_sweep_diag, dim3((waves + 3) / 4, D.np, 2), dim3(256), c->s_dx, D, c->d_model, t);
         c->n_launch[2]++;
     }
     hipLaunchKernelGGL(dx_logz, dim3(D.np), dim3(1024), 0, c->s_dx, D, c->d_model);
@@ -609,7 +614,7 @@ int launch_dx_lin(rh_ctx* c)
         // inside diagonal sd = 2+2t+k: (lam e^eu)^(sd-2) lam^2 ; outside sd = Smax-2t-1+k: (lam e^eu)^(2t+1-k) lam^2
         X.pw_in[0] = std::pow(leu, 2.0 * t) * l2;      X.pw_in[1] = X.pw_in[0] * leu;
         X.pw_out[1] = std::pow(leu, 2.0 * t) * l2;     X.pw_out[0] = X.pw_out[1] * leu;
-        hipLaunchKernelGGL(dxl_sweep<W>, dim3(2 * groups, X.np, 2), dim3(64 * W), 0, c->s_dx, X, c->d_dxlin, t, groups);
+        KLAUNCH(c, 4, dxl_sweep<W>, dim3(2 * groups, X.np, 2), dim3(64 * W), c->s_dx, X, c->d_dxlin, t, groups);
         c->n_launch[2]++;
     }
     hipLaunchKernelGGL(dxl_logz, dim3(X.np), dim3(1024), 0, c->s_dx, X, c->d_dxlin, (double*)c->d_zbar, (double*)c->d_logz,
@@ -651,6 +656,7 @@ int compute(rh_ctx* c)
 {
     HIP_TRY(c, hipSetDevice(c->device));
     c->n_launch[0] = c->n_launch[1] = c->n_launch[2] = 0;
+    c->n_far[0] = c->n_far[1] = c->n_far[2] = 0;
     c->last_path = 0;
     // sequence -> XCD affinity only when the batch spreads evenly over the 8 XCDs (speed only)
     const int pin = (c->has_mc && c->mc.ns % 8 == 0) ? 1 : 0;
@@ -666,7 +672,7 @@ int compute(rh_ctx* c)
         const int steps = (D.n1max + D.n2max) / 2;
         const int waves = 2 * std::min(D.n1max, D.n2max);
         for (int t = 0; t < steps; t++) {
-            hipLaunchKernelGGL(dxv_sweep_diag, dim3((waves + 3) / 4, D.np, 2), dim3(256), 0, c->s_dx, D, c->d_vienna, t);
+            KLAUNCH(c, 4, dxv_sweep_diag, dim3((waves + 3) / 4, D.np, 2), dim3(256), c->s_dx, D, c->d_vienna, t);
             c->n_launch[2]++;
         }
         hipLaunchKernelGGL(dxv_logz, dim3(D.np), dim3(1024), 0, c->s_dx, D, c->d_vienna);
@@ -674,7 +680,7 @@ int compute(rh_ctx* c)
         c->last_dx_path = 2;
     } else if (c->has_dx && !skip_dx) {
         if (c->mode != RH_MODE_LOG) {
-            if ((rc = run_graphed(c, c->g_dx, shape_key(c, 2), c->s_dx, &c->n_launch[2], [&] { return launch_dx_lin_any(c); }))) return rc;
+            if ((rc = run_graphed(c, c->g_dx, shape_key(c, 2), c->s_dx, &c->n_launch[2], &c->n_far[2], [&] { return launch_dx_lin_any(c); }))) return rc;
             dx_lin_launched = true;
         } else {
             if ((rc = launch_dx_log(c))) return rc;
@@ -682,6 +688,7 @@ int compute(rh_ctx* c)
         }
     }
     HIP_TRY(c, hipEventRecord(c->ev[4], c->s_dx));
+    if (!c->overlap) HIP_TRY(c, hipStreamSynchronize(c->s_dx));   // isolated phase timings: nothing else on the device
 
     HIP_TRY(c, hipEventRecord(c->ev[0], c->s_mc));
     bool need_log = c->has_mc && c->mode == RH_MODE_LOG && !skip_mc && c->model != RH_MODEL_VIENNA_BL;
@@ -689,9 +696,9 @@ int compute(rh_ctx* c)
         if ((rc = launch_mc_vienna(c, pin))) return rc;
         c->last_path = 2;
     } else if (c->has_mc && c->mode != RH_MODE_LOG && !skip_mc) {
-        if ((rc = run_graphed(c, c->g_in, shape_key(c, 0), c->s_mc, &c->n_launch[0], [&] { return launch_mc_lin_any(c, pin, 0); }))) return rc;
+        if ((rc = run_graphed(c, c->g_in, shape_key(c, 0), c->s_mc, &c->n_launch[0], &c->n_far[0], [&] { return launch_mc_lin_any(c, pin, 0); }))) return rc;
         HIP_TRY(c, hipEventRecord(c->ev[1], c->s_mc));
-        if ((rc = run_graphed(c, c->g_out, shape_key(c, 1), c->s_mc, &c->n_launch[1], [&] { return launch_mc_lin_any(c, pin, 1); }))) return rc;
+        if ((rc = run_graphed(c, c->g_out, shape_key(c, 1), c->s_mc, &c->n_launch[1], &c->n_far[1], [&] { return launch_mc_lin_any(c, pin, 1); }))) return rc;
         c->last_path = 1;
         if (c->mode == RH_MODE_AUTO) {  // did every sequence stay inside the double range?
             std::vector<int> bad(c->mc.ns);
@@ -705,6 +712,7 @@ int compute(rh_ctx* c)
     }
     if (need_log) {
         c->n_launch[0] = c->n_launch[1] = 0;
+        c->n_far[0] = c->n_far[1] = 0;
         HIP_TRY(c, hipEventRecord(c->ev[0], c->s_mc));
         HIP_TRY(c, hipMemsetAsync(c->d_bp, 0, sizeof(double) * c->mc.tri_stride * c->mc.ns, c->s_mc));
         if ((rc = launch_mc_log(c, pin))) return rc;
@@ -1085,6 +1093,35 @@ int rh_set_mode(rh_ctx* c, int mode)
 }
 
 int rh_last_path(const rh_ctx* c) { return c ? c->last_path : RH_ERR_ARG; }
+
+int rh_batch_kernels(rh_ctx* c, const char* fine[3], const char* far[3], int n_far[3])
+{
+    if (!c) return RH_ERR_ARG;
+    if (!c->computed) return fail(c, RH_ERR_ARG, "no computed batch");
+    static thread_local std::string names[6];
+    const std::string w = std::to_string(c->lin_w == 16 ? 16 : 8), bs = std::to_string(c->lin_bs == 0 || c->lin_bs == 32 ? c->lin_bs : 16);
+    const bool vienna = c->model == RH_MODEL_VIENNA_BL, lin = c->last_path == 1;
+    names[0] = !c->has_mc ? "" : vienna ? "mcv_inside_diag" : lin ? "lin_inside_diag<" + w + ", " + bs + ">" : "mc_inside_diag";
+    names[1] = !c->has_mc ? "" : vienna ? "mcv_outside_diag" : lin ? "lin_outside_diag<" + w + ", " + bs + ">" : "mc_outside_diag";
+    names[2] = !c->has_dx ? "" : vienna ? "dxv_sweep_diag" : c->last_dx_path == 1 ? "dxl_sweep<" + std::to_string(c->dx_w == 2 || c->dx_w == 8 ? c->dx_w : 4) + ">" : "dx_sweep_diag";
+    const bool mfma = c->far_mfma && c->lin_bs != 0 && c->lin_bs != 32;
+    names[3] = (c->has_mc && lin && c->n_far[0]) ? (mfma ? "lin_far_inside_mfma" : "lin_far_inside<" + bs + ">") : "";
+    names[4] = (c->has_mc && lin && c->n_far[1]) ? (mfma ? "lin_far_outside_mfma" : "lin_far_outside<" + bs + ">") : "";
+    names[5] = "";
+    for (int k = 0; k < 3; k++) {
+        if (fine) fine[k] = names[k].c_str();
+        if (far) far[k] = names[3 + k].c_str();
+        if (n_far) n_far[k] = c->n_far[k];
+    }
+    return RH_OK;
+}
+
+int rh_set_overlap(rh_ctx* c, int on)
+{
+    if (!c) return RH_ERR_ARG;
+    c->overlap = on != 0;
+    return RH_OK;
+}
 
 int rh_batch_timings(rh_ctx* c, double ms[4], int n_launch[3])
 {

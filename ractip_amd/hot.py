@@ -18,7 +18,7 @@ EXPORTS = [
     "rh_create", "rh_destroy", "rh_last_error", "rh_set_mode", "rh_last_path", "rh_bpp", "rh_unpaired", "rh_fold", "rh_duplex",
     "rh_batch_upload", "rh_batch_compute", "rh_batch_results", "rh_batch_candidates",
     "rh_batch_timings", "rh_batch_device_views", "rh_batch_logz", "rh_batch_candidates_all", "rh_batch_layout",
-    "rh_batch_results_all", "rh_set_max_w", "rh_get_max_w",
+    "rh_batch_results_all", "rh_set_max_w", "rh_get_max_w", "rh_set_overlap", "rh_batch_kernels",
 ]
 
 
@@ -52,6 +52,10 @@ def load_library():
     L.rh_set_mode.argtypes = [vp, ci]
     L.rh_set_mode.restype = ci
     L.rh_last_path.argtypes = [vp]
+    L.rh_set_overlap.argtypes = [vp, ci]
+    L.rh_batch_kernels.argtypes = [vp, vp, vp, vp]
+    L.rh_batch_kernels.restype = ci
+    L.rh_set_overlap.restype = ci
     L.rh_set_max_w.argtypes = [vp, ci]
     L.rh_set_max_w.restype = ci
     L.rh_get_max_w.argtypes = [vp]
@@ -222,6 +226,16 @@ class Context:
                 u1, u2 = u1.reshape(n1, w), u2.reshape(n2, w)
             out.append(dict(bp1=bp[2 * p][:tri_size(n1)], bp2=bp[2 * p + 1][:tri_size(n2)], up1=u1, up2=u2, hp=h, logZ=z[p]))
         return out
+
+    def set_overlap(self, on):
+        """False: phases run one after the other (isolated per-phase device times in batch_timings)."""
+        self._check(self.L.rh_set_overlap(self.h, 1 if on else 0))
+
+    def batch_kernels(self):
+        """[(per-diagonal kernel, block-product kernel or '', block-product launches)] for inside, outside, duplex."""
+        fine, far, nf = (ctypes.c_char_p * 3)(), (ctypes.c_char_p * 3)(), (ctypes.c_int * 3)()
+        self._check(self.L.rh_batch_kernels(self.h, fine, far, nf))
+        return [((fine[k] or b"").decode(), (far[k] or b"").decode(), nf[k]) for k in range(3)]
 
     def batch_timings(self):
         ms = (ctypes.c_double * 4)()

@@ -30,6 +30,18 @@ def test_single_gpu_line(hotlib):
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     assert "workload" in d["config"] and "model" in d["config"] and d["config"]["model"] is None
+    # the roofline kernel is a real kernel name with its own event-timed launch duration
+    assert rf["kernel"] in rf["kernels"] and rf["avg_launch_us"] > 0 and rf["alg_bytes_per_launch"] > 0
+    assert abs(rf["achieved"] - rf["alg_bytes_per_launch"] / 1e9 / (rf["avg_launch_us"] / 1e6)) < 1e-6 * rf["achieved"]
+    assert rf["kernel"].startswith(("lin_", "dxl_"))
+
+
+def test_vienna_model_line(hotlib):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--model", "vienna", "--n", "100", "--batch", "4",
+                        "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = last_json(r.stdout)
+    assert d["value"] > 0 and "Vienna-BL" in d["config"]["scoring"] and d["roofline"]["kernel"].startswith("mcv_")
 
 
 def test_two_ranks_on_one_gpu_gloo(hotlib):
