@@ -335,7 +335,11 @@ double vo_bruteforce(const vo_model* P, const char* s1, int n1, const char* s2, 
  *     FM2[i,j] = (+)_k FM1[i,k] + FM[k,j]                        FM[i,j]  = FM2[i,j] (+) FMS[i,j]
  * Validated independently by brute-force enumeration of all secondary structures.
  * =================================================================================================== */
-typedef struct { const vo_model* P; const int* S; int n; double sc; } mc_t;
+/* cut = 0: one molecule.  cut = n1 > 0: two molecules s1+s2 concatenated (co_pf_fold, src/ractip.cpp:400-458): the
+ * backbone gap between letters cut and cut+1 does not exist.  A loop whose backbone holds that gap is an exterior-like
+ * loop (only the stems' own dangle/TerminalAU terms count), dangles are never taken across it. */
+typedef struct { const vo_model* P; const int* S; int n; double sc; int cut; } mc_t;
+#define GAP_OK(c, g) ((c)->cut == 0 || (g) != (c)->cut)   /* letters g and g+1 are neighbours on one strand */
 
 static int tetra_bonus(const vo_model* P, const int* S, int a)
 {
@@ -370,17 +374,31 @@ static double e_mlclose(const mc_t* c, int a, int b)
     return P->ML_closing + P->ML_intern + P->d3x[tt][S[a + 1]] + P->d5x[tt][S[b - 1]];
 }
 static double e_stem(const mc_t* c, int p, int q)
-{   /* stem (p,q) in a multi or exterior loop, without ML_intern */
+{   /* stem (p,q) in a multi or exterior loop, without ML_intern; no dangle from a letter of the other molecule */
     const vo_model* P = c->P; const int* S = c->S;
     const int t = ptype(S[p], S[q]);
-    return P->d5x[t][S[p - 1]] + P->d3x[t][S[q + 1]];
+    return P->d5x[t][GAP_OK(c, p - 1) ? S[p - 1] : 0] + P->d3x[t][GAP_OK(c, q) ? S[q + 1] : 0];
+}
+static double e_nickclose(const mc_t* c, int a, int b)
+{   /* pair (a,b) closing the loop that holds the nick: an exterior stem seen from inside */
+    const vo_model* P = c->P; const int* S = c->S;
+    const int tt = RTYPE[ptype(S[a], S[b])];
+    return P->d3x[tt][GAP_OK(c, a) ? S[a + 1] : 0] + P->d5x[tt][GAP_OK(c, b - 1) ? S[b - 1] : 0];
 }
 
 /* post: T(n) triangular (reference layout) or NULL; up: n*max_w row-major, up[i*max_w+w] = P(letters i+1..i+1+w
  * unpaired) (0 where the region runs off the end) or NULL; tabs: 8*T log-space tables FCi,FMi,FM1i,FCo,FMo,FM1o,
  * FMSi,FMSo + f5: 2*(n+1) (F5i, F5o) or NULL.  Returns log Z (inside); *logz_out = outside log Z. */
+double vo_mccaskill_cut(const vo_model* P, const char* seq, int n, int cut, double* post, double* logz_out,
+                        double* up, int max_w, double* tabs, double* f5);
 double vo_mccaskill(const vo_model* P, const char* seq, int n, double* post, double* logz_out,
                     double* up, int max_w, double* tabs, double* f5)
+{
+    return vo_mccaskill_cut(P, seq, n, 0, post, logz_out, up, max_w, tabs, f5);
+}
+/* cut > 0: co_pf_fold semantics for s1 = seq[0..cut), s2 = seq[cut..n) (accessibility is not defined then: up must be NULL) */
+double vo_mccaskill_cut(const vo_model* P, const char* seq, int n, int cut, double* post, double* logz_out,
+                        double* up, int max_w, double* tabs, double* f5)
 {
     const int L = n;
     const long T = (long)(L + 1) * (L + 2) / 2;
@@ -388,41 +406,66 @@ double vo_mccaskill(const vo_model* P, const char* seq, int n, double* post, dou
     for (int i = 1; i <= L; i++) S[i] = vcode(seq[i - 1]);
     long* off = (long*)malloc(sizeof(long) * (L + 2));
     for (int i = 0; i <= L; i++) off[i] = (long)i * (2 * (L + 1) - i - 1) / 2;
-    double* buf = (double*)malloc(sizeof(double) * (8 * T + 2 * (L + 1)));
+    double* buf = (double*)malloc(sizeof(double) * (8 * T + 6 * (L + 2)));
     double *FCi = buf, *FMi = buf + T, *FM1i = buf + 2 * T, *FCo = buf + 3 * T, *FMo = buf + 4 * T, *FM1o = buf + 5 * T,
-           *FMSi = buf + 6 * T, *FMSo = buf + 7 * T, *F5i = buf + 8 * T, *F5o = buf + 8 * T + (L + 1);
-    for (long k = 0; k < 8 * T + 2 * (L + 1); k++) buf[k] = -INFINITY;
-    mc_t c = {P, S, L, 10.0 / P->kT};
+           *FMSi = buf + 6 * T, *FMSo = buf + 7 * T, *F5i = buf + 8 * T, *F5o = buf + 8 * T + (L + 1),
+           *XP = buf + 8 * T + 2 * (L + 2), *XS = XP + (L + 2), *XPo = XS + (L + 2), *XSo = XPo + (L + 2);
+    for (long k = 0; k < 8 * T + 6 * (L + 2); k++) buf[k] = -INFINITY;
+    mc_t c = {P, S, L, 10.0 / P->kT, cut};
+    if (cut > 0 && up) { free(buf); free(off); free(S); return NAN; }
+#define NICKED(i, j) (cut > 0 && (i) <= cut && cut <= (j))   /* the gap lies inside the pair (i, j+1) */
     const double sc = c.sc, mlb = -P->ML_base * sc, mli = -P->ML_intern * sc;
 #define PAIR(a, b) ((a) >= 1 && (b) <= L && ptype(S[a], S[b]))
     /* inside */
-    for (int i = L; i >= 0; i--)
+    for (int i = L; i >= 0; i--) {
+        if (cut > 0 && i == cut) {   /* rows > cut are final: exterior partition function of s2's prefixes cut+1..b */
+            XP[cut] = 0.0;
+            for (int b = cut + 1; b <= L; b++) {
+                double acc = XP[b - 1];
+                for (int k = cut; k < b; k++)
+                    if (PAIR(k + 1, b)) acc = logadd(acc, XP[k] + FCi[off[k + 1] + b - 1] - e_stem(&c, k + 1, b) * sc);
+                XP[b] = acc;
+            }
+            XS[cut + 1] = 0.0;
+        }
         for (int j = i; j <= L; j++) {
             double fm2 = -INFINITY;
             for (int k = i + 1; k < j; k++) fm2 = logadd(fm2, FM1i[off[i] + k] + FMi[off[k] + j]);
-            if (0 < i && j < L && PAIR(i, j + 1)) {
+            if (0 < i && j < L && j + 1 - i >= 4 && PAIR(i, j + 1)) {
                 double acc = -INFINITY;
-                if (j - i >= 3) acc = logadd(acc, -e_hairpin(&c, i, j + 1) * sc);
+                if (j - i >= 3 && !NICKED(i, j)) acc = logadd(acc, -e_hairpin(&c, i, j + 1) * sc);
                 for (int p = i; p <= (i + MAXLOOP < j ? i + MAXLOOP : j); p++) {
+                    if (NICKED(i, p)) break;                       /* 5' side i..p+1 must be one strand */
                     int qmin = p + 2 > p - i + j - MAXLOOP ? p + 2 : p - i + j - MAXLOOP;
                     for (int q = j; q >= qmin; q--) {
+                        if (NICKED(q, j)) continue;                /* 3' side q..j+1 */
                         if (!PAIR(p + 1, q)) continue;
                         acc = logadd(acc, FCi[off[p + 1] + q - 1] - e_interior(&c, i, j + 1, p + 1, q) * sc);
                     }
                 }
                 acc = logadd(acc, fm2 - e_mlclose(&c, i, j + 1) * sc);
+                if (NICKED(i, j)) acc = logadd(acc, XS[i + 1] + XP[j] - e_nickclose(&c, i, j + 1) * sc);
                 FCi[off[i] + j] = acc;
             }
             if (0 < i && i + 2 <= j && j < L) {
                 double acc = -INFINITY;
-                if (PAIR(i + 1, j)) acc = logadd(acc, FCi[off[i + 1] + j - 1] + mli - e_stem(&c, i + 1, j) * sc);
-                acc = logadd(acc, FM1i[off[i + 1] + j] + mlb);
+                if (PAIR(i + 1, j) && GAP_OK(&c, i) && GAP_OK(&c, j))
+                    acc = logadd(acc, FCi[off[i + 1] + j - 1] + mli - e_stem(&c, i + 1, j) * sc);
+                if (GAP_OK(&c, i) && GAP_OK(&c, i + 1)) acc = logadd(acc, FM1i[off[i + 1] + j] + mlb);
                 FM1i[off[i] + j] = acc;
-                const double fms = logadd(acc, FMSi[off[i] + j - 1] + mlb);
+                double fms = acc;
+                if (GAP_OK(&c, j - 1) && GAP_OK(&c, j)) fms = logadd(fms, FMSi[off[i] + j - 1] + mlb);
                 FMSi[off[i] + j] = fms;
                 FMi[off[i] + j] = logadd(fm2, fms);
             }
         }
+        if (cut > 0 && i >= 1 && i <= cut) {   /* row i is final: exterior partition function of s1's suffix i..cut */
+            double acc = XS[i + 1];
+            for (int l = i + 4; l <= cut; l++)
+                if (PAIR(i, l)) acc = logadd(acc, FCi[off[i] + l - 1] - e_stem(&c, i, l) * sc + XS[l + 1]);
+            XS[i] = acc;
+        }
+    }
     F5i[0] = 0.0;
     for (int j = 1; j <= L; j++) {
         double acc = F5i[j - 1];
@@ -442,23 +485,52 @@ double vo_mccaskill(const vo_model* P, const char* seq, int n, double* post, dou
             FCo[off[k + 1] + j - 1] = logadd(FCo[off[k + 1] + j - 1], t + F5i[k]);
         }
     }
-    for (int i = 0; i <= L; i++)
+    for (int i = 0; i <= L; i++) {
+        if (cut > 0 && i == cut + 1)   /* every pair around the nick has pushed into XPo: unwind the prefix recursion of s2 */
+            for (int b = L; b > cut; b--) {
+                if (!(XPo[b] > -INFINITY)) continue;
+                XPo[b - 1] = logadd(XPo[b - 1], XPo[b]);
+                for (int k = cut; k < b; k++) {
+                    if (!PAIR(k + 1, b)) continue;
+                    const double t = XPo[b] - e_stem(&c, k + 1, b) * sc;
+                    XPo[k] = logadd(XPo[k], t + FCi[off[k + 1] + b - 1]);
+                    FCo[off[k + 1] + b - 1] = logadd(FCo[off[k + 1] + b - 1], t + XP[k]);
+                }
+            }
+        if (cut > 0 && i >= 1 && i <= cut && XSo[i] > -INFINITY) {   /* XSo[i] is final (pushed by rows < i): unwind the suffix recursion */
+            XSo[i + 1] = logadd(XSo[i + 1], XSo[i]);
+            for (int l = i + 4; l <= cut; l++) {
+                if (!PAIR(i, l)) continue;
+                const double t = XSo[i] - e_stem(&c, i, l) * sc;
+                XSo[l + 1] = logadd(XSo[l + 1], t + FCi[off[i] + l - 1]);
+                FCo[off[i] + l - 1] = logadd(FCo[off[i] + l - 1], t + XS[l + 1]);
+            }
+        }
         for (int j = L; j >= i; j--) {
             double fm2o = -INFINITY;
             if (0 < i && i + 2 <= j && j < L) {
                 fm2o = logadd(fm2o, FMo[off[i] + j]);
                 FMSo[off[i] + j] = logadd(FMSo[off[i] + j], FMo[off[i] + j]);
-                FMSo[off[i] + j - 1] = logadd(FMSo[off[i] + j - 1], FMSo[off[i] + j] + mlb);
+                if (GAP_OK(&c, j - 1) && GAP_OK(&c, j))
+                    FMSo[off[i] + j - 1] = logadd(FMSo[off[i] + j - 1], FMSo[off[i] + j] + mlb);
                 FM1o[off[i] + j] = logadd(FM1o[off[i] + j], FMSo[off[i] + j]);
-                if (PAIR(i + 1, j))
+                if (PAIR(i + 1, j) && GAP_OK(&c, i) && GAP_OK(&c, j))
                     FCo[off[i + 1] + j - 1] = logadd(FCo[off[i + 1] + j - 1], FM1o[off[i] + j] + mli - e_stem(&c, i + 1, j) * sc);
-                FM1o[off[i + 1] + j] = logadd(FM1o[off[i + 1] + j], FM1o[off[i] + j] + mlb);
+                if (GAP_OK(&c, i) && GAP_OK(&c, i + 1))
+                    FM1o[off[i + 1] + j] = logadd(FM1o[off[i + 1] + j], FM1o[off[i] + j] + mlb);
             }
-            if (0 < i && j < L && PAIR(i, j + 1)) {
+            if (0 < i && j < L && j + 1 - i >= 4 && PAIR(i, j + 1)) {
                 const double fco = FCo[off[i] + j];
+                if (NICKED(i, j)) {
+                    const double t = fco - e_nickclose(&c, i, j + 1) * sc;
+                    XSo[i + 1] = logadd(XSo[i + 1], t + XP[j]);
+                    XPo[j] = logadd(XPo[j], t + XS[i + 1]);
+                }
                 for (int p = i; p <= (i + MAXLOOP < j ? i + MAXLOOP : j); p++) {
+                    if (NICKED(i, p)) break;
                     int qmin = p + 2 > p - i + j - MAXLOOP ? p + 2 : p - i + j - MAXLOOP;
                     for (int q = j; q >= qmin; q--) {
+                        if (NICKED(q, j)) continue;
                         if (!PAIR(p + 1, q)) continue;
                         FCo[off[p + 1] + q - 1] = logadd(FCo[off[p + 1] + q - 1], fco - e_interior(&c, i, j + 1, p + 1, q) * sc);
                     }
@@ -470,11 +542,12 @@ double vo_mccaskill(const vo_model* P, const char* seq, int n, double* post, dou
                 FMo[off[k] + j] = logadd(FMo[off[k] + j], fm2o + FM1i[off[i] + k]);
             }
         }
+    }
     if (post) {
         for (long k = 0; k < T; k++) post[k] = 0.0;
         for (int i = 1; i <= L; i++)
             for (int j = i; j < L; j++)
-                if (PAIR(i, j + 1)) {
+                if (j + 1 - i >= 4 && PAIR(i, j + 1)) {
                     const double e = FCo[off[i] + j] + FCi[off[i] + j] - Z;
                     post[off[i] + j + 1] = e > -INFINITY ? exp(e) : 0.0;
                 }
@@ -538,6 +611,7 @@ double vo_mccaskill(const vo_model* P, const char* seq, int n, double* post, dou
         free(Hs); free(GL); free(GR);
     }
 #undef PAIR
+#undef NICKED
     if (logz_out) *logz_out = F5o[0];
     if (tabs) memcpy(tabs, buf, sizeof(double) * 8 * T);
     if (f5) memcpy(f5, F5i, sizeof(double) * 2 * (L + 1));
@@ -552,12 +626,18 @@ static double loop_logw(const sbf_t* b, int a, int bb)
 {   /* log weight of the loop closed by (a,bb) and of everything nested in it */
     const mc_t* c = &b->c;
     int stems = 0, unpaired = 0, sp[64], sq[64];
+    int nick = 0;   /* does the loop's own backbone hold the gap between the two molecules? */
     for (int x = a + 1; x < bb;) {
+        if (c->cut > 0 && x - 1 == c->cut) nick = 1;          /* gap x-1 precedes the element starting at x */
         if (b->pt[x] > x) { sp[stems] = x; sq[stems] = b->pt[x]; stems++; x = b->pt[x] + 1; }
         else { unpaired++; x++; }
     }
+    if (c->cut > 0 && bb - 1 == c->cut) nick = 1;
     double lw = 0.0;
-    if (stems == 0) lw = -e_hairpin(c, a, bb) * c->sc;
+    if (nick) {
+        lw = -e_nickclose(c, a, bb) * c->sc;
+        for (int k = 0; k < stems; k++) lw += -e_stem(c, sp[k], sq[k]) * c->sc;
+    } else if (stems == 0) lw = -e_hairpin(c, a, bb) * c->sc;
     else if (stems == 1) {
         if (unpaired > MAXLOOP) return -INFINITY;
         lw = -e_interior(c, a, bb, sp[0], sq[0]) * c->sc;
@@ -604,12 +684,17 @@ static void sbf_rec(sbf_t* b, int pos)
     }
     b->pt[pos] = 0;
 }
+double vo_fold_bruteforce_cut(const vo_model* P, const char* seq, int n, int cut, double* post, double* up, int max_w);
 double vo_fold_bruteforce(const vo_model* P, const char* seq, int n, double* post, double* up, int max_w)
+{
+    return vo_fold_bruteforce_cut(P, seq, n, 0, post, up, max_w);
+}
+double vo_fold_bruteforce_cut(const vo_model* P, const char* seq, int n, int cut, double* post, double* up, int max_w)
 {
     int* S = (int*)calloc(n + 3, sizeof(int));
     for (int i = 1; i <= n; i++) S[i] = vcode(seq[i - 1]);
     sbf_t b;
-    b.c.P = P; b.c.S = S; b.c.n = n; b.c.sc = 10.0 / P->kT;
+    b.c.P = P; b.c.S = S; b.c.n = n; b.c.sc = 10.0 / P->kT; b.c.cut = cut;
     b.pt = (int*)calloc(n + 2, sizeof(int));
     b.Z = 0.0;
     const long T = (long)(n + 1) * (n + 2) / 2;

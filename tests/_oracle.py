@@ -153,6 +153,11 @@ class ViennaOracle:
                                    ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         L.vo_fold_bruteforce.restype = ctypes.c_double
         L.vo_fold_bruteforce.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        L.vo_mccaskill_cut.restype = ctypes.c_double
+        L.vo_mccaskill_cut.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                       ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        L.vo_fold_bruteforce_cut.restype = ctypes.c_double
+        L.vo_fold_bruteforce_cut.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         self.L = L
         self.m = L.vo_load(os.path.join(ROOT, "ractip_amd", "data", "vienna_bl_star.params").encode())
         assert self.m
@@ -169,6 +174,26 @@ class ViennaOracle:
                                 up.ctypes.data if max_w else None, max_w,
                                 tabs.ctypes.data if tables else None, f5.ctypes.data if tables else None)
         return dict(logZ=z, logZ_out=zo.value, post=post, up=up, tables=tabs, f5=f5)
+
+    def cofold(self, s1, s2, bruteforce=False):
+        """co_pf_fold semantics on s1+s2 (cut after s1): logZ of the two-molecule ensemble, the full pair matrix of the
+        concatenation (triangular, reference layout) and the intermolecular block hp[i][j] = P(s1[i] pairs s2[j]),
+        (n1+1) x (n2+1), 1-based, the layout of src/ractip.cpp:451-454."""
+        n1, n2 = len(s1), len(s2)
+        n = n1 + n2
+        post = np.zeros(tri_size(n))
+        zo = ctypes.c_double()
+        seq = (s1 + s2).encode()
+        if bruteforce:
+            z = self.L.vo_fold_bruteforce_cut(self.m, seq, n, n1, post.ctypes.data, None, 0)
+            zo.value = z
+        else:
+            z = self.L.vo_mccaskill_cut(self.m, seq, n, n1, post.ctypes.data, ctypes.byref(zo), None, 0, None, None)
+        hp = np.zeros((n1 + 1, n2 + 1))
+        for i in range(1, n1 + 1):
+            o = tri_offset(n, i)
+            hp[i, 1:] = post[o + n1 + 1:o + n + 1]
+        return dict(logZ=z, logZ_out=zo.value, post=post, hp=hp)
 
     def fold_bruteforce(self, seq, max_w=0):
         n = len(seq)

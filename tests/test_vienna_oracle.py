@@ -89,3 +89,36 @@ def test_mccaskill_invariants_on_bundled_sequences(vo, golden):
         # wider regions are less accessible; regions running off the end are 0
         assert (np.diff(up, axis=1) <= 1e-12).all()
         assert up[n - 1, 1] == 0 and up[n - 3, 3] == 0
+
+
+# ---- two-molecule ensemble (co_pf_fold semantics, src/ractip.cpp:400-458; PARITY UNPINNED) ------------------------
+def test_cofold_equals_bruteforce_enumeration(vo):
+    """log Z, the full pair matrix of s1+s2 and hence hp == explicit enumeration of every joint structure, where the
+    loop that holds the gap between the molecules is exterior-like and no dangle crosses it."""
+    rng = np.random.RandomState(11)
+    cases = [("GGGAAACCC", "GGGUUUCCC"), ("GGGG", "CCCC"), ("G", "C"), ("GGGAC", "GUCCC"), ("GCGCAAAGCGC", "GGGAAACCCA"),
+             ("GGGAAACCCAGG", "CCUGGGAAACCC"), ("GGAGGAAACUCC", "GGAGGAAACUCC"), ("GGGAAACCCAGGGAAACCCA", "UGGG"),
+             ("CCCA", "GGGAAACCCAGGGAAACCCAUGGG")]
+    for n1, n2 in ((3, 5), (6, 6), (8, 9), (12, 10), (11, 13), (13, 12), (5, 20), (14, 13)):
+        for _ in range(2):
+            cases.append(("".join(rng.choice(list("ACGU"), n1, p=[.15, .35, .35, .15])),
+                          "".join(rng.choice(list("ACGU"), n2, p=[.15, .35, .35, .15]))))
+    for s1, s2 in cases:
+        a, b = vo.cofold(s1, s2), vo.cofold(s1, s2, bruteforce=True)
+        assert abs(a["logZ"] - b["logZ"]) < 1e-11, (s1, s2)
+        assert abs(a["logZ"] - a["logZ_out"]) < 1e-11, (s1, s2)
+        assert np.abs(a["post"] - b["post"]).max() < 1e-11, (s1, s2)
+
+
+def test_cofold_limits(vo, golden):
+    # a molecule that cannot pair with its partner folds as if alone: Z factorises
+    a, b = "GGGAAACCCAGGGAAACCCA", "AAAAAAAA"
+    zab = vo.cofold(a, b)["logZ"]
+    assert abs(zab - vo.mccaskill(a)["logZ"] - vo.mccaskill(b)["logZ"]) < 1e-10
+    # bundled pair: inside == outside, probabilities sane, hp rows/columns are distributions
+    s1, s2 = str(golden["mc/CopA/seq"]), str(golden["mc/CopT/seq"])
+    r = vo.cofold(s1, s2)
+    assert abs(r["logZ"] - r["logZ_out"]) < 1e-9 * abs(r["logZ"])
+    hp = r["hp"]
+    assert hp.min() >= 0 and hp.sum(axis=1).max() <= 1 + 1e-9 and hp.sum(axis=0).max() <= 1 + 1e-9
+    assert hp.max() > 0.9     # fully complementary antisense pair
