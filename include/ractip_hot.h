@@ -82,6 +82,16 @@ int rh_unpaired(rh_ctx* ctx, const char* seq, int n, int max_w, double* up);
 int rh_set_max_w(rh_ctx* ctx, int max_w);
 int rh_get_max_w(const rh_ctx* ctx);
 
+/* Source of the hybridization matrix hp under RH_MODEL_VIENNA_BL (rh_duplex and the batched form):
+ *   RH_HYBRID_DUPLEX (default): pf_duplex -- duplexes only, the --duplex branch (src/ractip.cpp:390-398);
+ *   RH_HYBRID_COFOLD: the joint ensemble of both molecules, the default branch (src/ractip.cpp:400-458):
+ *     co_pf_fold(s1+s2) with cut_point = n1+1, hp[i][j] = pr(i, n1+j).  The reference keeps only entries
+ *     with p > th_hy (assign_plist_from_pr); this ABI returns the dense block and the adapter thresholds.
+ *     logZ = log partition function of the two-molecule ensemble.  PARITY UNPINNED like the rest of this model. */
+#define RH_HYBRID_DUPLEX 0
+#define RH_HYBRID_COFOLD 1
+int rh_set_hybrid(rh_ctx* ctx, int hybrid);
+
 /* Both of the above from ONE inside/outside pass -- the whole of RactIP::contrafold (src/ractip.cpp:199-222) or of
  * the accessibility overload of RactIP::rnafold (src/ractip.cpp:308-382).  bp_tri, up (n*max_w doubles, max_w as set
  * by rh_set_max_w) or logZ may be NULL. */

@@ -35,7 +35,7 @@ enum McTable {
     T_COUNT
 };
 
-constexpr int kViennaMcTables = 15;   // VmTable of mccaskill_vienna.hip (own enum, same square layout)
+constexpr int kViennaMcTables = 16;   // VmTable of mccaskill_vienna.hip (own enum, same square layout)
 
 struct McBatch {
     const uint8_t* seq;  // [NS][lds] nucleotide codes, seq[0] = seq[n+1] = 4
@@ -45,6 +45,14 @@ struct McBatch {
     double* f5o;         // [NS][ld]  F5o[0..n]
     double* bp;          // [NS][tri_stride] posterior, reference triangular layout
     double* up;          // [NS][ld*max_w]  up[i*max_w+w] = P(letters i+1..i+1+w unpaired); max_w = 1 for the CONTRAfold model
+    // two-molecule form (co_pf_fold semantics, mccaskill_vienna.hip only): cut[sq] = n1 > 0 means the sequence is s1+s2
+    // and the backbone gap after letter n1 does not exist; xp/xs = exterior partition functions of s2's prefixes
+    // cut+1..b and s1's suffixes a..cut, xpo/xso their outside counterparts.  cut == nullptr: one molecule each.
+    const int* cut;      // [NS] or nullptr
+    double* xp;          // [NS][ld]
+    double* xs;
+    double* xpo;
+    double* xso;
     int ns, nmax, ld, lds;
     size_t tab_stride;   // doubles per table  (ld*ld)
     size_t seq_stride;   // doubles per sequence (T_COUNT*ld*ld)

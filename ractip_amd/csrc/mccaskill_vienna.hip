@@ -16,7 +16,12 @@
 //   * accessibility from the finished inside/outside tables: a run of unpaired letters a..b lies in exactly one loop,
 //         E: F5i[a-1] F5o[b]      H: sum_{p<a,q>b} FCo(p,q) hairpin(p,q)     I: runs inside the left / right gap of an
 //         interior loop           M: FM1o[a-1,j] b^len FM1[b,j]  (before a branch),  FMSo[i,b] b^len FMS[i,a-1] (trailing)
-//     all divided by Z; the sums run over probabilities in linear space.
+//     all divided by Z; the sums run over probabilities in linear space;
+//   * the two-molecule ensemble of co_pf_fold (/root/reference/src/ractip.cpp:400-458: hp from the joint pair matrix of
+//     s1+s2): McBatch::cut marks the backbone gap that does not exist.  A loop whose backbone holds it is
+//     exterior-like -- for the pair (i,j+1) around it: XS[i+1] + XP[j] + the pair's own dangles, with XS / XP the
+//     exterior partition functions of s1's suffixes / s2's prefixes, one extra wavefront each per diagonal -- no
+//     hairpin, interior loop side, multiloop backbone or dangle may cross it.  cut = 0 reproduces the one-molecule case.
 #include <hip/hip_runtime.h>
 
 #include "batch.h"
@@ -27,10 +32,10 @@ namespace rh {
 
 // square ld x ld tables per sequence; *T = stored transposed ([j][i])
 enum VmTable { VM_FC = 0, VM_FCX, VM_FCA, VM_FCAT, VM_FM1, VM_FM1T, VM_FM, VM_FMT, VM_FMST,
-               VM_FCO, VM_FCOX, VM_FM2O, VM_FM2OT, VM_FMSOT, VM_FM1O, VM_COUNT };
+               VM_FCO, VM_FCOX, VM_FM2O, VM_FM2OT, VM_FMSOT, VM_FM1O, VM_FCOT, VM_COUNT };
 // scratch slots of the accessibility pass (their sweep contents are dead by then)
 constexpr int VM_S_FCT = VM_FCAT;    // FC transposed
-constexpr int VM_S_FCOT = VM_FM2OT;  // FCo transposed
+constexpr int VM_S_FCOT = VM_FCOT;   // FCo transposed (written by the outside cells themselves)
 constexpr int VM_S_HP = VM_FCX;      // hairpin probabilities [p][q] -> exclusive prefix sums over p
 static_assert((int)VM_COUNT == kViennaMcTables, "batch.h and mccaskill_vienna.hip disagree on the table count");
 
@@ -42,6 +47,10 @@ __device__ __forceinline__ void block_map_v(int pin, int* sq, int* slot)
     *slot = pin ? blockIdx.y : blockIdx.x;
 }
 __device__ __forceinline__ size_t tri_offset_v(int n, int i) { return (size_t)i * (size_t)(2 * (n + 1) - i - 1) / 2; }
+// letters g and g+1 are neighbours on one strand
+__device__ __forceinline__ bool gap_ok(int cut, int g) { return g != cut; }   // cut = 0 never equals a gap index >= 1
+// the missing gap lies among gaps lo..hi
+__device__ __forceinline__ bool nicked(int cut, int lo, int hi) { return cut > 0 && lo <= cut && cut <= hi; }
 
 // index of shape (l1,l2) in the row-major shape list of ViennaDx
 __device__ __forceinline__ int shape_index(int l1, int l2) { return l1 * 31 - l1 * (l1 - 1) / 2 + l2; }
@@ -79,8 +88,18 @@ __global__ void mcv_init(McBatch B)
 {
     const int sq = blockIdx.x * blockDim.x + threadIdx.x;
     if (sq >= B.ns) return;
+    const int n = B.n[sq];
     B.f5i[(size_t)sq * B.ld] = 0.0;
-    B.f5o[(size_t)sq * B.ld + B.n[sq]] = 0.0;
+    B.f5o[(size_t)sq * B.ld + n] = 0.0;
+    const int cut = B.cut ? B.cut[sq] : 0;
+    if (cut > 0) {
+        const size_t o = (size_t)sq * B.ld;
+        B.xp[o + cut] = 0.0;          // empty prefix of s2
+        B.xs[o + cut + 1] = 0.0;      // empty suffix of s1
+        B.xpo[o + n] = kNeg;          // no pair (i, n+1) exists
+        B.xso[o + 1] = kNeg;          // no pair (0, j) exists
+        B.xso[o + cut + 1] = kNeg;
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -94,7 +113,8 @@ __global__ __launch_bounds__(256) void mcv_inside_diag(McBatch B, const ViennaDx
     const int wave = slot * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int ncell = n - 1 - d > 0 ? n - 1 - d : 0;
-    if (d > n - 1 || wave > ncell) return;
+    const int cut = B.cut ? B.cut[sq] : 0;
+    if (d > n - 1 || wave > ncell + (cut > 0 ? 2 : 0)) return;
 
     const int ld = B.ld;
     const uint8_t* __restrict__ s = B.seq + (size_t)sq * B.lds;
@@ -102,6 +122,32 @@ __global__ __launch_bounds__(256) void mcv_inside_diag(McBatch B, const ViennaDx
     double* __restrict__ f5i = B.f5i + (size_t)sq * ld;
     const size_t ts = B.tab_stride;
 
+    if (wave == ncell + 1) {
+        // XP[b], b = cut+d+1: exterior partition function of s2's prefix cut+1..b (its stems have spans <= d-1)
+        const int b = cut + d + 1;
+        if (b > n) return;
+        double* __restrict__ xp = B.xp + (size_t)sq * ld;
+        const double* __restrict__ fcat = tab + VM_FCAT * ts + (size_t)(b - 1) * ld;
+        Lse acc = lse_empty();
+        lse_stream2<4>(acc, xp, fcat + 1, cut, b - 1, lane);
+        if (lane == 0) lse_add(acc, xp[b - 1]);
+        const double v = lse_wave_finish(acc);
+        if (lane == 0) xp[b] = v;
+        return;
+    }
+    if (wave == ncell + 2) {
+        // XS[a], a = cut-d: exterior partition function of s1's suffix a..cut: XS[a+1] (+) FCA[a][l-1] + XS[l+1]
+        const int a = cut - d;
+        if (a < 1) return;
+        double* __restrict__ xs = B.xs + (size_t)sq * ld;
+        const double* __restrict__ fca = tab + VM_FCA * ts + (size_t)a * ld;
+        Lse acc = lse_empty();
+        lse_stream2<4>(acc, fca, xs + 2, a + 3, cut, lane);   // index t = l-1
+        if (lane == 0) lse_add(acc, xs[a + 1]);
+        const double v = lse_wave_finish(acc);
+        if (lane == 0) xs[a] = v;
+        return;
+    }
     if (wave == ncell) {
         // q[1,jj] = q[1,jj-1] + sum_k q[1,k] * qb(k+1,jj) * dangles            (exterior stems carry no other term)
         const int jj = d + 1;
@@ -121,12 +167,15 @@ __global__ __launch_bounds__(256) void mcv_inside_diag(McBatch B, const ViennaDx
     const int rt = V->rtype[type];
     const bool inner = d >= 2;
     const double tau_here = type > 2 ? V->tau : 0.0;
+    const bool nick_in = nicked(cut, i, j);   // the missing gap lies inside the pair (i, j+1)
 
     double op_fca = kNeg, op_fm1 = kNeg, op_fms = kNeg;
     if (inner) {
-        op_fca = tab[VM_FCA * ts + (size_t)(i + 1) * ld + (j - 1)];
-        op_fm1 = tab[VM_FM1 * ts + (size_t)(i + 1) * ld + j];
-        op_fms = tab[VM_FMST * ts + (size_t)(j - 1) * ld + i];
+        // a multiloop element may not touch the missing gap: a branch checks the gaps on both of its sides, an
+        // unpaired letter the two gaps next to it
+        if (gap_ok(cut, i) && gap_ok(cut, j)) op_fca = tab[VM_FCA * ts + (size_t)(i + 1) * ld + (j - 1)];
+        if (gap_ok(cut, i) && gap_ok(cut, i + 1)) op_fm1 = tab[VM_FM1 * ts + (size_t)(i + 1) * ld + j];
+        if (gap_ok(cut, j - 1) && gap_ok(cut, j)) op_fms = tab[VM_FMST * ts + (size_t)(j - 1) * ld + i];
     }
 
     // ---- loops with one enclosed pair (p,q) = (i+1+l1, j-l2): qb(i,j+1) += qb(p,q) * expLoopEnergy
@@ -140,7 +189,8 @@ __global__ __launch_bounds__(256) void mcv_inside_diag(McBatch B, const ViennaDx
             const Shape sh = V->shape[64 * u + lane];
             const int kind = V->kind[64 * u + lane];
             x[u] = kEmptyMax;
-            if (sh.l1 + sh.l2 <= tmax) {
+            // both sides of the loop (letters i..p and q..j+1) must lie on one strand each
+            if (sh.l1 + sh.l2 <= tmax && !nicked(cut, i, i + sh.l1) && !nicked(cut, j - sh.l2, j)) {
                 const int p = i + 1 + sh.l1, q = j - sh.l2;
                 const size_t at = (size_t)p * ld + (q - 1);
                 if (kind == 1) x[u] = tab[VM_FCX * ts + at] + sh.score + mm_out;
@@ -153,7 +203,12 @@ __global__ __launch_bounds__(256) void mcv_inside_diag(McBatch B, const ViennaDx
         }
         lse_add_group<kMcShapeIters>(acc_c, x);
     }
-    if (pairable && lane == 0 && d >= kMinHairpin) lse_add(acc_c, hairpin_w(V, s, i, d, type));
+    if (pairable && lane == 0 && d >= kMinHairpin) {
+        if (!nick_in) lse_add(acc_c, hairpin_w(V, s, i, d, type));
+        else   // the loop that holds the missing gap: two exterior-loop halves and the pair's own dangles
+            lse_add(acc_c, B.xs[(size_t)sq * ld + i + 1] + B.xp[(size_t)sq * ld + j] +
+                               V->d3x[rt * 5 + (gap_ok(cut, i) ? s_ip1 : 0)] + V->d5x[rt * 5 + (gap_ok(cut, j) ? s_j : 0)]);
+    }
 
     // ---- FM2[i,j] = (+)_{i<k<j} FM1[i,k] + FM[k,j]
     Lse acc_2 = lse_empty();
@@ -176,7 +231,7 @@ __global__ __launch_bounds__(256) void mcv_inside_diag(McBatch B, const ViennaDx
         const size_t ij = (size_t)i * ld + j, ji = (size_t)j * ld + i;
         // as the enclosed pair of a generic loop: mismatchI[rtype][S[q+1]][S[p-1]]; as a stem: dangles on both sides
         const double dec_x = V->mmI[rt * 25 + s_jp2 * 5 + s_im1];
-        const double dec_a = V->d5x[type * 5 + s_im1] + V->d3x[type * 5 + s_jp2];
+        const double dec_a = V->d5x[type * 5 + (gap_ok(cut, i - 1) ? s_im1 : 0)] + V->d3x[type * 5 + (gap_ok(cut, j + 1) ? s_jp2 : 0)];
         tab[VM_FC * ts + ij] = fc;
         tab[VM_FCX * ts + ij] = pairable ? fc + dec_x : kNeg;
         const double fca = pairable ? fc + dec_a : kNeg;
@@ -201,7 +256,8 @@ __global__ __launch_bounds__(256) void mcv_outside_diag(McBatch B, const ViennaD
     const int wave = slot * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int ncell = n - 1 - d;
-    if (ncell < 1 || wave > ncell) return;
+    const int cut = B.cut ? B.cut[sq] : 0;
+    if (ncell < 1 || wave > ncell + (cut > 0 ? 2 : 0)) return;
 
     const int ld = B.ld;
     const uint8_t* __restrict__ s = B.seq + (size_t)sq * B.lds;
@@ -210,6 +266,46 @@ __global__ __launch_bounds__(256) void mcv_outside_diag(McBatch B, const ViennaD
     double* __restrict__ f5o = B.f5o + (size_t)sq * ld;
     const size_t ts = B.tab_stride;
 
+    if (wave == ncell + 1) {
+        // XPo[b], b = cut+d+1 <= n-1: pairs (i, b+1) around the missing gap (spans >= d+1, final) (+) XPo[b+1] (+) stems (b+1, b')
+        const int b = cut + d + 1;
+        if (b > n - 1) return;
+        double* __restrict__ xpo = B.xpo + (size_t)sq * ld;
+        const double* __restrict__ xs = B.xs + (size_t)sq * ld;
+        const double* __restrict__ fcot = tab + VM_FCOT * ts + (size_t)b * ld;   // FCo[i][b] at [i]
+        Lse acc = lse_empty();
+        for (int i = 1 + lane; i <= cut; i += 64) {
+            const int t = V->ptype[s[i] * 5 + s[b + 1]];
+            if (!t || b + 1 - i < 4) continue;
+            const int rt = V->rtype[t];
+            lse_add(acc, fcot[i] + xs[i + 1] + V->d3x[rt * 5 + (gap_ok(cut, i) ? s[i + 1] : 0)] + V->d5x[rt * 5 + (gap_ok(cut, b) ? s[b] : 0)]);
+        }
+        lse_stream2<4>(acc, xpo + 1, tab + VM_FCA * ts + (size_t)(b + 1) * ld, b + 1, n, lane);
+        if (lane == 0) lse_add(acc, xpo[b + 1]);
+        const double v = lse_wave_finish(acc);
+        if (lane == 0) xpo[b] = v;
+        return;
+    }
+    if (wave == ncell + 2) {
+        // XSo[a], a = cut-d >= 2: pairs (a-1, j+1) around the missing gap (+) XSo[a-1] (+) stems (a', a-1) before it
+        const int a = cut - d;
+        if (a < 2) return;
+        double* __restrict__ xso = B.xso + (size_t)sq * ld;
+        const double* __restrict__ xp = B.xp + (size_t)sq * ld;
+        const double* __restrict__ fco = tab + VM_FCO * ts + (size_t)(a - 1) * ld;   // FCo[a-1][j]
+        Lse acc = lse_empty();
+        for (int j = cut + lane; j <= n - 1; j += 64) {
+            const int t = V->ptype[s[a - 1] * 5 + s[j + 1]];
+            if (!t || j + 1 - (a - 1) < 4) continue;
+            const int rt = V->rtype[t];
+            lse_add(acc, fco[j] + xp[j] + V->d3x[rt * 5 + (gap_ok(cut, a - 1) ? s[a] : 0)] + V->d5x[rt * 5 + (gap_ok(cut, j) ? s[j] : 0)]);
+        }
+        if (a >= 3) lse_stream2<4>(acc, xso, tab + VM_FCAT * ts + (size_t)(a - 2) * ld, 1, a - 1, lane);   // a' = 1..a-2
+        if (lane == 0) lse_add(acc, xso[a - 1]);
+        const double v = lse_wave_finish(acc);
+        if (lane == 0) xso[a] = v;
+        return;
+    }
     if (wave == ncell) {
         const int k = d + 1;
         const double* __restrict__ fca = tab + VM_FCA * ts + (size_t)(k + 1) * ld;
@@ -229,22 +325,26 @@ __global__ __launch_bounds__(256) void mcv_outside_diag(McBatch B, const ViennaD
     const int rt = V->rtype[type];
     const double tau_here = type > 2 ? V->tau : 0.0;
 
-    double op_fmso = kNeg, op_fm1o = kNeg, op_fm1o_up = kNeg, op_f5o = kNeg, op_f5i = kNeg;
+    double op_fmso = kNeg, op_fm1o = kNeg, op_fm1o_up = kNeg, op_f5o = kNeg, op_f5i = kNeg, op_x = kNeg;
     if (guard_m) {
-        if (j + 1 <= n - 1) op_fmso = tab[VM_FMSOT * ts + (size_t)(j + 1) * ld + i];
-        if (i - 1 >= 1) op_fm1o = tab[VM_FM1O * ts + (size_t)(i - 1) * ld + j];
+        if (j + 1 <= n - 1 && gap_ok(cut, j) && gap_ok(cut, j + 1)) op_fmso = tab[VM_FMSOT * ts + (size_t)(j + 1) * ld + i];
+        if (i - 1 >= 1 && gap_ok(cut, i - 1) && gap_ok(cut, i)) op_fm1o = tab[VM_FM1O * ts + (size_t)(i - 1) * ld + j];
     }
     if (pairable) {
         op_f5o = f5o[j + 1];
         op_f5i = f5i[i - 1];
-        if (i - 1 >= 1 && j + 1 <= n - 1) op_fm1o_up = tab[VM_FM1O * ts + (size_t)(i - 1) * ld + (j + 1)];
+        if (i - 1 >= 1 && j + 1 <= n - 1 && gap_ok(cut, i - 1) && gap_ok(cut, j + 1))
+            op_fm1o_up = tab[VM_FM1O * ts + (size_t)(i - 1) * ld + (j + 1)];
+        // stem of one of the exterior-loop halves of a loop around the missing gap
+        if (cut > 0 && i > cut) op_x = B.xpo[(size_t)sq * ld + j + 1] + B.xp[(size_t)sq * ld + i - 1];
+        if (cut > 0 && j + 1 <= cut) op_x = B.xso[(size_t)sq * ld + i] + B.xs[(size_t)sq * ld + j + 2];
     }
     const double fc_in = tab[VM_FC * ts + (size_t)i * ld + j];
     const double Z = f5i[n];
 
     // ---- enclosing loops: outer pair (i-1-l1, j+2+l2) [letters], gap cell (i-1-l1, j+1+l2)
     Lse acc_c = lse_empty();
-    const double dec_a = V->d5x[type * 5 + s_im1] + V->d3x[type * 5 + s_jp2];
+    const double dec_a = V->d5x[type * 5 + (gap_ok(cut, i - 1) ? s_im1 : 0)] + V->d3x[type * 5 + (gap_ok(cut, j + 1) ? s_jp2 : 0)];
     if (pairable) {
         const double dec_in = V->mmI[rt * 25 + s_jp2 * 5 + s_im1];
         const int l1max = i - 2, l2max = n - 2 - j;
@@ -255,7 +355,7 @@ __global__ __launch_bounds__(256) void mcv_outside_diag(McBatch B, const ViennaD
                 const Shape sh = V->shape[64 * u + lane];
                 const int kind = V->kind[64 * u + lane];
                 x[u] = kEmptyMax;
-                if (sh.l1 <= l1max && sh.l2 <= l2max) {
+                if (sh.l1 <= l1max && sh.l2 <= l2max && !nicked(cut, i - 1 - sh.l1, i - 1) && !nicked(cut, j + 1, j + 1 + sh.l2)) {
                     const int io = i - 1 - sh.l1, jo = j + 1 + sh.l2;
                     const size_t at = (size_t)io * ld + jo;
                     if (kind == 1) x[u] = tab[VM_FCOX * ts + at] + sh.score + dec_in;
@@ -271,6 +371,7 @@ __global__ __launch_bounds__(256) void mcv_outside_diag(McBatch B, const ViennaD
         if (lane == 0) {
             lse_add(acc_c, op_f5o + op_f5i + dec_a);            // stem of the exterior loop
             lse_add(acc_c, op_fm1o_up + V->mli + dec_a);        // branch of a multiloop
+            lse_add(acc_c, op_x + dec_a);
         }
     }
 
@@ -296,6 +397,7 @@ __global__ __launch_bounds__(256) void mcv_outside_diag(McBatch B, const ViennaD
     if (lane == 0) {
         const size_t ij = (size_t)i * ld + j, ji = (size_t)j * ld + i;
         tab[VM_FCO * ts + ij] = fco;
+        tab[VM_FCOT * ts + ji] = fco;
         tab[VM_FCOX * ts + ij] = pairable ? fco + V->mmI[type * 25 + s_ip1 * 5 + s_j] : kNeg;
         tab[VM_FM2O * ts + ij] = fm2o;
         tab[VM_FM2OT * ts + ji] = fm2o;
@@ -304,7 +406,7 @@ __global__ __launch_bounds__(256) void mcv_outside_diag(McBatch B, const ViennaD
         const double e = fco + fc_in - Z;
         double p = e > kNeg / 2 ? exp(e) : 0.0;
         p = p > 1.0 ? 1.0 : p;
-        B.bp[(size_t)sq * B.tri_stride + tri_offset_v(n, i) + (j + 1)] = pairable ? p : 0.0;
+        B.bp[(size_t)sq * B.tri_stride + tri_offset_v(n, i) + (j + 1)] = (pairable && d >= kMinHairpin) ? p : 0.0;
     }
 }
 
@@ -322,9 +424,10 @@ __global__ __launch_bounds__(256) void mcv_acc_prep(McBatch B, const ViennaDx* _
     double* __restrict__ tab = B.tab + (size_t)sq * B.seq_stride;
     const size_t ts = B.tab_stride;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
-    if (blockIdx.z < 2) {
-        const double* __restrict__ src = tab + (blockIdx.z ? VM_FCO : VM_FC) * ts;
-        double* __restrict__ dst = tab + (blockIdx.z ? VM_S_FCOT : VM_S_FCT) * ts;
+    if (blockIdx.z == 1) return;   // FCo^T is written by the outside cells
+    if (blockIdx.z == 0) {
+        const double* __restrict__ src = tab + VM_FC * ts;
+        double* __restrict__ dst = tab + VM_S_FCT * ts;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int r = tr * 32 + ty + 8 * k, c = tc * 32 + tx;
@@ -489,6 +592,19 @@ __global__ __launch_bounds__(256) void mcv_acc_final(McBatch B, const ViennaDx* 
         acc = wave_sum(acc);
         if (lane == 0) up[w] = acc > 1.0 ? 1.0 : acc;
     }
+}
+
+// two-molecule batch: hp[p][i][j] = P(letter i of s1 pairs letter j of s2) = joint pair matrix entry (i, cut+j), the copy
+// of /root/reference/src/ractip.cpp:451-454 without its threshold (the host adapter applies th_hy); logz[p] = F5i[n]
+__global__ __launch_bounds__(256) void mcv_extract_hp(McBatch B, double* __restrict__ hp, size_t hp_stride, int ldd, double* __restrict__ logz)
+{
+    const int p = blockIdx.y;
+    const int n = B.n[p], n1 = B.cut[p], n2 = n - n1;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0) logz[p] = B.f5i[(size_t)p * B.ld + n];
+    if (c >= n1 * n2) return;
+    const int i = c / n2 + 1, j = c % n2 + 1;
+    hp[(size_t)p * hp_stride + (size_t)i * ldd + j] = B.bp[(size_t)p * B.tri_stride + tri_offset_v(n, i) + n1 + j];
 }
 
 // logZ = F5i[n]

@@ -53,6 +53,7 @@ __global__ void mcv_acc_hscan(McBatch B);
 __global__ void mcv_acc_gaps(McBatch B, const ViennaDx* __restrict__ V, double* __restrict__ gaps);
 __global__ void mcv_acc_final(McBatch B, const ViennaDx* __restrict__ V, const double* __restrict__ gaps, int max_w);
 __global__ void mcv_finish(McBatch B, double* __restrict__ logz);
+__global__ void mcv_extract_hp(McBatch B, double* __restrict__ hp, size_t hp_stride, int ldd, double* __restrict__ logz);
 }  // namespace rh
 
 using namespace rh;
@@ -261,6 +262,14 @@ struct rh_ctx {
     void* d_zbar = nullptr;  size_t cap_zbar = 0;
     void* d_cand = nullptr;  size_t cap_cand = 0;
     void* d_gaps = nullptr;  size_t cap_gaps = 0;
+    // two-molecule (co_pf_fold) form of the hybridization matrix: one concatenated sequence s1+s2 per pair
+    int hybrid = RH_HYBRID_DUPLEX;
+    McBatch co = {};
+    void* d_coseq = nullptr; size_t cap_coseq = 0;
+    void* d_con = nullptr;   size_t cap_con = 0;     // [2][np]: lengths, cuts
+    void* d_cotab = nullptr; size_t cap_cotab = 0;
+    void* d_cof5 = nullptr;  size_t cap_cof5 = 0;    // f5i, f5o, xp, xs, xpo, xso
+    void* d_cobp = nullptr;  size_t cap_cobp = 0;
     double ms[4] = {0, 0, 0, 0};
     int n_launch[3] = {0, 0, 0};
     int n_far[3] = {0, 0, 0};      // of which block-product launches (mccaskill_far.hip)
@@ -423,6 +432,40 @@ int stage(rh_ctx* c, int ns, const char* const* seqs, const int* lens, bool with
         HIP_TRY(c, hipMemsetAsync(c->d_hp, 0, hp_bytes, c->s_dx));  // row 0 / column 0 stay zero
         D.seq = (const uint8_t*)c->d_seq; D.n = (const int*)c->d_n;
         D.tab = (double*)c->d_dxtab; D.hp = (double*)c->d_hp; D.logz = (double*)c->d_logz;
+        if (vienna && c->hybrid == RH_HYBRID_COFOLD) {
+            // concatenated sequences s1+s2, cut after s1
+            McBatch& C = c->co;
+            const int np = ns / 2, cmax = n1max + n2max;
+            C = McBatch{};
+            C.ns = np; C.nmax = cmax;
+            C.lds = (cmax + 3 + 15) & ~15;
+            C.ld = (cmax + 2 + 1) & ~1;
+            C.tab_stride = (size_t)C.ld * C.ld;
+            C.seq_stride = C.tab_stride * kViennaMcTables;
+            C.tri_stride = (tri_size(cmax) + 1) & ~(size_t)1;
+            std::vector<uint8_t> cc((size_t)np * C.lds, 0);
+            std::vector<int> nn(2 * (size_t)np);
+            for (int p = 0; p < np; p++) {
+                const int a = lens[2 * p], b = lens[2 * p + 1];
+                for (int i = 0; i < a; i++) cc[(size_t)p * C.lds + 1 + i] = vienna_code(seqs[2 * p][i]);
+                for (int i = 0; i < b; i++) cc[(size_t)p * C.lds + 1 + a + i] = vienna_code(seqs[2 * p + 1][i]);
+                nn[p] = a + b; nn[np + p] = a;
+            }
+            if ((rc = ensure(c, &c->d_coseq, &c->cap_coseq, cc.size(), false))) return rc;
+            if ((rc = ensure(c, &c->d_con, &c->cap_con, sizeof(int) * nn.size(), false))) return rc;
+            if ((rc = ensure(c, &c->d_cotab, &c->cap_cotab, sizeof(double) * C.seq_stride * np, false))) return rc;
+            if ((rc = ensure(c, &c->d_cof5, &c->cap_cof5, sizeof(double) * 6 * C.ld * np, false))) return rc;
+            if ((rc = ensure(c, &c->d_cobp, &c->cap_cobp, sizeof(double) * C.tri_stride * np, false))) return rc;
+            HIP_TRY(c, hipMemcpyAsync(c->d_coseq, cc.data(), cc.size(), hipMemcpyHostToDevice, c->s_dx));
+            HIP_TRY(c, hipMemcpyAsync(c->d_con, nn.data(), sizeof(int) * nn.size(), hipMemcpyHostToDevice, c->s_dx));
+            HIP_TRY(c, hipStreamSynchronize(c->s_dx));
+            C.seq = (const uint8_t*)c->d_coseq; C.n = (const int*)c->d_con; C.cut = (const int*)c->d_con + np;
+            C.tab = (double*)c->d_cotab;
+            double* f = (double*)c->d_cof5;
+            const size_t fs = (size_t)C.ld * np;
+            C.f5i = f; C.f5o = f + fs; C.xp = f + 2 * fs; C.xs = f + 3 * fs; C.xpo = f + 4 * fs; C.xso = f + 5 * fs;
+            C.bp = (double*)c->d_cobp; C.up = nullptr;
+        }
         X.seq = D.seq; X.n = D.n; X.tab = D.tab; X.hp = D.hp; X.hp_stride = D.tab_stride;
     }
     return RH_OK;
@@ -473,6 +516,27 @@ int launch_mc_vienna(rh_ctx* c, int pin)
     hipLaunchKernelGGL(mcv_acc_gaps, dim3((B.nmax * 30 + 3) / 4, B.ns, 2), dim3(256), 0, c->s_mc, B, c->d_vienna, (double*)c->d_gaps);
     hipLaunchKernelGGL(mcv_acc_final, dim3((B.nmax + 3) / 4, B.ns), dim3(256), 0, c->s_mc, B, c->d_vienna, (const double*)c->d_gaps, c->max_w);
     c->n_launch[1] += 4;
+    return RH_OK;
+}
+
+// ---- hybridization matrix from the two-molecule ensemble (co_pf_fold semantics): the same sweeps over s1+s2 with a cut
+int launch_cofold(rh_ctx* c)
+{
+    const McBatch& B = c->co;
+    const DxBatch& D = c->dx;
+    const int pin = B.ns % 8 == 0 ? 1 : 0;
+    hipLaunchKernelGGL(mcv_init, dim3((B.ns + 63) / 64), dim3(64), 0, c->s_dx, B);
+    for (int d = 0; d <= B.nmax - 1; d++) {
+        const int waves = std::max(B.nmax - 1 - d, 0) + 3;   // cells, F5i, XP, XS
+        KLAUNCH(c, 4, mcv_inside_diag, pin ? dim3(B.ns, (waves + 3) / 4) : dim3((waves + 3) / 4, B.ns), dim3(256), c->s_dx, B, c->d_vienna, d, pin);
+        c->n_launch[2]++;
+    }
+    for (int d = B.nmax - 2; d >= 0; d--) {
+        const int waves = (B.nmax - 1 - d) + 3;
+        KLAUNCH(c, 4, mcv_outside_diag, pin ? dim3(B.ns, (waves + 3) / 4) : dim3((waves + 3) / 4, B.ns), dim3(256), c->s_dx, B, c->d_vienna, d, pin);
+        c->n_launch[2]++;
+    }
+    hipLaunchKernelGGL(mcv_extract_hp, dim3((D.n1max * D.n2max + 255) / 256, B.ns), dim3(256), 0, c->s_dx, B, D.hp, D.tab_stride, D.ldd, D.logz);
     return RH_OK;
 }
 
@@ -667,7 +731,11 @@ int compute(rh_ctx* c)
     const bool skip_dx = skip && !std::strcmp(skip, "dx"), skip_mc = skip && !std::strcmp(skip, "mc");
     HIP_TRY(c, hipEventRecord(c->ev[3], c->s_dx));
     bool dx_lin_launched = false;
-    if (c->has_dx && !skip_dx && c->model == RH_MODEL_VIENNA_BL) {
+    if (c->has_dx && !skip_dx && c->model == RH_MODEL_VIENNA_BL && c->hybrid == RH_HYBRID_COFOLD) {
+        HIP_TRY(c, hipMemsetAsync(c->d_cobp, 0, sizeof(double) * c->co.tri_stride * c->co.ns, c->s_dx));
+        if ((rc = launch_cofold(c))) return rc;
+        c->last_dx_path = 2;
+    } else if (c->has_dx && !skip_dx && c->model == RH_MODEL_VIENNA_BL) {
         const DxBatch& D = c->dx;
         const int steps = (D.n1max + D.n2max) / 2;
         const int waves = 2 * std::min(D.n1max, D.n2max);
@@ -856,7 +924,7 @@ void rh_destroy(rh_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    void* bufs[] = {c->d_seq, c->d_n, c->d_mctab, c->d_f5, c->d_bp, c->d_up, c->d_dxtab, c->d_hp, c->d_logz, c->d_scal, c->d_mclogz, c->d_bad, c->d_cnt, c->d_cand, c->d_dxbad, c->d_zbar, c->d_gaps, c->d_model, c->d_lin, c->d_dxlin, c->d_vienna};
+    void* bufs[] = {c->d_seq, c->d_n, c->d_mctab, c->d_f5, c->d_bp, c->d_up, c->d_dxtab, c->d_hp, c->d_logz, c->d_scal, c->d_mclogz, c->d_bad, c->d_cnt, c->d_cand, c->d_dxbad, c->d_zbar, c->d_gaps, c->d_coseq, c->d_con, c->d_cotab, c->d_cof5, c->d_cobp, c->d_model, c->d_lin, c->d_dxlin, c->d_vienna};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (GraphSlot* g : {&c->g_in, &c->g_out, &c->g_dx}) if (g->exec) (void)hipGraphExecDestroy(g->exec);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -1083,6 +1151,16 @@ int rh_set_max_w(rh_ctx* c, int max_w)
     return RH_OK;
 }
 int rh_get_max_w(const rh_ctx* c) { return c ? c->max_w : RH_ERR_ARG; }
+
+int rh_set_hybrid(rh_ctx* c, int hybrid)
+{
+    if (!c) return RH_ERR_ARG;
+    if (hybrid != RH_HYBRID_DUPLEX && hybrid != RH_HYBRID_COFOLD) return fail(c, RH_ERR_ARG, "unknown hybridization mode %d", hybrid);
+    if (hybrid == RH_HYBRID_COFOLD && c->model != RH_MODEL_VIENNA_BL)
+        return fail(c, RH_ERR_UNSUPPORTED, "the two-molecule (co_pf_fold) hybridization matrix needs RH_MODEL_VIENNA_BL");
+    if (hybrid != c->hybrid) { c->hybrid = hybrid; c->computed = false; c->ns = 0; }
+    return RH_OK;
+}
 
 int rh_set_mode(rh_ctx* c, int mode)
 {

@@ -1,7 +1,7 @@
 // prob_cli.cpp -- drives the C++ adapters exactly as RactIP::solve does
 // (/root/reference/src/ractip.cpp:536-548) and prints the float matrices it would
 // hand to the ILP, one value per line, for tests/test_gpu_host_adapter.py.
-//   prob_cli contrafold SEQ | rnafold SEQ MAX_W | contraduplex S1 S2 TH | rnaduplex S1 S2 | pfduplex S1 S2 | solve S1 S2 [S1 S2 ...]
+//   prob_cli contrafold SEQ | rnafold SEQ MAX_W | contraduplex S1 S2 TH | rnaduplex S1 S2 | cofold S1 S2 | pfduplex S1 S2 | solve S1 S2 [S1 S2 ...]
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -64,6 +64,8 @@ int main(int argc, char** argv)
             for (const VF& r : up) for (float v : r) std::printf("%.9g\n", v);
         } else if (mode == "contraduplex") {
             VVF hp; en.contraduplex(argv[2], argv[3], hp); dump_hp(hp);
+        } else if (mode == "cofold") {
+            VVF hp; en.rnaduplex_cofold(argv[2], argv[3], hp); dump_hp(hp);
         } else if (mode == "rnaduplex") {
             VVF hp; en.rnaduplex(argv[2], argv[3], hp); dump_hp(hp);
         } else if (mode == "solve") {

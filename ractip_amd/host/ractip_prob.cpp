@@ -85,6 +85,25 @@ void ProbabilityEngine::rnafold(const std::string& seq, VF& bp, VI& offset, VVF&
         for (uint w = 0; w < max_w; ++w) up[i][w] = (float)dup[(size_t)i * max_w + w];
 }
 
+void ProbabilityEngine::rnaduplex_cofold(const std::string& seq1, const std::string& seq2, VVF& hp) const
+{
+    const uint n1 = seq1.size(), n2 = seq2.size();
+    hp.assign(n1 + 1, VF(n2 + 1, 0.0f));   // hp.resize(s1.size()+1, VF(s2.size()+1, 0.0)), :403-404
+    if (n1 == 0 || n2 == 0) return;
+    rh_ctx* v = vienna();
+    std::vector<double> d((size_t)(n1 + 1) * (n2 + 1));
+    bool ok = rh_set_hybrid(v, RH_HYBRID_COFOLD) == RH_OK &&
+              rh_duplex(v, seq1.c_str(), (int)n1, seq2.c_str(), (int)n2, d.data(), nullptr) == RH_OK;
+    const std::string why = ok ? "" : rh_last_error(v);
+    rh_set_hybrid(v, RH_HYBRID_DUPLEX);
+    if (!ok) throw std::logic_error("ractip_amd::rnaduplex: " + why);
+    for (uint i = 1; i <= n1; ++i)
+        for (uint j = 1; j <= n2; ++j) {
+            const float p = (float)d[(size_t)i * (n2 + 1) + j];   // pair_info::p is a float
+            if (p > th_hy_) hp[i][j] = p;                          // :451-454
+        }
+}
+
 void ProbabilityEngine::contraduplex(const std::string& seq1, const std::string& seq2, VVF& hp) const
 {
     const uint n1 = seq1.size(), n2 = seq2.size();

@@ -120,3 +120,25 @@ def test_solve_probabilities_batch(cli, oracle, golden):
 def test_errors_become_logic_error_exit_code(cli):
     r = subprocess.run([cli, "nosuchmode", "ACGU"], capture_output=True, text=True)
     assert r.returncode == 1 and "unknown mode" in r.stderr
+
+
+def test_default_cli_path_members_rnafold_and_cofold(cli, golden):
+    """RactIP's default path: rnafold (pf_fold bp + pf_unstru up, src/ractip.cpp:308-382) and the co_pf_fold branch of
+    rnaduplex (:400-458) through the C++ mirror, against the float-narrowed CPU restatement (PARITY UNPINNED model)."""
+    from _oracle import ViennaOracle
+    vo = ViennaOracle()
+    s1, s2 = str(golden["mc/DIS/seq"]), str(golden["mc/Tar/seq"])
+    n = len(s1)
+    lines = run(cli, "rnafold", s1, "15")
+    off, p = take(lines, 0, "offset")
+    bp, p = take(lines, p, "bp")
+    up, p = take(lines, p, "up")
+    assert list(off.astype(int)) == [i * (2 * (n + 1) - i - 1) // 2 for i in range(n + 1)]
+    o = vo.mccaskill(s1, max_w=15)
+    close32(bp, o["post"], "rnafold bp")
+    close32(up.reshape(n, 15), o["up"], "rnafold up")
+    hp, _ = take(run(cli, "cofold", s1, s2), 0, "hp")
+    ref = vo.cofold(s1, s2)["hp"].astype(np.float32)
+    ref[ref <= np.float32(0.1)] = 0            # p > th_hy_, src/ractip.cpp:452
+    near = np.abs(vo.cofold(s1, s2)["hp"] - 0.1) < 1e-6   # entries within rounding of the threshold may fall either side
+    assert np.all((np.abs(hp.astype(np.float32) - ref) <= 2e-6 * np.maximum(ref, 1e-6) + 1e-12) | near)

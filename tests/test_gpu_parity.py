@@ -358,6 +358,38 @@ def test_vienna_bl_pair_batch(vctx, golden):
         assert [(int(a), int(b)) for a, b in zip(mine["i"], mine["j"])] == [(i, j) for i, j, _ in single]
 
 
+def test_vienna_bl_cofold_hybridization(vctx, golden):
+    """RH_HYBRID_COFOLD: hp from the two-molecule ensemble (co_pf_fold semantics, the default branch of
+    RactIP::rnaduplex, src/ractip.cpp:400-458).  PARITY UNPINNED; HIP == oracle/vienna_oracle.c == brute force."""
+    from _oracle import ViennaOracle
+    vo = ViennaOracle()
+    rng = np.random.RandomState(93)
+    vctx.set_hybrid(True)
+    try:
+        cases = [(str(golden["mc/%s/seq" % a]), str(golden["mc/%s/seq" % b])) for a, b in (("DIS", "DIS"), ("CopA", "CopT"), ("OxyS", "fhlA"))]
+        cases += [("GGGAAACCC", "GGGUUUCCC"), ("G", "C"), ("GGGAAACCCAGGGAAACCCA", "UGGG"), ("CCCA", "GGGAAACCCAGGGAAACCCAUGGG"),
+                  ("GGGTTTNNNCCC", "GGGAAACCCUUU")]
+        cases += [(rnd(rng, a), rnd(rng, b)) for a, b in ((1, 1), (3, 9), (40, 33), (64, 1), (90, 75))]
+        for s1, s2 in cases:
+            hp, z = vctx.duplex(s1, s2)
+            o = vo.cofold(s1, s2)
+            assert abs(z - o["logZ"]) < 1e-9 * max(1.0, abs(z)), (len(s1), len(s2))
+            assert_prob_close(hp, o["hp"], rel=REL, what="cofold hp %d/%d" % (len(s1), len(s2)))
+        # batched: bp/up of the single molecules are untouched by the choice of hp source
+        pairs = cases[:3] + [(rnd(rng, 70), rnd(rng, 52))]
+        vctx.batch_upload(pairs)
+        vctx.batch_compute()
+        for p, (s1, s2) in enumerate(pairs):
+            r = vctx.batch_results(p)
+            o = vo.cofold(s1, s2)
+            assert_prob_close(r["hp"], o["hp"], rel=REL, what="batched cofold hp")
+            assert abs(r["logZ"][2] - o["logZ"]) < 1e-8
+            assert_prob_close(r["bp1"], vo.mccaskill(s1)["post"], rel=REL, what="bp1")
+            assert_prob_close(r["up2"], vo.mccaskill(s2, max_w=15)["up"], rel=REL, abs_floor=1e-11, what="up2")
+    finally:
+        vctx.set_hybrid(False)
+
+
 def test_errors_are_reported_not_swallowed(ctx):
     import ractip_amd
     with pytest.raises(ractip_amd.RhError):
