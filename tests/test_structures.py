@@ -1,0 +1,91 @@
+"""Joint structures: the integer programme of RactIP::solve (ractip_amd/ilp.py) over the probability matrices.
+
+CPU part: the solver wrapper, and the only program output the reference records -- README.md:91-97, `ractip DIS.fa DIS.fa`
+on its default path (ViennaRNA pf_fold + pf_unstru + co_pf_fold, unknown version) -- as a smoke check of the
+parity-unpinned Vienna-BL restatement.  GPU part (BASELINE.json: "identical bracket structures on the bundled data/*.fa
+pairs"): for all eight interacting pairs of /root/reference/data the structure decoded from the HIP path's matrices equals
+the one decoded from the reference engines' matrices (golden vectors; CONTRAfold model) resp. from the CPU restatement
+(Vienna-BL model), through the same programme."""
+import numpy as np
+import pytest
+
+from ractip_amd import ilp
+
+PAIRS = [("DIS", "DIS"), ("CopA", "CopT"), ("IncRNA54", "RepZ"), ("MicA", "ompA"), ("OxyS", "fhlA"), ("R1inv", "R2inv"),
+         ("RyhB", "SodB"), ("Tar", "Tarstar")]
+README_DIS = "((((.(((((((..[[[[[[.)))))))...))))"   # README.md:94, second strand with ']' for '['
+
+
+def balanced(r):
+    depth = 0
+    for ch in r:
+        depth += ch == "("
+        depth -= ch == ")"
+        assert depth >= 0
+    return depth == 0
+
+
+def test_ip_model_is_class_ip():
+    ip = ilp.IPModel()
+    a, b, c = ip.make_variable(1.0), ip.make_variable(2.0), ip.make_variable(-1.0)
+    r = ip.make_constraint(ilp.UP, 0, 1)           # a + b <= 1
+    ip.add_constraint(r, a, 1); ip.add_constraint(r, b, 1)
+    r = ip.make_constraint(ilp.LO, 1, 0)           # b + c >= 1
+    ip.add_constraint(r, b, 1); ip.add_constraint(r, c, 1)
+    assert abs(ip.solve() - 2.0) < 1e-9
+    assert [round(ip.get_value(k)) for k in (a, b, c)] == [0, 1, 0]
+
+
+def test_readme_dis_dis_default_path(golden):
+    """The reference's recorded output is reproduced by the Vienna-BL restatement + programme once the accessibility
+    threshold is 0.01; at the default 0.003 the interaction is two pairs longer on either side because the restatement puts
+    P(letters 11..23 unpaired) = 0.0038, a hair above the threshold (0.14 kcal/mol): the one point where the unpinned
+    energy model (ViennaRNA-1.8 semantics instead of the unknown 2.x build behind the README) shows."""
+    from _oracle import ViennaOracle
+    vo = ViennaOracle()
+    s = str(golden["mc/DIS/seq"])
+    f, co = vo.mccaskill(s, max_w=15), vo.cofold(s, s)
+    r1, r2, _ = ilp.solve(s, s, f["post"], f["post"], co["hp"], f["up"], f["up"], ilp.Options(th_ac=0.01))
+    assert r1 == README_DIS and r2 == README_DIS.replace("[", "]")
+    assert 0.003 < f["up"][10][12] < 0.01
+    r1, r2, _ = ilp.solve(s, s, f["post"], f["post"], co["hp"], f["up"], f["up"])
+    assert r1 == "((((.((((([[..[[[[[[.[[)))))...))))" and r2 == r1.replace("[", "]")
+
+
+def test_structures_from_reference_matrices_are_well_formed(golden):
+    for a, b in PAIRS:
+        s1, s2 = str(golden["mc/%s/seq" % a]), str(golden["mc/%s/seq" % b])
+        hp = golden["dx/%s+%s/post" % (a, b)].reshape(len(s1) + 1, len(s2) + 1)
+        r1, r2, _ = ilp.solve(s1, s2, golden["mc/%s/post" % a], golden["mc/%s/post" % b], hp, None, None, ilp.Options(min_w=0))
+        assert len(r1) == len(s1) and len(r2) == len(s2) and balanced(r1) and balanced(r2)
+        assert r1.count("[") == r2.count("]")
+
+
+@pytest.mark.gpu
+def test_identical_joint_structures_on_all_bundled_pairs(hotlib, golden):
+    import ractip_amd
+    from ractip_amd import pipeline
+    from _oracle import ViennaOracle
+    vo = ViennaOracle()
+    cf = ractip_amd.Context(device=0)
+    vi = ractip_amd.Context(device=0, model=ractip_amd.hot.RH_MODEL_VIENNA_BL)
+    try:
+        for a, b in PAIRS:
+            s1, s2 = str(golden["mc/%s/seq" % a]), str(golden["mc/%s/seq" % b])
+            # CONTRAfold model: reference engines (golden vectors) vs HIP path
+            hp = golden["dx/%s+%s/post" % (a, b)].reshape(len(s1) + 1, len(s2) + 1)
+            want = ilp.solve(s1, s2, golden["mc/%s/post" % a], golden["mc/%s/post" % b], hp, None, None, ilp.Options(min_w=0))[:2]
+            got = pipeline.predict(s1, s2, model="contrafold", ctx=cf)[:2]
+            assert got == want, (a, b, got, want)
+            # Vienna-BL model, default path (rnafold + co_pf_fold): CPU restatement vs HIP path
+            f1, f2, co = vo.mccaskill(s1, max_w=15), vo.mccaskill(s2, max_w=15), vo.cofold(s1, s2)
+            want = ilp.solve(s1, s2, f1["post"], f2["post"], co["hp"], f1["up"], f2["up"])[:2]
+            got = pipeline.predict(s1, s2, model="vienna", ctx=vi)[:2]
+            assert got == want, (a, b, got, want)
+            # --duplex
+            want = ilp.solve(s1, s2, f1["post"], f2["post"], vo.pf_duplex(s1, s2)["pr"], f1["up"], f2["up"])[:2]
+            got = pipeline.predict(s1, s2, model="vienna", duplex=True, ctx=vi)[:2]
+            assert got == want, (a, b, got, want)
+    finally:
+        cf.close()
+        vi.close()
