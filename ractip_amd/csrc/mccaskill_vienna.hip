@@ -483,6 +483,9 @@ __global__ __launch_bounds__(256) void mcv_acc_hscan(McBatch B)
 // gap probabilities of interior loops.  z = 0: GL[p][l1] = P(loop with outer 5' letter p and l1 >= 1 unpaired letters
 // p+1..p+l1 before the enclosed pair), one wavefront per (p,l1), lanes over the outer 3' letter q;
 // z = 1: GR[q][l2] likewise for the 3' gap q-l2..q-1, lanes over p (reads the transposed copies).
+// a loop whose outside x inside weight is below e^-70 of Z cannot reach e^-60 even with the most favourable loop energy
+// (a stack is worth < e^6): skipping it changes no accessibility by more than 1e-20
+constexpr double kSkipLog = -70.0;
 __global__ __launch_bounds__(256) void mcv_acc_gaps(McBatch B, const ViennaDx* __restrict__ V, double* __restrict__ gaps)
 {
     const int sq = blockIdx.y;
@@ -514,7 +517,7 @@ __global__ __launch_bounds__(256) void mcv_acc_gaps(McBatch B, const ViennaDx* _
                 const int ti = V->ptype[s[k] * 5 + s[l]];
                 if (!ti) continue;
                 const double in = fc[l - 1];
-                if (!(in > kNeg / 2)) continue;
+                if (!(o + in - Z > kSkipLog)) continue;
                 acc += exp(o + in - Z + loop_w(V, l1, l2, to, ti, s[p + 1], s[q - 1], s[k - 1], s[l + 1]));
             }
         }
@@ -536,7 +539,7 @@ __global__ __launch_bounds__(256) void mcv_acc_gaps(McBatch B, const ViennaDx* _
                     const int ti = V->ptype[s[k] * 5 + s[l]];
                     if (!ti) continue;
                     const double in = fct[k];
-                    if (!(in > kNeg / 2)) continue;
+                    if (!(o + in - Z > kSkipLog)) continue;
                     acc += exp(o + in - Z + loop_w(V, l1, l2, to, ti, s[p + 1], s[q - 1], s[k - 1], s[l + 1]));
                 }
             }
