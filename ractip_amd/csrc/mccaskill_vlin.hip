@@ -1,0 +1,523 @@
+// mccaskill_vlin.hip -- Vienna-BL McCaskill inside / outside / posterior in SCALED LINEAR space (the fast path of the
+// default-CLI model; mccaskill_vienna.hip is its log-space form and the fallback).  PARITY UNPINNED, see vienna_model.h.
+//
+// Same organisation as mccaskill_lin.hip: diagonal-major tables ([d*ld + i] = cell (i, i+d)), one THREAD per cell, 64
+// consecutive cells of a diagonal per wavefront, the term loops of a group split over W wavefronts, block products
+// (mccaskill_far.hip, unchanged -- it only sees FM1, FM, FM2o) for the far k-terms of the O(n^3) sums.  What differs is
+// the model:
+//   * loops with one enclosed pair: generic interior loops factor as mismatchI(outer) x w(l1,l2) x mismatchI(inner) and run
+//     as LDS-staged filters over the decorated table FCX exactly like the CONTRAfold shapes; bulges of length >= 2 factor
+//     as TerminalAU(outer) x w(l) x TerminalAU(inner): two more taps per total length over a second decorated table
+//     (FCB), read straight from HBM; the seven small shapes with joint energy tables (stack, 1-bulges, 1x1, 1x2, 2x1,
+//     2x2) are gathered per cell from the raw table in the epilogue;
+//   * hairpins: length table x mismatchH, tetraloop bonus, TerminalAU for triloops;
+//   * the unambiguous multiloop grammar of mccaskill_vienna.hip (FMS = one branch with trailing unpaired letters).
+#include <hip/hip_runtime.h>
+
+#include "batch.h"
+#include "vienna_model.h"
+
+namespace rh {
+
+namespace {
+
+__device__ __forceinline__ size_t tri_off_vl(int n, int i) { return (size_t)i * (size_t)(2 * (n + 1) - i - 1) / 2; }
+
+__device__ __forceinline__ double wsum_vl(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ void block_map_vl(int pin, int* sq, int* slot)
+{
+    *sq = pin ? blockIdx.x : blockIdx.y;
+    *slot = pin ? blockIdx.y : blockIdx.x;
+}
+
+template <int T>
+__device__ __forceinline__ double vfilt_fwd(const double* __restrict__ wt, const double* seg)
+{
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int l1 = 0; l1 <= T; l1 += 2) {
+        s0 = fma(wt[l1], seg[l1], s0);
+        if (l1 + 1 <= T) s1 = fma(wt[l1 + 1], seg[l1 + 1], s1);
+    }
+    return s0 + s1;
+}
+template <int T>
+__device__ __forceinline__ double vfilt_rev(const double* __restrict__ wt, const double* seg)
+{
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int l1 = 0; l1 <= T; l1 += 2) {
+        s0 = fma(wt[l1], seg[T - l1], s0);
+        if (l1 + 1 <= T) s1 = fma(wt[l1 + 1], seg[T - l1 - 1], s1);
+    }
+    return s0 + s1;
+}
+// generic loops need l1, l2 >= 1 and t >= 4 (1x1, 1x2, 2x1 are tabulated; 2x2 has weight 0 in shape_w)
+#define RH_VT_CASES(X) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) \
+    X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30)
+__device__ __forceinline__ double vfilt_fwd_any(int t, const double* __restrict__ wt, const double* seg)
+{
+    switch (t) {
+#define X(T) case T: return vfilt_fwd<T>(wt, seg);
+        RH_VT_CASES(X)
+#undef X
+    }
+    return 0.0;
+}
+__device__ __forceinline__ double vfilt_rev_any(int t, const double* __restrict__ wt, const double* seg)
+{
+    switch (t) {
+#define X(T) case T: return vfilt_rev<T>(wt, seg);
+        RH_VT_CASES(X)
+#undef X
+    }
+    return 0.0;
+}
+
+// the seven tabulated loop shapes: outer pair type t1, inner pair type t2 (0: the letters do not pair), letters si1/sj1
+// next to the outer pair inside the loop, sp1/sq1 next to the inner pair
+__device__ __forceinline__ double small_w(const VLinModel* L, int l1, int l2, int t1, int t2, int si1, int sj1, int sp1, int sq1)
+{
+    const int r2 = L->rtype[t2];
+    const int tt = t1 * 8 + r2;
+    if (l1 == 0 && l2 == 0) return L->E_stack[tt];
+    if (l1 + l2 == 1) return L->E_bulge1[tt];
+    if (l1 == 1 && l2 == 1) return L->E_int11[tt * 25 + si1 * 5 + sj1];
+    if (l1 == 1 && l2 == 2) return L->E_int21[tt * 125 + (si1 * 5 + sq1) * 5 + sj1];
+    if (l1 == 2 && l2 == 1) return L->E_int21[(r2 * 8 + t1) * 125 + (sq1 * 5 + si1) * 5 + sp1];
+    return L->E_int22[tt * 625 + ((si1 * 5 + sp1) * 5 + sq1) * 5 + sj1];
+}
+
+}  // namespace
+
+// table slots: 3, 4, 7, 10, 11, 12 are the ones mccaskill_far.hip addresses (LinTableFar)
+enum VLinTable { VL_FC = 0, VL_FCX, VL_FCA, VL_FM1, VL_FM, VL_FCO, VL_FCOX, VL_FM2O, VL_FMSO, VL_FM1O,
+                 VL_FM2F, VL_FMOF, VL_FM1OF, VL_FMS, VL_FCB, VL_FCOB, VL_COUNT };
+static_assert((int)VL_COUNT <= kViennaMcTables, "linear tables reuse the log-space table buffer");
+
+__global__ void vlin_init(McBatch B, int* __restrict__ bad)
+{
+    const int sq = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sq >= B.ns) return;
+    B.f5i[(size_t)sq * B.ld] = 1.0;
+    B.f5o[(size_t)sq * B.ld + B.n[sq]] = 1.0;
+    bad[sq] = 0;
+}
+
+// ---------------------------------------------------------------------------------
+// inside, diagonal d.  hp_d = lam^d * hairpin length weight of a loop of d unpaired letters.
+template <int W, int BS>
+__global__ __launch_bounds__(64 * W) void vlin_inside_diag(McBatch B, const VLinModel* __restrict__ L, int d, double hp_d, int pin)
+{
+    __shared__ double part[3][W][64];
+    __shared__ double gbuf[W][2 * ((kMaxSingle / 2 + W) / W)][96];
+    int sq, slot;
+    block_map_vl(pin, &sq, &slot);
+    if (sq >= B.ns) return;
+    const int n = B.n[sq];
+    if (d > n - 1) return;
+    const int ncell = n - 1 - d > 0 ? n - 1 - d : 0;
+    const int ngroup = (ncell + 63) >> 6;
+    if (slot > ngroup) return;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int ld = B.ld;
+    const size_t ts = B.tab_stride;
+    const uint8_t* __restrict__ s = B.seq + (size_t)sq * B.lds;
+    double* __restrict__ tab = B.tab + (size_t)sq * B.seq_stride;
+    double* __restrict__ f5i = B.f5i + sq * ld;
+
+    if (slot == ngroup) {
+        // F5i~[jj] = F5i~[jj-1]*lam + sum_{k<=jj-2} F5i~[k]*FCA~[k+1,jj-1]*lam^2
+        const int jj = d + 1;
+        const double* __restrict__ fca = tab + VL_FCA * ts;
+        double acc = 0.0;
+        for (int k = threadIdx.x; k <= jj - 2; k += 64 * W) acc = fma(f5i[k], fca[(jj - 2 - k) * ld + (k + 1)], acc);
+        acc = wsum_vl(acc);
+        if (lane == 0) part[0][w][0] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+#pragma unroll
+            for (int k = 0; k < W; k++) t += part[0][k][0];
+            f5i[jj] = f5i[jj - 1] * L->lam + t * L->lam2;
+        }
+        return;
+    }
+
+    const int i = 1 + slot * 64 + lane, j = i + d;
+    const bool valid = i <= ncell;
+    int s_im1 = 0, s_i = 0, s_ip1 = 0, s_j = 0, s_jp1 = 0, s_jp2 = 0;
+    if (valid) { s_im1 = s[i - 1]; s_i = s[i]; s_ip1 = s[i + 1]; s_j = s[j]; s_jp1 = s[j + 1]; s_jp2 = s[j + 2]; }
+    const int type = L->ptype[s_i * 5 + s_jp1];
+    const bool pairable = valid && type != 0;
+
+    // epilogue operands (wave 0 only), issued ahead of the term loops
+    const size_t at = d * ld + i;
+    const int idx = 25 * (5 * s_i + s_ip1) + 5 * s_jp1 + s_j;       // (i,j+1) seen from inside
+    const int idd = 25 * (5 * s_jp1 + s_jp2) + 5 * s_i + s_im1;     // seen from outside
+    double e_txo = 0, e_tmc = 0, e_tmh = 0, e_txi = 0, e_tsa = 0, e_tau = 1, e_tet = 1;
+    double o_fca = 0, o_fm1 = 0, o_fms = 0, sm7 = 0.0;
+    if (w == 0 && valid) {
+        e_txo = L->TXO[idx]; e_tmc = L->TMC[idx]; e_tmh = L->TMH[idx];
+        e_txi = L->TXI[idd]; e_tsa = L->TSA[idd]; e_tau = L->E_tau[type];
+        if (d == 4 && pairable) {   // tetraloop bonus: closing pair + 4 loop letters
+            int code = 0; bool ok = true;
+#pragma unroll
+            for (int k = 0; k < 6; k++) { const int c = s[i + k]; ok = ok && c != 0; code = code * 4 + (c - 1); }
+            if (ok) e_tet = L->E_tetra[code];
+        }
+        if (d >= 2) {
+            o_fca = tab[VL_FCA * ts + (d - 2) * ld + i + 1];
+            o_fm1 = tab[VL_FM1 * ts + (d - 1) * ld + i + 1];
+            o_fms = tab[VL_FMS * ts + (d - 1) * ld + i];
+        }
+        if (pairable && d >= 2) {
+            // the seven tabulated shapes: inner pair letters (p, q) = (i+1+l1, j-l2), raw table cell (p, q-1)
+            const double* __restrict__ fc = tab + VL_FC * ts;
+#pragma unroll
+            for (int k = 0; k < 7; k++) {
+                const int l1 = (k == 2 || k == 3 || k == 4) ? 1 : (k >= 5 ? 2 : 0);
+                const int l2 = (k == 1 || k == 3 || k == 5) ? 1 : ((k == 4 || k == 6) ? 2 : 0);
+                const int t = l1 + l2;
+                if (d - 2 - t >= 0) {
+                    const int p = i + 1 + l1, q = j - l2;
+                    const int t2 = L->ptype[s[p] * 5 + s[q]];
+                    const double v = fc[(d - 2 - t) * ld + p];
+                    sm7 = fma(v, small_w(L, l1, l2, type, t2, s_ip1, s_j, s[p - 1], s[q + 1]), sm7);
+                }
+            }
+        }
+    }
+
+    // ---- FM2[i,d] = sum_{m=1}^{d-1} FM1[m][i] * FM[d-m][i+m]: near terms here, far blocks from FM2F
+    double acc2 = 0.0;
+    {
+        const double* __restrict__ fm1 = tab + VL_FM1 * ts + i;
+        const double* __restrict__ fm = tab + VL_FM * ts + i;
+        int kA = 1 << 30, kB = 0;
+        if (BS > 0) {
+            const int I = i / BS, J = j / BS;
+            if (J - I >= 4) { kA = (I + 2) * BS; kB = (J - 1) * BS; }
+        }
+        constexpr int UF = 8;
+        const bool split = BS > 0 && d - 1 > 4 * BS;
+        const int lo0 = 1, hi0 = split ? 2 * BS : d - 1;
+        const int lo1 = split ? d - 2 * BS : 1, hi1 = split ? d - 1 : 0;
+#pragma unroll
+        for (int part_i = 0; part_i < 2; part_i++) {
+            const int lo = part_i ? lo1 : lo0, hi = part_i ? hi1 : hi0;
+            for (int m = lo + w; m <= hi; m += UF * W) {
+                double a[UF], b[UF];
+#pragma unroll
+                for (int u = 0; u < UF; u++) {
+                    const int mm = m + u * W, k = i + mm;
+                    const bool ok = valid && mm <= hi && (k < kA || k >= kB);
+                    a[u] = ok ? fm1[mm * ld] : 0.0;
+                    b[u] = ok ? fm[(d - mm) * ld + mm] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < UF; u++) acc2 = fma(a[u], b[u], acc2);
+            }
+        }
+        if (BS > 0 && valid && kB > 0) acc2 += (w == 0) ? tab[VL_FM2F * ts + d * ld + i] : 0.0;
+    }
+
+    // ---- generic interior loops (LDS-staged filters over FCX) and long bulges (two taps per length over FCB)
+    double accc = 0.0, accb = 0.0;
+    if (d >= 2) {
+        const int tmax = d - 2 < kMaxSingle ? d - 2 : kMaxSingle;
+        const int i0 = 1 + slot * 64;
+        const double* __restrict__ fcx = tab + VL_FCX * ts;
+        const double* __restrict__ fcb = tab + VL_FCB * ts;
+        constexpr int NSEG = 2 * ((kMaxSingle / 2 + W) / W);
+        int tseg[NSEG];
+        double b0[NSEG], b1[NSEG];
+#pragma unroll
+        for (int q = 0; q < NSEG; q++) {
+            const int g = w + (q >> 1) * W;
+            const int t = (q & 1) ? kMaxSingle - g : g;
+            const bool on = g <= kMaxSingle / 2 && !((q & 1) && t == g) && t <= tmax && t >= 2;   // wave-uniform
+            tseg[q] = on ? t : -1;
+            b0[q] = b1[q] = 0.0;
+            if (on) {
+                const int col0 = i0 + 1;
+                if (t >= 4) {
+                    const double* __restrict__ row = fcx + (d - 2 - t) * ld + col0;
+                    gbuf[w][q][lane] = col0 + lane < ld ? row[lane] : 0.0;
+                    if (lane < 32) gbuf[w][q][64 + lane] = col0 + 64 + lane < ld ? row[64 + lane] : 0.0;
+                }
+                if (valid) {   // bulge of length t on the 3' side (l1 = 0) and on the 5' side (l1 = t)
+                    b0[q] = fcb[(d - 2 - t) * ld + i + 1];
+                    b1[q] = fcb[(d - 2 - t) * ld + i + 1 + t];
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NSEG; q++)
+            if (tseg[q] >= 0) {
+                if (tseg[q] >= 4) accc += vfilt_fwd_any(tseg[q], L->shape_w + tseg[q] * (tseg[q] + 1) / 2, &gbuf[w][q][lane]);
+                accb = fma(L->WB[tseg[q]], b0[q] + b1[q], accb);
+            }
+        if (!pairable) { accc = 0.0; accb = 0.0; }
+    }
+
+    part[0][w][lane] = acc2;
+    part[1][w][lane] = accc;
+    part[2][w][lane] = accb;
+    __syncthreads();
+    if (w != 0 || !valid) return;
+    double fm2 = 0.0, g = 0.0, gb = 0.0;
+#pragma unroll
+    for (int k = 0; k < W; k++) { fm2 += part[0][k][lane]; g += part[1][k][lane]; gb += part[2][k][lane]; }
+
+    double fc = 0.0;
+    if (pairable) {
+        double hp = 0.0;
+        if (d >= 3) hp = hp_d * (d == 3 ? e_tau : e_tmh * e_tet);
+        fc = e_txo * g + e_tau * gb + sm7 + hp + fm2 * e_tmc;
+    }
+    double fm1v = 0.0, fmsv = 0.0, fmv = 0.0;
+    if (d >= 2) {
+        fm1v = o_fca * L->w_mp2 + o_fm1 * L->w_mu;
+        fmsv = fm1v + o_fms * L->w_mu;
+        fmv = fm2 + fmsv;
+    }
+    tab[VL_FC * ts + at] = fc;
+    tab[VL_FCX * ts + at] = fc * e_txi;
+    tab[VL_FCB * ts + at] = fc * e_tau;
+    tab[VL_FCA * ts + at] = fc * e_tsa;
+    tab[VL_FM1 * ts + at] = fm1v;
+    tab[VL_FMS * ts + at] = fmsv;
+    tab[VL_FM * ts + at] = fmv;
+}
+
+// ---------------------------------------------------------------------------------
+// outside (pull form) + posterior, diagonal d; last group: F5o~[d+1]
+template <int W, int BS>
+__global__ __launch_bounds__(64 * W) void vlin_outside_diag(McBatch B, const VLinModel* __restrict__ L, int d, int pin, int* __restrict__ bad)
+{
+    __shared__ double part[4][W][64];
+    __shared__ double gbuf[W][2 * ((kMaxSingle / 2 + W) / W)][96];
+    int sq, slot;
+    block_map_vl(pin, &sq, &slot);
+    if (sq >= B.ns) return;
+    const int n = B.n[sq];
+    const int ncell = n - 1 - d;
+    if (ncell < 1) return;
+    const int ngroup = (ncell + 63) >> 6;
+    if (slot > ngroup) return;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int ld = B.ld;
+    const size_t ts = B.tab_stride;
+    const uint8_t* __restrict__ s = B.seq + (size_t)sq * B.lds;
+    double* __restrict__ tab = B.tab + (size_t)sq * B.seq_stride;
+    const double* __restrict__ f5i = B.f5i + sq * ld;
+    double* __restrict__ f5o = B.f5o + sq * ld;
+
+    if (slot == ngroup) {
+        const int k = d + 1;
+        const double* __restrict__ fca = tab + VL_FCA * ts + (k + 1);
+        double acc = 0.0;
+        for (int jj = k + 2 + threadIdx.x; jj <= n; jj += 64 * W) acc = fma(f5o[jj], fca[(jj - 2 - k) * ld], acc);
+        acc = wsum_vl(acc);
+        if (lane == 0) part[0][w][0] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+#pragma unroll
+            for (int q = 0; q < W; q++) t += part[0][q][0];
+            f5o[k] = f5o[k + 1] * L->lam + t * L->lam2;
+        }
+        return;
+    }
+
+    const int i0 = 1 + slot * 64;
+    const int i = i0 + lane, j = i + d;
+    const bool valid = i <= ncell;
+    int s_im1 = 0, s_i = 0, s_ip1 = 0, s_j = 0, s_jp1 = 0, s_jp2 = 0;
+    if (valid) { s_im1 = s[i - 1]; s_i = s[i]; s_ip1 = s[i + 1]; s_j = s[j]; s_jp1 = s[j + 1]; s_jp2 = s[j + 2]; }
+    const int type = L->ptype[s_i * 5 + s_jp1];
+    const bool pairable = valid && type != 0;
+    const bool guard_m = d >= 2;
+
+    const size_t at = d * ld + i;
+    const bool up_ok = i - 1 >= 1 && j + 1 <= n - 1;
+    const int idx = 25 * (5 * s_i + s_ip1) + 5 * s_jp1 + s_j;
+    const int idd = 25 * (5 * s_jp1 + s_jp2) + 5 * s_i + s_im1;
+    double e_txo = 0, e_tmc = 0, e_txi = 0, e_tsa = 0, e_tau = 1;
+    double o_fmso = 0, o_fm1o = 0, o_f5o = 0, o_f5i = 0, o_fm1o_up = 0, o_fc = 0, o_z = 1, sm7 = 0.0;
+    if (w == 0 && valid) {
+        e_txo = L->TXO[idx]; e_tmc = L->TMC[idx];
+        e_txi = L->TXI[idd]; e_tsa = L->TSA[idd]; e_tau = L->E_tau[type];
+        if (guard_m) {
+            if (j + 1 <= n - 1) o_fmso = tab[VL_FMSO * ts + (d + 1) * ld + i];
+            if (i - 1 >= 1) o_fm1o = tab[VL_FM1O * ts + (d + 1) * ld + i - 1];
+        }
+        o_f5o = f5o[j + 1]; o_f5i = f5i[i - 1]; o_z = f5i[n];
+        o_fc = tab[VL_FC * ts + at];
+        if (up_ok) o_fm1o_up = tab[VL_FM1O * ts + (d + 2) * ld + i - 1];
+        if (pairable) {
+            // the seven tabulated shapes: outer pair letters (io, jo+1) = (i-1-l1, j+2+l2), raw outside cell (io, jo)
+            const double* __restrict__ fco = tab + VL_FCO * ts;
+#pragma unroll
+            for (int k = 0; k < 7; k++) {
+                const int l1 = (k == 2 || k == 3 || k == 4) ? 1 : (k >= 5 ? 2 : 0);
+                const int l2 = (k == 1 || k == 3 || k == 5) ? 1 : ((k == 4 || k == 6) ? 2 : 0);
+                const int io = i - 1 - l1, jo = j + 1 + l2;
+                if (io >= 1 && jo <= n - 1) {
+                    const int to = L->ptype[s[io] * 5 + s[jo + 1]];
+                    const double v = fco[(jo - io) * ld + io];
+                    sm7 = fma(v, small_w(L, l1, l2, to, type, s[io + 1], s[jo], s_im1, s_jp2), sm7);
+                }
+            }
+        }
+    }
+
+    double accm = 0.0, acc1 = 0.0, accc = 0.0, accb = 0.0;
+    if (guard_m) {
+        constexpr int UO = 6;
+        {   // FMo[i,d] += FM2o[d+e][i-e] * FM1[e][i-e]; blocks <= I-2 come from FMOF
+            const int i_last = ncell < i0 + 63 ? ncell : i0 + 63;
+            const int emax = BS > 0 ? (i_last - 1 < 2 * BS ? i_last - 1 : 2 * BS) : i_last - 1;
+            const double* __restrict__ x = tab + VL_FM2O * ts + i;
+            const double* __restrict__ y = tab + VL_FM1 * ts + i;
+            int mine = valid ? i - 1 : 0;
+            if (BS > 0 && valid) { const int lim = i - (i / BS - 1) * BS; mine = mine < lim ? mine : lim; }
+            for (int e = 1 + w; e <= emax; e += UO * W) {
+                double xv[UO], yv[UO];
+#pragma unroll
+                for (int u = 0; u < UO; u++) {
+                    const int ee = e + u * W;
+                    const bool ok = ee <= mine;
+                    xv[u] = ok ? x[(d + ee) * ld - ee] : 0.0;
+                    yv[u] = ok ? y[ee * ld - ee] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < UO; u++) accm = fma(xv[u], yv[u], accm);
+            }
+            if (BS > 0 && valid && w == 0) accm += tab[VL_FMOF * ts + d * ld + i];
+        }
+        {   // FM1o[i,d] += FM2o[d+e][i] * FM[e][i+d]; blocks >= J+2 come from FM1OF
+            const int emax_all = n - 1 - (i0 + d);
+            const int emax = BS > 0 ? (emax_all < 2 * BS ? emax_all : 2 * BS) : emax_all;
+            const double* __restrict__ x = tab + VL_FM2O * ts + i;
+            const double* __restrict__ y = tab + VL_FM * ts + j;
+            int mine = valid ? n - 1 - j : 0;
+            if (BS > 0 && valid) { const int lim = (j / BS + 2) * BS - 1 - j; mine = mine < lim ? mine : lim; }
+            for (int e = 1 + w; e <= emax; e += UO * W) {
+                double xv[UO], yv[UO];
+#pragma unroll
+                for (int u = 0; u < UO; u++) {
+                    const int ee = e + u * W;
+                    const bool ok = ee <= mine;
+                    xv[u] = ok ? x[(d + ee) * ld] : 0.0;
+                    yv[u] = ok ? y[ee * ld] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < UO; u++) acc1 = fma(xv[u], yv[u], acc1);
+            }
+            if (BS > 0 && valid && w == 0) acc1 += tab[VL_FM1OF * ts + d * ld + i];
+        }
+    }
+    {   // enclosing generic loops (staged, zero-filled outside the interior) and long bulges over FCoB
+        const int room = n - 4 - d;
+        if (room >= 0) {
+            const int tmax = room < kMaxSingle ? room : kMaxSingle;
+            const double* __restrict__ fcox = tab + VL_FCOX * ts;
+            const double* __restrict__ fcob = tab + VL_FCOB * ts;
+            constexpr int NSEG = 2 * ((kMaxSingle / 2 + W) / W);
+            int tseg[NSEG];
+            double b0[NSEG], b1[NSEG];
+#pragma unroll
+            for (int q = 0; q < NSEG; q++) {
+                const int g = w + (q >> 1) * W;
+                const int t = (q & 1) ? kMaxSingle - g : g;
+                const bool on = g <= kMaxSingle / 2 && !((q & 1) && t == g) && t <= tmax && t >= 2;
+                tseg[q] = on ? t : -1;
+                b0[q] = b1[q] = 0.0;
+                if (on) {
+                    const int cmax = n - 1 - (d + 2 + t);         // last interior column of the source row
+                    if (t >= 4) {
+                        const int col0 = i0 - 1 - t;
+                        const double* __restrict__ row = fcox + (d + 2 + t) * ld;
+                        const int c = col0 + lane;
+                        gbuf[w][q][lane] = (c >= 1 && c <= cmax) ? row[c] : 0.0;
+                        const int c2 = col0 + 64 + lane;
+                        if (lane < 32) gbuf[w][q][64 + lane] = (c2 >= 1 && c2 <= cmax) ? row[c2] : 0.0;
+                    }
+                    if (valid) {   // outer pair (i-1, j+2+t): bulge on the 3' side; (i-1-t, j+2): on the 5' side
+                        const double* __restrict__ row = fcob + (d + 2 + t) * ld;
+                        const int c0 = i - 1, c1 = i - 1 - t;
+                        b0[q] = (c0 >= 1 && c0 <= cmax) ? row[c0] : 0.0;
+                        b1[q] = (c1 >= 1 && c1 <= cmax) ? row[c1] : 0.0;
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NSEG; q++)
+                if (tseg[q] >= 0) {
+                    if (tseg[q] >= 4) accc += vfilt_rev_any(tseg[q], L->shape_w + tseg[q] * (tseg[q] + 1) / 2, &gbuf[w][q][lane]);
+                    accb = fma(L->WB[tseg[q]], b0[q] + b1[q], accb);
+                }
+            if (!pairable) { accc = 0.0; accb = 0.0; }
+        }
+    }
+    part[0][w][lane] = accm;
+    part[1][w][lane] = acc1;
+    part[2][w][lane] = accc;
+    part[3][w][lane] = accb;
+    __syncthreads();
+    if (w != 0 || !valid) return;
+    double sm = 0.0, s1 = 0.0, g = 0.0, gb = 0.0;
+#pragma unroll
+    for (int k = 0; k < W; k++) { sm += part[0][k][lane]; s1 += part[1][k][lane]; g += part[2][k][lane]; gb += part[3][k][lane]; }
+
+    double fmo = 0.0, fmso = 0.0, fm1o = 0.0;
+    if (guard_m) {
+        fmo = sm;
+        fmso = fmo + o_fmso * L->w_mu;
+        fm1o = s1 + fmso + o_fm1o * L->w_mu;
+    }
+    double fco = 0.0;
+    if (pairable) {
+        const double ext = o_f5o * o_f5i * L->lam2;
+        const double multi = o_fm1o_up * L->w_mp2;
+        fco = e_tsa * (ext + multi) + e_txi * g + e_tau * gb + sm7;
+    }
+    const double fm2o = fmo + fco * e_tmc;
+    tab[VL_FCO * ts + at] = fco;
+    tab[VL_FCOX * ts + at] = fco * e_txo;
+    tab[VL_FCOB * ts + at] = fco * e_tau;
+    tab[VL_FMSO * ts + at] = fmso;
+    tab[VL_FM1O * ts + at] = fm1o;
+    tab[VL_FM2O * ts + at] = fm2o;
+    double p = fco * o_fc / o_z;
+    if (!(p == p) || p > 1e300) { atomicOr(&bad[sq], 1); p = 0.0; }
+    p = p > 1.0 ? 1.0 : (p < 0.0 ? 0.0 : p);
+    B.bp[(size_t)sq * B.tri_stride + tri_off_vl(n, i) + (j + 1)] = p;
+}
+
+// logZ = log F5i~[n] + s*n; flags a sequence whose scaled values left the double range
+__global__ void vlin_finish(McBatch B, const VLinModel* __restrict__ L, double* __restrict__ logz, int* __restrict__ bad)
+{
+    const int sq = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sq >= B.ns) return;
+    const int n = B.n[sq];
+    const double z = B.f5i[(size_t)sq * B.ld + n];
+    const double zo = n >= 2 ? B.f5o[(size_t)sq * B.ld + 1] : 1.0;
+    if (!(z > 1e-200 && z < 1e200) || !(zo > 1e-200 && zo < 1e200)) atomicOr(&bad[sq], 1);
+    logz[sq] = log(z) + L->s * (double)n;
+}
+
+template __global__ void vlin_inside_diag<8, 16>(McBatch, const VLinModel*, int, double, int);
+template __global__ void vlin_outside_diag<8, 16>(McBatch, const VLinModel*, int, int, int*);
+template __global__ void vlin_inside_diag<8, 0>(McBatch, const VLinModel*, int, double, int);
+template __global__ void vlin_outside_diag<8, 0>(McBatch, const VLinModel*, int, int, int*);
+
+}  // namespace rh

@@ -53,6 +53,10 @@ __global__ void mcv_acc_hscan(McBatch B);
 __global__ void mcv_acc_gaps(McBatch B, const ViennaDx* __restrict__ V, double* __restrict__ gaps);
 __global__ void mcv_acc_final(McBatch B, const ViennaDx* __restrict__ V, const double* __restrict__ gaps, int max_w);
 __global__ void mcv_finish(McBatch B, double* __restrict__ logz);
+__global__ void vlin_init(McBatch B, int* __restrict__ bad);
+template <int W, int BS> __global__ void vlin_inside_diag(McBatch B, const VLinModel* __restrict__ L, int d, double hp_d, int pin);
+template <int W, int BS> __global__ void vlin_outside_diag(McBatch B, const VLinModel* __restrict__ L, int d, int pin, int* __restrict__ bad);
+__global__ void vlin_finish(McBatch B, const VLinModel* __restrict__ L, double* __restrict__ logz, int* __restrict__ bad);
 __global__ void mcv_extract_hp(McBatch B, double* __restrict__ hp, size_t hp_stride, int ldd, double* __restrict__ logz);
 }  // namespace rh
 
@@ -223,6 +227,8 @@ struct rh_ctx {
     LinModel* d_lin = nullptr;
     LinModel h_lin;
     ViennaDx* d_vienna = nullptr;  // RH_MODEL_VIENNA_BL only
+    VLinModel* d_vlin = nullptr;   // the same model in scaled linear space
+    VLinModel* h_vlin = nullptr;
     DxLinModel* d_dxlin = nullptr;
     DxLinModel h_dxlin;
     DxLinBatch dxl = {};
@@ -519,6 +525,54 @@ int launch_mc_vienna(rh_ctx* c, int pin)
     return RH_OK;
 }
 
+// ---- Vienna-BL McCaskill sweeps, scaled linear-space path (mccaskill_vlin.hip) with the block products of mccaskill_far.hip
+template <int BS>
+int launch_mc_vlin(rh_ctx* c, int pin, int phase)
+{
+    constexpr int W = 8;
+    const McBatch& B = c->mc;
+    int* bad = (int*)c->d_bad;
+    const VLinModel& H = *c->h_vlin;
+    const int last_block = BS > 0 ? (B.nmax - 1) / BS : 0;
+    if (phase == 0) {
+        hipLaunchKernelGGL(vlin_init, dim3((B.ns + 63) / 64), dim3(64), 0, c->s_mc, B, bad);
+        for (int d = 0; d <= B.nmax - 1; d++) {
+            const int groups = (std::max(B.nmax - 1 - d, 0) + 63) / 64 + 1;
+            // hairpin of d unpaired letters: length weight (extrapolated beyond 30 as part_func.c does) x lam^d
+            const double hp_d = (d <= 30 ? H.E_hairpin[d] : std::exp(H.hairpin30 - H.lxc * std::log(d / 30.0))) * std::exp(-H.s * d);
+            KLAUNCH(c, 0, (vlin_inside_diag<W, BS>), pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(64 * W), c->s_mc, B, c->d_vlin, d, hp_d, pin);
+            c->n_launch[0]++;
+            if (BS > 0 && (d + 1) % BS == 0) {
+                const int D = (d + 1) / BS + 1;
+                if (D >= 4 && D <= last_block) {
+                    KLAUNCH(c, 1, lin_far_inside_mfma, dim3(last_block - D + 1, B.ns), dim3(256), c->s_mc, B, D);
+                    c->n_launch[0]++; c->n_far[0]++;
+                }
+            }
+        }
+        return RH_OK;
+    }
+    if (BS > 0)
+        for (int D = last_block; D >= 0 && (D + 1) * BS - 1 > B.nmax - 2; D--) {
+            KLAUNCH(c, 3, lin_far_outside_mfma, dim3(last_block - D + 1, B.ns, 2), dim3(256), c->s_mc, B, D);
+            c->n_launch[1]++; c->n_far[1]++;
+        }
+    for (int d = B.nmax - 2; d >= 0; d--) {
+        if (BS > 0 && (d + 1) % BS == 0) {
+            const int D = (d + 1) / BS - 1;
+            if (D >= 0 && D <= last_block) {
+                KLAUNCH(c, 3, lin_far_outside_mfma, dim3(last_block - D + 1, B.ns, 2), dim3(256), c->s_mc, B, D);
+                c->n_launch[1]++; c->n_far[1]++;
+            }
+        }
+        const int groups = (B.nmax - 1 - d + 63) / 64 + 1;
+        KLAUNCH(c, 2, (vlin_outside_diag<W, BS>), pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(64 * W), c->s_mc, B, c->d_vlin, d, pin, bad);
+        c->n_launch[1]++;
+    }
+    hipLaunchKernelGGL(vlin_finish, dim3((B.ns + 63) / 64), dim3(64), 0, c->s_mc, B, c->d_vlin, (double*)c->d_mclogz, bad);
+    return RH_OK;
+}
+
 // ---- hybridization matrix from the two-molecule ensemble (co_pf_fold semantics): the same sweeps over s1+s2 with a cut
 int launch_cofold(rh_ctx* c)
 {
@@ -760,7 +814,14 @@ int compute(rh_ctx* c)
 
     HIP_TRY(c, hipEventRecord(c->ev[0], c->s_mc));
     bool need_log = c->has_mc && c->mode == RH_MODE_LOG && !skip_mc && c->model != RH_MODEL_VIENNA_BL;
-    if (c->has_mc && c->model == RH_MODEL_VIENNA_BL && !skip_mc) {
+    if (c->has_mc && c->model == RH_MODEL_VIENNA_BL && !skip_mc && c->mode == RH_MODE_LINEAR) {
+        // experimental: linear sweeps only (bp, log Z); accessibility is not computed on this path yet
+        const bool far = c->lin_bs != 0;
+        if ((rc = far ? launch_mc_vlin<16>(c, pin, 0) : launch_mc_vlin<0>(c, pin, 0))) return rc;
+        HIP_TRY(c, hipEventRecord(c->ev[1], c->s_mc));
+        if ((rc = far ? launch_mc_vlin<16>(c, pin, 1) : launch_mc_vlin<0>(c, pin, 1))) return rc;
+        c->last_path = 1;
+    } else if (c->has_mc && c->model == RH_MODEL_VIENNA_BL && !skip_mc) {
         if ((rc = launch_mc_vienna(c, pin))) return rc;
         c->last_path = 2;
     } else if (c->has_mc && c->mode != RH_MODE_LOG && !skip_mc) {
@@ -907,9 +968,16 @@ rh_ctx* rh_create(int device, int model, const char* param_file)
               hipMemcpy(c->d_lin, &c->h_lin, sizeof(LinModel), hipMemcpyHostToDevice) == hipSuccess &&
               hipMalloc((void**)&c->d_dxlin, sizeof(DxLinModel)) == hipSuccess &&
               hipMemcpy(c->d_dxlin, &c->h_dxlin, sizeof(DxLinModel), hipMemcpyHostToDevice) == hipSuccess;
-    if (ok && host_vienna)
+    if (ok && host_vienna) {
+        c->h_vlin = new VLinModel;
+        // scale exponent: log Z per nucleotide of random ACGU under the BL* energies is 0.21..0.33 for n = 200..500 (up to 0.45 on the bundled RNAs)
+        build_vlin_model(*host_vienna, 0.28, c->h_vlin);
+        if (const char* e = std::getenv("RH_VLIN_S")) build_vlin_model(*host_vienna, std::atof(e), c->h_vlin);
         ok = hipMalloc((void**)&c->d_vienna, sizeof(ViennaDx)) == hipSuccess &&
-             hipMemcpy(c->d_vienna, host_vienna, sizeof(ViennaDx), hipMemcpyHostToDevice) == hipSuccess;
+             hipMemcpy(c->d_vienna, host_vienna, sizeof(ViennaDx), hipMemcpyHostToDevice) == hipSuccess &&
+             hipMalloc((void**)&c->d_vlin, sizeof(VLinModel)) == hipSuccess &&
+             hipMemcpy(c->d_vlin, c->h_vlin, sizeof(VLinModel), hipMemcpyHostToDevice) == hipSuccess;
+    }
     delete host_vienna;
     for (int k = 0; ok && k < 6; k++) ok = hipEventCreate(&c->ev[k]) == hipSuccess;
     if (!ok) {
@@ -924,12 +992,13 @@ void rh_destroy(rh_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    void* bufs[] = {c->d_seq, c->d_n, c->d_mctab, c->d_f5, c->d_bp, c->d_up, c->d_dxtab, c->d_hp, c->d_logz, c->d_scal, c->d_mclogz, c->d_bad, c->d_cnt, c->d_cand, c->d_dxbad, c->d_zbar, c->d_gaps, c->d_coseq, c->d_con, c->d_cotab, c->d_cof5, c->d_cobp, c->d_model, c->d_lin, c->d_dxlin, c->d_vienna};
+    void* bufs[] = {c->d_seq, c->d_n, c->d_mctab, c->d_f5, c->d_bp, c->d_up, c->d_dxtab, c->d_hp, c->d_logz, c->d_scal, c->d_mclogz, c->d_bad, c->d_cnt, c->d_cand, c->d_dxbad, c->d_zbar, c->d_gaps, c->d_coseq, c->d_con, c->d_cotab, c->d_cof5, c->d_cobp, c->d_vlin, c->d_model, c->d_lin, c->d_dxlin, c->d_vienna};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (GraphSlot* g : {&c->g_in, &c->g_out, &c->g_dx}) if (g->exec) (void)hipGraphExecDestroy(g->exec);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->s_mc) (void)hipStreamDestroy(c->s_mc);
     if (c->s_dx) (void)hipStreamDestroy(c->s_dx);
+    delete c->h_vlin;
     delete c;
 }
 

@@ -137,4 +137,51 @@ bool load_vienna_dx(const char* path, ViennaDx* V, char* err, int errlen)
     return true;
 }
 
+void build_vlin_model(const ViennaDx& V, double s, VLinModel* L)
+{
+    std::memset(L, 0, sizeof(*L));
+    const double lam = std::exp(-s);
+    L->s = s; L->lam = lam; L->lam2 = lam * lam;
+    L->w_mu = lam * std::exp(V.mlb);
+    L->w_mp2 = lam * lam * std::exp(V.mli);
+    L->hairpin30 = V.hairpin30; L->lxc = V.lxc;
+    std::memcpy(L->ptype, V.ptype, sizeof L->ptype);
+    std::memcpy(L->rtype, V.rtype, sizeof L->rtype);
+    for (int t = 0; t < 8; t++) L->E_tau[t] = t > 2 ? std::exp(V.tau) : 1.0;
+    for (int x = 0; x < 5; x++) for (int x1 = 0; x1 < 5; x1++) for (int y1 = 0; y1 < 5; y1++) for (int y = 0; y < 5; y++) {
+        const int idx = 25 * (5 * x + x1) + (5 * y1 + y);
+        const int ti = V.ptype[x * 5 + y1];          // seen from inside: letters (i, j+1) = (x, y1)
+        if (ti) {
+            const int rt = V.rtype[ti];
+            L->TXO[idx] = std::exp(V.mmI[ti * 25 + x1 * 5 + y]);
+            L->TMC[idx] = std::exp(V.ml_close + V.d3x[rt * 5 + x1] + V.d5x[rt * 5 + y]);
+            L->TMH[idx] = std::exp(V.mmH[ti * 25 + x1 * 5 + y]);
+        }
+        const int to = V.ptype[y1 * 5 + x];          // seen from outside: letters (i, j+1) = (y1, x)
+        if (to) {
+            const int rt = V.rtype[to];
+            L->TXI[idx] = std::exp(V.mmI[rt * 25 + x1 * 5 + y]);
+            L->TSA[idx] = std::exp(V.d5x[to * 5 + y] + V.d3x[to * 5 + x1]);
+        }
+    }
+    const double l2 = lam * lam, l3 = l2 * lam, l4 = l2 * l2, l5 = l4 * lam, l6 = l4 * l2;
+    for (int k = 0; k < 64; k++) { L->E_stack[k] = std::exp(V.stack[k]) * l2; L->E_bulge1[k] = std::exp(V.bulge1[k]) * l3; }
+    for (int k = 0; k < 64 * 25; k++) L->E_int11[k] = std::exp(V.int11[k]) * l4;
+    for (int k = 0; k < 64 * 125; k++) L->E_int21[k] = std::exp(V.int21[k]) * l5;
+    for (int k = 0; k < 64 * 625; k++) L->E_int22[k] = std::exp(V.int22[k]) * l6;
+    // type 0 rows/columns of the joint tables hold log-weight 0 -> weight 1; they are only ever multiplied by an FC of 0
+    for (int k = 0; k < 4096; k++) L->E_tetra[k] = std::exp(V.tetra[k]);
+    for (int u = 0; u <= 30; u++) L->E_hairpin[u] = std::exp(V.hairpin[u]);
+    L->E_hairpin[31] = L->E_hairpin[30];
+    // generic loops and long bulges from the row-major (l1,l2) shape list
+    auto at = [&](int l1, int l2) { return l1 * 31 - l1 * (l1 - 1) / 2 + l2; };
+    int k = 0;
+    for (int t = 0; t <= kMaxSingle; t++)
+        for (int l1 = 0; l1 <= t; l1++, k++) {
+            const int q = at(l1, t - l1);
+            L->shape_w[k] = V.kind[q] == 1 ? std::exp(V.shape[q].score) * std::pow(lam, t + 2) : 0.0;
+        }
+    for (int l = 2; l <= kMaxSingle; l++) L->WB[l] = std::exp(V.shape[at(l, 0)].score) * std::pow(lam, l + 2);
+}
+
 }  // namespace rh

@@ -52,4 +52,31 @@ __host__ __device__ inline double vienna_small_loop(const ViennaDx* V, int l1, i
 
 bool load_vienna_dx(const char* path, ViennaDx* out, char* err, int errlen);
 
+// ---- the same model in SCALED LINEAR space (mccaskill_vlin.hip): every DP quantity of span d is stored as Q*lam^d
+// (inside) / Q*lam^(n-d) (outside), lam = exp(-s), exactly as lin_model.h does for the CONTRAfold model; all entries
+// are Boltzmann weights exp(-E*10/kT), loop weights already carry lam^(l1+l2+2).
+// Sequence-dependent factors are tabulated over two per-position letter pairs (x, x1 | y1, y), index 25*(5x+x1)+(5y1+y):
+//   pair (i,j+1) seen from INSIDE its loop : x = s[i], x1 = s[i+1], y1 = s[j+1], y = s[j]
+//   pair (i,j+1) seen from OUTSIDE         : x = s[j+1], x1 = s[j+2], y1 = s[i], y = s[i-1]
+struct VLinModel {
+    double TXO[625];      // mismatchI[type][x1][y]: closing pair of a generic interior loop (0 where the letters do not pair)
+    double TMC[625];      // multiloop closure: MLclosing + MLintern + dangle3[rt][x1] + dangle5[rt][y]
+    double TMH[625];      // hairpin mismatchH[type][x1][y]
+    double TXI[625];      // enclosed pair of a generic interior loop: mismatchI[rt][x1][y]
+    double TSA[625];      // stem of a multi / exterior loop: dangle5[type][y] + dangle3[type][x1] (TerminalAU inside dangle3)
+    double E_tau[8];      // TerminalAU by pair type (1 for CG/GC)
+    double E_stack[64], E_bulge1[64];
+    double E_int11[64 * 25], E_int21[64 * 125], E_int22[64 * 625];
+    double E_tetra[4096];
+    double E_hairpin[32];
+    double shape_w[496];  // generic interior loops (l1, l2 >= 1, not 1x1 1x2 2x1 2x2), sorted by t = l1+l2, then l1; 0 elsewhere
+    double WB[32];        // bulge of length l >= 2
+    int ptype[25], rtype[8];
+    double s, lam, lam2;
+    double w_mu;          // lam   * exp(-ML_base)
+    double w_mp2;         // lam^2 * exp(-ML_intern)
+    double hairpin30, lxc;   // log-space pieces for hairpins longer than 30
+};
+void build_vlin_model(const ViennaDx& V, double s, VLinModel* out);
+
 }  // namespace rh
