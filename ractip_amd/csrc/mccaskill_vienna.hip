@@ -462,13 +462,13 @@ __global__ __launch_bounds__(256) void mcv_acc_prep(McBatch B, const ViennaDx* _
 }
 
 // exclusive prefix sums over p, in place: C[a][q] = sum_{p<a} Hp[p][q]; one thread per column q
-__global__ __launch_bounds__(256) void mcv_acc_hscan(McBatch B)
+__global__ __launch_bounds__(256) void mcv_acc_hscan(McBatch B, int slot)
 {
     const int sq = blockIdx.y;
     const int n = B.n[sq], ld = B.ld;
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q > n) return;
-    double* __restrict__ hp = B.tab + (size_t)sq * B.seq_stride + VM_S_HP * B.tab_stride + q;
+    double* __restrict__ hp = B.tab + (size_t)sq * B.seq_stride + (size_t)slot * B.tab_stride + q;
     double run = 0.0;
     for (int a = 0; a <= n; a += 4) {
         double v[4];

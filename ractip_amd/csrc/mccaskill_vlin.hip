@@ -515,6 +515,173 @@ __global__ void vlin_finish(McBatch B, const VLinModel* __restrict__ L, double* 
     logz[sq] = log(z) + L->s * (double)n;
 }
 
+// =================================================================================
+// accessibility from the linear tables (same decomposition as mccaskill_vienna.hip; every product of an outside and an
+// inside quantity divided by Z~ is already free of the scaling, each unpaired letter of the run contributes one lam)
+constexpr int VL_S_HP = VL_FM2F;   // scratch: hairpin probabilities, square [p][q] (the far sums of the inside sweep are dead)
+
+// Hp[p][q] = P(letters p, q close a hairpin loop); hplen[d] = lam^d * length weight (host table, as the inside sweep's hp_d)
+__global__ __launch_bounds__(256) void vlin_acc_prep(McBatch B, const VLinModel* __restrict__ L, const double* __restrict__ hplen)
+{
+    const int sq = blockIdx.y;
+    const int n = B.n[sq], ld = B.ld;
+    const int tiles = (ld + 31) / 32;
+    const int tr = blockIdx.x / tiles, tc = blockIdx.x % tiles;
+    double* __restrict__ tab = B.tab + (size_t)sq * B.seq_stride;
+    const size_t ts = B.tab_stride;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const uint8_t* __restrict__ s = B.seq + (size_t)sq * B.lds;
+    const double Z = B.f5i[(size_t)sq * ld + n];
+    double* __restrict__ hp = tab + VL_S_HP * ts;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int p = tr * 32 + ty + 8 * k, q = tc * 32 + tx;
+        if (p >= ld || q >= ld) continue;
+        double v = 0.0;
+        const int u = q - p - 1;
+        if (p >= 1 && q <= n && u >= kMinHairpin) {
+            const int type = L->ptype[s[p] * 5 + s[q]];
+            if (type) {
+                double e = hplen[u];
+                if (u == 3) e *= L->E_tau[type];
+                else {
+                    e *= L->TMH[25 * (5 * s[p] + s[p + 1]) + 5 * s[q] + s[q - 1]];
+                    if (u == 4) {
+                        int code = 0; bool ok = true;
+#pragma unroll
+                        for (int c = 0; c < 6; c++) { const int x = s[p + c]; ok = ok && x != 0; code = code * 4 + (x - 1); }
+                        if (ok) e *= L->E_tetra[code];
+                    }
+                }
+                v = tab[VL_FCO * ts + (size_t)u * ld + p] * e / Z;
+            }
+        }
+        hp[(size_t)p * ld + q] = v;
+    }
+}
+
+// gap probabilities of interior loops, one THREAD per (letter, own gap length g >= 1), lanes over the letter:
+//   z = 0: GL[p][g] = sum over loops with outer 5' letter p and g unpaired letters p+1..p+g:  loop over the outer span D and l2
+//   z = 1: GR[q][g] = the same for the 3' gap q-g..q-1 of the outer 3' letter q:              loop over D and l1
+// A loop is at most as probable as its outer pair: pairs below 1e-25 are skipped.
+__global__ __launch_bounds__(256) void vlin_acc_gaps(McBatch B, const VLinModel* __restrict__ L, double* __restrict__ gaps)
+{
+    const int sq = blockIdx.y;
+    const int n = B.n[sq], ld = B.ld;
+    const int g = blockIdx.z % 30 + 1;
+    const bool right = blockIdx.z >= 30;
+    const int pos = blockIdx.x * blockDim.x + threadIdx.x + 1;   // p (left) or q (right)
+    if (pos > n) return;
+    const uint8_t* __restrict__ s = B.seq + (size_t)sq * B.lds;
+    const double* __restrict__ tab = B.tab + (size_t)sq * B.seq_stride;
+    const size_t ts = B.tab_stride;
+    const double Z = B.f5i[(size_t)sq * ld + n];
+    const double* __restrict__ FCO = tab + VL_FCO * ts;
+    const double* __restrict__ FCOX = tab + VL_FCOX * ts;
+    const double* __restrict__ FCOB = tab + VL_FCOB * ts;
+    const double* __restrict__ FC = tab + VL_FC * ts;
+    const double* __restrict__ FCX = tab + VL_FCX * ts;
+    const double* __restrict__ FCB = tab + VL_FCB * ts;
+    double acc = 0.0;
+    for (int D = g + 2; D <= n - 2; D++) {     // outer cell (p, p+D), pair letters (p, q = p+D+1)
+        const int p = right ? pos - D - 1 : pos;
+        if (p < 1 || p + D > n - 1) { if (right) break; else if (p + D > n - 1) break; else continue; }
+        const size_t oc = (size_t)D * ld + p;
+        const double fco = FCO[oc];
+        if (!(fco * FC[oc] > 1e-25 * Z)) continue;
+        const int q = p + D + 1;
+        const int to = L->ptype[s[p] * 5 + s[q]];
+        const double fcox = FCOX[oc], fcob = FCOB[oc];
+        const int omax = kMaxSingle - g < D - 2 - g ? kMaxSingle - g : D - 2 - g;   // other gap length
+        for (int o = 0; o <= omax; o++) {
+            const int l1 = right ? o : g, l2 = right ? g : o;
+            const int t = l1 + l2;
+            const int k = p + 1 + l1;                       // inner 5' letter; inner cell (k, l-1), l = q-1-l2
+            const size_t ic = (size_t)(D - 2 - t) * ld + k;
+            const int nl = l1 > l2 ? l1 : l2, ns = l1 > l2 ? l2 : l1;
+            if (ns == 0) {
+                if (nl >= 2) acc = fma(fcob * L->WB[nl], FCB[ic], acc);
+                else {                                      // 1-bulge: joint table
+                    const int l = q - 1 - l2;
+                    acc = fma(fco * small_w(L, l1, l2, to, L->ptype[s[k] * 5 + s[l]], s[p + 1], s[q - 1], s[k - 1], s[l + 1]), FC[ic], acc);
+                }
+            } else if (nl <= 2) {                           // 1x1, 1x2, 2x1, 2x2
+                const int l = q - 1 - l2;
+                acc = fma(fco * small_w(L, l1, l2, to, L->ptype[s[k] * 5 + s[l]], s[p + 1], s[q - 1], s[k - 1], s[l + 1]), FC[ic], acc);
+            } else acc = fma(fcox * L->shape_w[t * (t + 1) / 2 + l1], FCX[ic], acc);
+        }
+    }
+    gaps[((size_t)(2 * sq + (right ? 1 : 0)) * ld + pos) * 32 + g] = acc / Z;
+}
+
+// up[(a-1)*max_w + w] = H part: sum_{p<a, q>a+w} Hp[p][q] from the column prefix sums C (square scratch); one wavefront per letter
+__global__ __launch_bounds__(256) void vlin_acc_hsum(McBatch B, int max_w)
+{
+    const int sq = blockIdx.y;
+    const int n = B.n[sq], ld = B.ld;
+    const int a = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) + 1;
+    const int lane = threadIdx.x & 63;
+    if (a > n) return;
+    const double* __restrict__ C = B.tab + (size_t)sq * B.seq_stride + VL_S_HP * B.tab_stride + (size_t)a * ld;
+    double* __restrict__ up = B.up + ((size_t)sq * ld + (a - 1)) * max_w;
+    // tail beyond the widest region, then one more column per narrower width
+    double tail = 0.0;
+    for (int q = a + max_w + lane; q <= n; q += 64) tail += C[q];
+    tail = wsum_vl(tail);
+    if (lane == 0) {
+        double run = tail;
+        for (int w = max_w - 1; w >= 0; w--) {
+            const int b = a + w;
+            up[w] = b <= n ? run : 0.0;
+            if (b <= n) run += C[b];     // width w-1 also counts q = b
+        }
+    }
+}
+
+// adds the E, I and M parts; one THREAD per (letter a, width w), lanes over a
+__global__ __launch_bounds__(256) void vlin_acc_final(McBatch B, const VLinModel* __restrict__ L, const double* __restrict__ gaps, int max_w)
+{
+    const int sq = blockIdx.y;
+    const int n = B.n[sq], ld = B.ld;
+    const int a = blockIdx.x * blockDim.x + threadIdx.x + 1;
+    const int w = blockIdx.z;
+    if (a > n) return;
+    const int b = a + w, len = w + 1;
+    double* __restrict__ up = B.up + ((size_t)sq * ld + (a - 1)) * max_w + w;
+    if (b > n) { *up = 0.0; return; }
+    const double* __restrict__ tab = B.tab + (size_t)sq * B.seq_stride;
+    const size_t ts = B.tab_stride;
+    const double* __restrict__ f5i = B.f5i + (size_t)sq * ld;
+    const double* __restrict__ f5o = B.f5o + (size_t)sq * ld;
+    const double Z = f5i[n];
+    const double* __restrict__ gl = gaps + (size_t)(2 * sq) * ld * 32;
+    const double* __restrict__ gr = gaps + (size_t)(2 * sq + 1) * ld * 32;
+    double lam_len = 1.0, mu_len = 1.0;
+    for (int k = 0; k < len; k++) { lam_len *= L->lam; mu_len *= L->w_mu; }
+    double acc = f5i[a - 1] * f5o[b] / Z * lam_len;                                          // E
+    for (int p = a - 1; p >= 1 && p >= b - kMaxSingle; p--)                                   // I, 5' gaps
+        for (int l = b - p; l <= kMaxSingle; l++) acc += gl[(size_t)p * 32 + l];
+    for (int q = b + 1; q <= n && q <= a + kMaxSingle; q++)                                   // I, 3' gaps
+        for (int l = q - a; l <= kMaxSingle; l++) acc += gr[(size_t)q * 32 + l];
+    double m = 0.0;
+    if (a >= 2 && b <= n - 3) {     // M, run before a branch: FM1o[a-1, j] * FM1[b, j], j = a+e
+        const double* __restrict__ x = tab + VL_FM1O * ts + (a - 1);
+        const double* __restrict__ y = tab + VL_FM1 * ts + b;
+        for (int e = w + 2; a + e <= n - 1; e++) m = fma(x[(size_t)(e + 1) * ld], y[(size_t)(e - w) * ld], m);
+    }
+    if (a >= 4 && b <= n - 1) {     // M, run after the last branch: FMSo[i, b] * FMS[i, a-1], i = a-1-e
+        const double* __restrict__ x = tab + VL_FMSO * ts;
+        const double* __restrict__ y = tab + VL_FMS * ts;
+        for (int e = 2; a - 1 - e >= 1; e++) {
+            const int i = a - 1 - e;
+            m = fma(x[(size_t)(e + len) * ld + i], y[(size_t)e * ld + i], m);
+        }
+    }
+    acc += m * mu_len / Z;
+    acc += *up;                                                                               // H (vlin_acc_hsum)
+    *up = acc > 1.0 ? 1.0 : acc;
+}
+
 template __global__ void vlin_inside_diag<8, 16>(McBatch, const VLinModel*, int, double, int);
 template __global__ void vlin_outside_diag<8, 16>(McBatch, const VLinModel*, int, int, int*);
 template __global__ void vlin_inside_diag<8, 0>(McBatch, const VLinModel*, int, double, int);

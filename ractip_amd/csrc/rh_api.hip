@@ -49,7 +49,11 @@ __global__ void mcv_init(McBatch B);
 __global__ void mcv_inside_diag(McBatch B, const ViennaDx* __restrict__ V, int d, int pin);
 __global__ void mcv_outside_diag(McBatch B, const ViennaDx* __restrict__ V, int d, int pin);
 __global__ void mcv_acc_prep(McBatch B, const ViennaDx* __restrict__ V);
-__global__ void mcv_acc_hscan(McBatch B);
+__global__ void mcv_acc_hscan(McBatch B, int slot);
+__global__ void vlin_acc_prep(McBatch B, const VLinModel* __restrict__ L, const double* __restrict__ hplen);
+__global__ void vlin_acc_gaps(McBatch B, const VLinModel* __restrict__ L, double* __restrict__ gaps);
+__global__ void vlin_acc_hsum(McBatch B, int max_w);
+__global__ void vlin_acc_final(McBatch B, const VLinModel* __restrict__ L, const double* __restrict__ gaps, int max_w);
 __global__ void mcv_acc_gaps(McBatch B, const ViennaDx* __restrict__ V, double* __restrict__ gaps);
 __global__ void mcv_acc_final(McBatch B, const ViennaDx* __restrict__ V, const double* __restrict__ gaps, int max_w);
 __global__ void mcv_finish(McBatch B, double* __restrict__ logz);
@@ -268,6 +272,8 @@ struct rh_ctx {
     void* d_zbar = nullptr;  size_t cap_zbar = 0;
     void* d_cand = nullptr;  size_t cap_cand = 0;
     void* d_gaps = nullptr;  size_t cap_gaps = 0;
+    void* d_hplen = nullptr; size_t cap_hplen = 0;   // lam^d x hairpin length weight, d = 0..nmax (linear Vienna path)
+    std::vector<double> h_hplen;
     // two-molecule (co_pf_fold) form of the hybridization matrix: one concatenated sequence s1+s2 per pair
     int hybrid = RH_HYBRID_DUPLEX;
     McBatch co = {};
@@ -397,6 +403,15 @@ int stage(rh_ctx* c, int ns, const char* const* seqs, const int* lens, bool with
         if ((rc = ensure(c, &c->d_f5, &c->cap_f5, sizeof(double) * 2 * B.ld * ns, false))) return rc;
         if ((rc = ensure(c, &c->d_up, &c->cap_up, sizeof(double) * B.ld * c->max_w * ns, false))) return rc;
         if (vienna && (rc = ensure(c, &c->d_gaps, &c->cap_gaps, sizeof(double) * 2 * 32 * B.ld * ns, false))) return rc;
+        if (vienna) {
+            const VLinModel& H = *c->h_vlin;
+            c->h_hplen.resize((size_t)B.ld);
+            for (int d = 0; d < B.ld; d++)   // hairpin of d unpaired letters: length weight (beyond 30 as part_func.c extrapolates) x lam^d
+                c->h_hplen[d] = (d <= 30 ? H.E_hairpin[d] : std::exp(H.hairpin30 - H.lxc * std::log(d / 30.0))) * std::exp(-H.s * d);
+            if ((rc = ensure(c, &c->d_hplen, &c->cap_hplen, sizeof(double) * B.ld, false))) return rc;
+            HIP_TRY(c, hipMemcpyAsync(c->d_hplen, c->h_hplen.data(), sizeof(double) * B.ld, hipMemcpyHostToDevice, c->s_mc));
+            HIP_TRY(c, hipStreamSynchronize(c->s_mc));
+        }
         if ((rc = ensure(c, &c->d_mclogz, &c->cap_mclogz, sizeof(double) * ns, false))) return rc;
         if ((rc = ensure(c, &c->d_bad, &c->cap_bad, sizeof(int) * ns, false))) return rc;
         // bp entries outside 1<=i<j<=n are never written by the sweep: keep them zero
@@ -518,7 +533,7 @@ int launch_mc_vienna(rh_ctx* c, int pin)
     // accessibility P(i..i+w unpaired), w < max_w, from the finished tables
     const int tiles = (B.ld + 31) / 32;
     hipLaunchKernelGGL(mcv_acc_prep, dim3(tiles * tiles, B.ns, 3), dim3(256), 0, c->s_mc, B, c->d_vienna);
-    hipLaunchKernelGGL(mcv_acc_hscan, dim3((B.nmax + 1 + 255) / 256, B.ns), dim3(256), 0, c->s_mc, B);
+    hipLaunchKernelGGL(mcv_acc_hscan, dim3((B.nmax + 1 + 255) / 256, B.ns), dim3(256), 0, c->s_mc, B, 1 /* VM_FCX */);
     hipLaunchKernelGGL(mcv_acc_gaps, dim3((B.nmax * 30 + 3) / 4, B.ns, 2), dim3(256), 0, c->s_mc, B, c->d_vienna, (double*)c->d_gaps);
     hipLaunchKernelGGL(mcv_acc_final, dim3((B.nmax + 3) / 4, B.ns), dim3(256), 0, c->s_mc, B, c->d_vienna, (const double*)c->d_gaps, c->max_w);
     c->n_launch[1] += 4;
@@ -532,14 +547,12 @@ int launch_mc_vlin(rh_ctx* c, int pin, int phase)
     constexpr int W = 8;
     const McBatch& B = c->mc;
     int* bad = (int*)c->d_bad;
-    const VLinModel& H = *c->h_vlin;
     const int last_block = BS > 0 ? (B.nmax - 1) / BS : 0;
     if (phase == 0) {
         hipLaunchKernelGGL(vlin_init, dim3((B.ns + 63) / 64), dim3(64), 0, c->s_mc, B, bad);
         for (int d = 0; d <= B.nmax - 1; d++) {
             const int groups = (std::max(B.nmax - 1 - d, 0) + 63) / 64 + 1;
-            // hairpin of d unpaired letters: length weight (extrapolated beyond 30 as part_func.c does) x lam^d
-            const double hp_d = (d <= 30 ? H.E_hairpin[d] : std::exp(H.hairpin30 - H.lxc * std::log(d / 30.0))) * std::exp(-H.s * d);
+            const double hp_d = c->h_hplen[d];
             KLAUNCH(c, 0, (vlin_inside_diag<W, BS>), pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(64 * W), c->s_mc, B, c->d_vlin, d, hp_d, pin);
             c->n_launch[0]++;
             if (BS > 0 && (d + 1) % BS == 0) {
@@ -570,6 +583,14 @@ int launch_mc_vlin(rh_ctx* c, int pin, int phase)
         c->n_launch[1]++;
     }
     hipLaunchKernelGGL(vlin_finish, dim3((B.ns + 63) / 64), dim3(64), 0, c->s_mc, B, c->d_vlin, (double*)c->d_mclogz, bad);
+    // accessibility P(i..i+w unpaired), w < max_w
+    const int tiles = (B.ld + 31) / 32;
+    hipLaunchKernelGGL(vlin_acc_prep, dim3(tiles * tiles, B.ns), dim3(256), 0, c->s_mc, B, c->d_vlin, (const double*)c->d_hplen);
+    hipLaunchKernelGGL(mcv_acc_hscan, dim3((B.nmax + 1 + 255) / 256, B.ns), dim3(256), 0, c->s_mc, B, 10 /* VL_FM2F */);
+    hipLaunchKernelGGL(vlin_acc_hsum, dim3((B.nmax + 3) / 4, B.ns), dim3(256), 0, c->s_mc, B, c->max_w);
+    hipLaunchKernelGGL(vlin_acc_gaps, dim3((B.nmax + 255) / 256, B.ns, 60), dim3(256), 0, c->s_mc, B, c->d_vlin, (double*)c->d_gaps);
+    hipLaunchKernelGGL(vlin_acc_final, dim3((B.nmax + 255) / 256, B.ns, c->max_w), dim3(256), 0, c->s_mc, B, c->d_vlin, (const double*)c->d_gaps, c->max_w);
+    c->n_launch[1] += 5;
     return RH_OK;
 }
 
@@ -759,7 +780,8 @@ size_t shape_key(const rh_ctx* c, int which)
         const McBatch& B = c->mc;
         for (size_t v : {(size_t)B.ns, (size_t)B.nmax, (size_t)B.ld, (size_t)B.lds, (size_t)B.tab, (size_t)B.seq, (size_t)B.n,
                          (size_t)B.f5i, (size_t)B.bp, (size_t)B.up, (size_t)c->d_bad, (size_t)c->d_mclogz, (size_t)c->lin_w,
-                         (size_t)c->lin_bs, (size_t)B.tri_stride, (size_t)c->far_mfma})
+                         (size_t)c->lin_bs, (size_t)B.tri_stride, (size_t)c->far_mfma, (size_t)c->max_w, (size_t)c->d_gaps,
+                         (size_t)c->d_hplen})
             h = mix(h, v);
     } else {
         const DxLinBatch& X = c->dxl;
@@ -814,16 +836,32 @@ int compute(rh_ctx* c)
 
     HIP_TRY(c, hipEventRecord(c->ev[0], c->s_mc));
     bool need_log = c->has_mc && c->mode == RH_MODE_LOG && !skip_mc && c->model != RH_MODEL_VIENNA_BL;
-    if (c->has_mc && c->model == RH_MODEL_VIENNA_BL && !skip_mc && c->mode == RH_MODE_LINEAR) {
-        // experimental: linear sweeps only (bp, log Z); accessibility is not computed on this path yet
-        const bool far = c->lin_bs != 0;
-        if ((rc = far ? launch_mc_vlin<16>(c, pin, 0) : launch_mc_vlin<0>(c, pin, 0))) return rc;
-        HIP_TRY(c, hipEventRecord(c->ev[1], c->s_mc));
-        if ((rc = far ? launch_mc_vlin<16>(c, pin, 1) : launch_mc_vlin<0>(c, pin, 1))) return rc;
-        c->last_path = 1;
-    } else if (c->has_mc && c->model == RH_MODEL_VIENNA_BL && !skip_mc) {
-        if ((rc = launch_mc_vienna(c, pin))) return rc;
-        c->last_path = 2;
+    if (c->has_mc && c->model == RH_MODEL_VIENNA_BL && !skip_mc) {
+        bool log_path = c->mode == RH_MODE_LOG;
+        if (!log_path) {   // scaled linear sweeps; a sequence that leaves the double range sends the batch to the log-space kernels
+            const bool far = c->lin_bs != 0;
+            if ((rc = run_graphed(c, c->g_in, shape_key(c, 0), c->s_mc, &c->n_launch[0], &c->n_far[0],
+                                  [&] { return far ? launch_mc_vlin<16>(c, pin, 0) : launch_mc_vlin<0>(c, pin, 0); }))) return rc;
+            HIP_TRY(c, hipEventRecord(c->ev[1], c->s_mc));
+            if ((rc = run_graphed(c, c->g_out, shape_key(c, 1), c->s_mc, &c->n_launch[1], &c->n_far[1],
+                                  [&] { return far ? launch_mc_vlin<16>(c, pin, 1) : launch_mc_vlin<0>(c, pin, 1); }))) return rc;
+            c->last_path = 1;
+            if (c->mode == RH_MODE_AUTO) {
+                std::vector<int> bad(c->mc.ns);
+                HIP_TRY(c, hipMemcpyAsync(bad.data(), c->d_bad, sizeof(int) * c->mc.ns, hipMemcpyDeviceToHost, c->s_mc));
+                HIP_TRY(c, hipStreamSynchronize(c->s_mc));
+                for (int b : bad) log_path |= (b != 0);
+                if (log_path) c->last_path = 3;
+            }
+        }
+        if (log_path) {
+            c->n_launch[0] = c->n_launch[1] = 0;
+            c->n_far[0] = c->n_far[1] = 0;
+            HIP_TRY(c, hipEventRecord(c->ev[0], c->s_mc));
+            HIP_TRY(c, hipMemsetAsync(c->d_bp, 0, sizeof(double) * c->mc.tri_stride * c->mc.ns, c->s_mc));
+            if ((rc = launch_mc_vienna(c, pin))) return rc;
+            if (c->last_path == 0) c->last_path = 2;
+        }
     } else if (c->has_mc && c->mode != RH_MODE_LOG && !skip_mc) {
         if ((rc = run_graphed(c, c->g_in, shape_key(c, 0), c->s_mc, &c->n_launch[0], &c->n_far[0], [&] { return launch_mc_lin_any(c, pin, 0); }))) return rc;
         HIP_TRY(c, hipEventRecord(c->ev[1], c->s_mc));
@@ -992,7 +1030,7 @@ void rh_destroy(rh_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    void* bufs[] = {c->d_seq, c->d_n, c->d_mctab, c->d_f5, c->d_bp, c->d_up, c->d_dxtab, c->d_hp, c->d_logz, c->d_scal, c->d_mclogz, c->d_bad, c->d_cnt, c->d_cand, c->d_dxbad, c->d_zbar, c->d_gaps, c->d_coseq, c->d_con, c->d_cotab, c->d_cof5, c->d_cobp, c->d_vlin, c->d_model, c->d_lin, c->d_dxlin, c->d_vienna};
+    void* bufs[] = {c->d_seq, c->d_n, c->d_mctab, c->d_f5, c->d_bp, c->d_up, c->d_dxtab, c->d_hp, c->d_logz, c->d_scal, c->d_mclogz, c->d_bad, c->d_cnt, c->d_cand, c->d_dxbad, c->d_zbar, c->d_gaps, c->d_coseq, c->d_con, c->d_cotab, c->d_cof5, c->d_cobp, c->d_vlin, c->d_hplen, c->d_model, c->d_lin, c->d_dxlin, c->d_vienna};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (GraphSlot* g : {&c->g_in, &c->g_out, &c->g_dx}) if (g->exec) (void)hipGraphExecDestroy(g->exec);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -1248,9 +1286,10 @@ int rh_batch_kernels(rh_ctx* c, const char* fine[3], const char* far[3], int n_f
     static thread_local std::string names[6];
     const std::string w = std::to_string(c->lin_w == 16 ? 16 : 8), bs = std::to_string(c->lin_bs == 0 || c->lin_bs == 32 ? c->lin_bs : 16);
     const bool vienna = c->model == RH_MODEL_VIENNA_BL, lin = c->last_path == 1;
-    names[0] = !c->has_mc ? "" : vienna ? "mcv_inside_diag" : lin ? "lin_inside_diag<" + w + ", " + bs + ">" : "mc_inside_diag";
-    names[1] = !c->has_mc ? "" : vienna ? "mcv_outside_diag" : lin ? "lin_outside_diag<" + w + ", " + bs + ">" : "mc_outside_diag";
-    names[2] = !c->has_dx ? "" : vienna ? "dxv_sweep_diag" : c->last_dx_path == 1 ? "dxl_sweep<" + std::to_string(c->dx_w == 2 || c->dx_w == 8 ? c->dx_w : 4) + ">" : "dx_sweep_diag";
+    const std::string pre = vienna ? "vlin_" : "lin_";
+    names[0] = !c->has_mc ? "" : lin ? pre + "inside_diag<" + w + ", " + bs + ">" : vienna ? "mcv_inside_diag" : "mc_inside_diag";
+    names[1] = !c->has_mc ? "" : lin ? pre + "outside_diag<" + w + ", " + bs + ">" : vienna ? "mcv_outside_diag" : "mc_outside_diag";
+    names[2] = !c->has_dx ? "" : vienna ? (c->hybrid == RH_HYBRID_COFOLD ? "mcv_inside_diag / mcv_outside_diag (s1+s2)" : "dxv_sweep_diag") : c->last_dx_path == 1 ? "dxl_sweep<" + std::to_string(c->dx_w == 2 || c->dx_w == 8 ? c->dx_w : 4) + ">" : "dx_sweep_diag";
     const bool mfma = c->far_mfma && c->lin_bs != 0 && c->lin_bs != 32;
     names[3] = (c->has_mc && lin && c->n_far[0]) ? (mfma ? "lin_far_inside_mfma" : "lin_far_inside<" + bs + ">") : "";
     names[4] = (c->has_mc && lin && c->n_far[1]) ? (mfma ? "lin_far_outside_mfma" : "lin_far_outside<" + bs + ">") : "";

@@ -290,10 +290,14 @@ def test_vienna_bl_duplex_vs_its_cpu_restatement(hotlib, golden):
     c.close()
 
 
-@pytest.fixture(scope="module")
-def vctx(hotlib):
+@pytest.fixture(scope="module", params=["auto", "log"])
+def vctx(hotlib, request):
+    """Vienna-BL context per arithmetic path: "auto" = scaled linear kernels (mccaskill_vlin.hip) with log-space
+    fallback, "log" = log-space kernels only (mccaskill_vienna.hip)."""
     import ractip_amd
     c = ractip_amd.Context(device=0, model=ractip_amd.hot.RH_MODEL_VIENNA_BL)
+    c.set_mode({"auto": 0, "log": 1}[request.param])
+    c.path_name = request.param
     yield c
     c.close()
 
@@ -318,10 +322,30 @@ def test_vienna_bl_mccaskill_and_accessibility_vs_cpu_restatement(vctx, golden):
         assert_prob_close(up, o["up"], rel=REL, abs_floor=1e-11, what="vienna up n=%d" % n)
         bp2, z2 = vctx.bpp(s)
         assert np.array_equal(bp, bp2) and z == z2
+    assert vctx.last_path() == (1 if vctx.path_name == "auto" else 2)
     # another width through rh_unpaired
     s = seqs[1]
     assert_prob_close(vctx.unpaired(s, max_w=4), vo.mccaskill(s, max_w=4)["up"], rel=REL, abs_floor=1e-11, what="up w=4")
     vctx.set_max_w(15)
+
+
+def test_vienna_bl_linear_path_falls_back_on_overflow(vctx):
+    """A 1200-nt perfect GC helix has log Z ~ 2.5 per nucleotide: the scaled linear values leave the double range, the
+    device flags it and the batch is recomputed in log space; results equal the log-space context's."""
+    if vctx.path_name != "auto":
+        pytest.skip("fallback logic belongs to the auto path")
+    import ractip_amd
+    s = "G" * 600 + "AAAA" + "C" * 600
+    bp, z = vctx.bpp(s)
+    assert vctx.last_path() == 3
+    ref = ractip_amd.Context(device=0, model=ractip_amd.hot.RH_MODEL_VIENNA_BL)
+    ref.set_mode(1)
+    bp2, z2 = ref.bpp(s)
+    ref.close()
+    assert np.array_equal(bp, bp2) and z == z2 and np.isfinite(z) and z > 1000
+    n = len(s)
+    o = tri_offset(n, 300)
+    assert bp[o + 301:o + n + 1].sum() > 0.99              # a G in the middle of the run is paired (the helix may slip)
 
 
 def test_vienna_bl_pair_batch(vctx, golden):
