@@ -62,6 +62,8 @@ const char* rh_last_error(const rh_ctx* ctx);
 int rh_set_mode(rh_ctx* ctx, int mode);
 /* path taken by the last compute: 1 = linear, 2 = log-space, 3 = linear, then log-space fallback */
 int rh_last_path(const rh_ctx* ctx);
+/* the same for the sweeps that produced hp (duplex or two-molecule ensemble) */
+int rh_last_hybrid_path(const rh_ctx* ctx);
 
 /* Base-pairing probabilities of one sequence.  Replaces the body of
  * RactIP::contrafold up to GetPosterior (src/ractip.cpp:199-211:

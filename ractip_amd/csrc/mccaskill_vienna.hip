@@ -599,12 +599,21 @@ __global__ __launch_bounds__(256) void mcv_acc_final(McBatch B, const ViennaDx* 
 
 // two-molecule batch: hp[p][i][j] = P(letter i of s1 pairs letter j of s2) = joint pair matrix entry (i, cut+j), the copy
 // of /root/reference/src/ractip.cpp:451-454 without its threshold (the host adapter applies th_hy); logz[p] = F5i[n]
-__global__ __launch_bounds__(256) void mcv_extract_hp(McBatch B, double* __restrict__ hp, size_t hp_stride, int ldd, double* __restrict__ logz)
+// lin_s >= 0: the tables are in scaled linear space (mccaskill_vlin.hip): log Z = log F5i~[n] + lin_s*n, and a Z~ outside the
+// safe double range flags the pair for the log-space recomputation
+__global__ __launch_bounds__(256) void mcv_extract_hp(McBatch B, double* __restrict__ hp, size_t hp_stride, int ldd, double* __restrict__ logz,
+                                                      double lin_s, int* __restrict__ bad)
 {
     const int p = blockIdx.y;
     const int n = B.n[p], n1 = B.cut[p], n2 = n - n1;
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0) logz[p] = B.f5i[(size_t)p * B.ld + n];
+    if (c == 0) {
+        const double z = B.f5i[(size_t)p * B.ld + n];
+        if (lin_s >= 0.0) {
+            if (!(z > 1e-200 && z < 1e200)) atomicOr(&bad[p], 1);
+            logz[p] = log(z) + lin_s * (double)n;
+        } else logz[p] = z;
+    }
     if (c >= n1 * n2) return;
     const int i = c / n2 + 1, j = c % n2 + 1;
     hp[(size_t)p * hp_stride + (size_t)i * ldd + j] = B.bp[(size_t)p * B.tri_stride + tri_offset_v(n, i) + n1 + j];

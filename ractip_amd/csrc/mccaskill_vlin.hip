@@ -58,6 +58,24 @@ __device__ __forceinline__ double vfilt_rev(const double* __restrict__ wt, const
     }
     return s0 + s1;
 }
+// the same filters with a per-lane limit on each gap (two-molecule form: a loop side may not cross the missing gap).
+// Only the few 64-cell groups next to the gap take this path: a rolled loop, taps outside [lo, hi] are skipped per lane.
+__device__ __forceinline__ double vfilt_fwd_m(int t, const double* __restrict__ wt, const double* seg, int l1max, int l2max)
+{
+    const int lo = t - l2max > 0 ? t - l2max : 0, hi = t < l1max ? t : l1max;
+    double s0 = 0.0;
+#pragma unroll 1
+    for (int l1 = 0; l1 <= t; l1++) s0 += (l1 >= lo && l1 <= hi) ? wt[l1] * seg[l1] : 0.0;
+    return s0;
+}
+__device__ __forceinline__ double vfilt_rev_m(int t, const double* __restrict__ wt, const double* seg, int l1max, int l2max)
+{
+    const int lo = t - l2max > 0 ? t - l2max : 0, hi = t < l1max ? t : l1max;
+    double s0 = 0.0;
+#pragma unroll 1
+    for (int l1 = 0; l1 <= t; l1++) s0 += (l1 >= lo && l1 <= hi) ? wt[l1] * seg[t - l1] : 0.0;
+    return s0;
+}
 // generic loops need l1, l2 >= 1 and t >= 4 (1x1, 1x2, 2x1 are tabulated; 2x2 has weight 0 in shape_w)
 #define RH_VT_CASES(X) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) \
     X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30)
@@ -79,6 +97,8 @@ __device__ __forceinline__ double vfilt_rev_any(int t, const double* __restrict_
     }
     return 0.0;
 }
+// letters g and g+1 are neighbours on one strand (cut = 0: one molecule, never equals a gap index >= 1)
+__device__ __forceinline__ bool gap_ok_vl(int cut, int g) { return g != cut; }
 
 // the seven tabulated loop shapes: outer pair type t1, inner pair type t2 (0: the letters do not pair), letters si1/sj1
 // next to the outer pair inside the loop, sp1/sq1 next to the inner pair
@@ -96,6 +116,7 @@ __device__ __forceinline__ double small_w(const VLinModel* L, int l1, int l2, in
 
 }  // namespace
 
+#define GAPOK(g) (!CUT || gap_ok_vl(cut, (g)))
 // table slots: 3, 4, 7, 10, 11, 12 are the ones mccaskill_far.hip addresses (LinTableFar)
 enum VLinTable { VL_FC = 0, VL_FCX, VL_FCA, VL_FM1, VL_FM, VL_FCO, VL_FCOX, VL_FM2O, VL_FMSO, VL_FM1O,
                  VL_FM2F, VL_FMOF, VL_FM1OF, VL_FMS, VL_FCB, VL_FCOB, VL_COUNT };
@@ -108,11 +129,19 @@ __global__ void vlin_init(McBatch B, int* __restrict__ bad)
     B.f5i[(size_t)sq * B.ld] = 1.0;
     B.f5o[(size_t)sq * B.ld + B.n[sq]] = 1.0;
     bad[sq] = 0;
+    const int cut = B.cut ? B.cut[sq] : 0;
+    if (cut > 0) {   // two-molecule form: exterior halves of the loop around the missing gap (see mccaskill_vienna.hip)
+        const size_t o = (size_t)sq * B.ld;
+        B.xp[o + cut] = 1.0;
+        B.xs[o + cut + 1] = 1.0;
+        B.xpo[o + B.n[sq]] = 0.0;
+        B.xso[o + 1] = 0.0;
+    }
 }
 
 // ---------------------------------------------------------------------------------
 // inside, diagonal d.  hp_d = lam^d * hairpin length weight of a loop of d unpaired letters.
-template <int W, int BS>
+template <int W, int BS, bool CUT>
 __global__ __launch_bounds__(64 * W) void vlin_inside_diag(McBatch B, const VLinModel* __restrict__ L, int d, double hp_d, int pin)
 {
     __shared__ double part[3][W][64];
@@ -124,7 +153,8 @@ __global__ __launch_bounds__(64 * W) void vlin_inside_diag(McBatch B, const VLin
     if (d > n - 1) return;
     const int ncell = n - 1 - d > 0 ? n - 1 - d : 0;
     const int ngroup = (ncell + 63) >> 6;
-    if (slot > ngroup) return;
+    const int cut = CUT ? B.cut[sq] : 0;   // CUT = false: one molecule per sequence, every gap test folds away
+    if (slot > ngroup + (CUT ? 2 : 0)) return;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int ld = B.ld;
     const size_t ts = B.tab_stride;
@@ -132,6 +162,28 @@ __global__ __launch_bounds__(64 * W) void vlin_inside_diag(McBatch B, const VLin
     double* __restrict__ tab = B.tab + (size_t)sq * B.seq_stride;
     double* __restrict__ f5i = B.f5i + sq * ld;
 
+    if (slot > ngroup) {
+        // XP~[b], b = cut+d+1 (exterior partition function of s2's prefix cut+1..b) or XS~[a], a = cut-d (s1's suffix a..cut)
+        const bool is_xp = slot == ngroup + 1;
+        const double* __restrict__ fca = tab + VL_FCA * ts;
+        double* __restrict__ xv = (is_xp ? B.xp : B.xs) + (size_t)sq * ld;
+        const int b = cut + d + 1, a = cut - d;
+        if (is_xp ? b > n : a < 1) return;
+        double acc = 0.0;
+        if (is_xp) for (int k = cut + threadIdx.x; k <= b - 2; k += 64 * W) acc = fma(xv[k], fca[(b - k - 2) * ld + (k + 1)], acc);
+        else for (int l = a + 4 + threadIdx.x; l <= cut; l += 64 * W) acc = fma(fca[(l - 1 - a) * ld + a], xv[l + 1], acc);
+        acc = wsum_vl(acc);
+        if (lane == 0) part[0][w][0] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+#pragma unroll
+            for (int k = 0; k < W; k++) t += part[0][k][0];
+            if (is_xp) xv[b] = xv[b - 1] * L->lam + t * L->lam2;
+            else xv[a] = xv[a + 1] * L->lam + t * L->lam2;
+        }
+        return;
+    }
     if (slot == ngroup) {
         // F5i~[jj] = F5i~[jj-1]*lam + sum_{k<=jj-2} F5i~[k]*FCA~[k+1,jj-1]*lam^2
         const int jj = d + 1;
@@ -156,26 +208,35 @@ __global__ __launch_bounds__(64 * W) void vlin_inside_diag(McBatch B, const VLin
     if (valid) { s_im1 = s[i - 1]; s_i = s[i]; s_ip1 = s[i + 1]; s_j = s[j]; s_jp1 = s[j + 1]; s_jp2 = s[j + 2]; }
     const int type = L->ptype[s_i * 5 + s_jp1];
     const bool pairable = valid && type != 0;
+    // two-molecule form: the missing gap inside the pair limits both sides of an enclosed loop to their own strand
+    const bool nick_in = CUT && valid && i <= cut && cut <= j;
+    const int l1max = nick_in ? cut - i - 1 : 99, l2max = nick_in ? j - cut - 1 : 99;
+    const bool masked = CUT && __any(l1max < kMaxSingle || l2max < kMaxSingle);   // the same for all W wavefronts of the group
 
     // epilogue operands (wave 0 only), issued ahead of the term loops
     const size_t at = d * ld + i;
     const int idx = 25 * (5 * s_i + s_ip1) + 5 * s_jp1 + s_j;       // (i,j+1) seen from inside
-    const int idd = 25 * (5 * s_jp1 + s_jp2) + 5 * s_i + s_im1;     // seen from outside
-    double e_txo = 0, e_tmc = 0, e_tmh = 0, e_txi = 0, e_tsa = 0, e_tau = 1, e_tet = 1;
+    // seen from outside; a neighbour on the other molecule gives no dangle (letter code 0)
+    const int idd = 25 * (5 * s_jp1 + (GAPOK(j + 1) ? s_jp2 : 0)) + 5 * s_i + (GAPOK(i - 1) ? s_im1 : 0);
+    const int idx_raw = 25 * (5 * s_jp1 + s_jp2) + 5 * s_i + s_im1;
+    double e_txo = 0, e_tmc = 0, e_tmh = 0, e_txi = 0, e_tsa = 0, e_tau = 1, e_tet = 1, nick = 0.0;
     double o_fca = 0, o_fm1 = 0, o_fms = 0, sm7 = 0.0;
     if (w == 0 && valid) {
         e_txo = L->TXO[idx]; e_tmc = L->TMC[idx]; e_tmh = L->TMH[idx];
-        e_txi = L->TXI[idd]; e_tsa = L->TSA[idd]; e_tau = L->E_tau[type];
+        e_txi = L->TXI[idx_raw]; e_tsa = L->TSA[idd]; e_tau = L->E_tau[type];
+        if (nick_in && pairable && d >= kMinHairpin)
+            nick = B.xs[(size_t)sq * ld + i + 1] * B.xp[(size_t)sq * ld + j] *
+                   L->TNC[25 * (5 * s_i + (GAPOK(i) ? s_ip1 : 0)) + 5 * s_jp1 + (GAPOK(j) ? s_j : 0)];
         if (d == 4 && pairable) {   // tetraloop bonus: closing pair + 4 loop letters
             int code = 0; bool ok = true;
 #pragma unroll
             for (int k = 0; k < 6; k++) { const int c = s[i + k]; ok = ok && c != 0; code = code * 4 + (c - 1); }
             if (ok) e_tet = L->E_tetra[code];
         }
-        if (d >= 2) {
-            o_fca = tab[VL_FCA * ts + (d - 2) * ld + i + 1];
-            o_fm1 = tab[VL_FM1 * ts + (d - 1) * ld + i + 1];
-            o_fms = tab[VL_FMS * ts + (d - 1) * ld + i];
+        if (d >= 2) {   // a multiloop element may not touch the missing gap
+            if (GAPOK(i) && GAPOK(j)) o_fca = tab[VL_FCA * ts + (d - 2) * ld + i + 1];
+            if (GAPOK(i) && GAPOK(i + 1)) o_fm1 = tab[VL_FM1 * ts + (d - 1) * ld + i + 1];
+            if (GAPOK(j - 1) && GAPOK(j)) o_fms = tab[VL_FMS * ts + (d - 1) * ld + i];
         }
         if (pairable && d >= 2) {
             // the seven tabulated shapes: inner pair letters (p, q) = (i+1+l1, j-l2), raw table cell (p, q-1)
@@ -185,7 +246,7 @@ __global__ __launch_bounds__(64 * W) void vlin_inside_diag(McBatch B, const VLin
                 const int l1 = (k == 2 || k == 3 || k == 4) ? 1 : (k >= 5 ? 2 : 0);
                 const int l2 = (k == 1 || k == 3 || k == 5) ? 1 : ((k == 4 || k == 6) ? 2 : 0);
                 const int t = l1 + l2;
-                if (d - 2 - t >= 0) {
+                if (d - 2 - t >= 0 && l1 <= l1max && l2 <= l2max) {
                     const int p = i + 1 + l1, q = j - l2;
                     const int t2 = L->ptype[s[p] * 5 + s[q]];
                     const double v = fc[(d - 2 - t) * ld + p];
@@ -253,15 +314,18 @@ __global__ __launch_bounds__(64 * W) void vlin_inside_diag(McBatch B, const VLin
                     if (lane < 32) gbuf[w][q][64 + lane] = col0 + 64 + lane < ld ? row[64 + lane] : 0.0;
                 }
                 if (valid) {   // bulge of length t on the 3' side (l1 = 0) and on the 5' side (l1 = t)
-                    b0[q] = fcb[(d - 2 - t) * ld + i + 1];
-                    b1[q] = fcb[(d - 2 - t) * ld + i + 1 + t];
+                    if (l1max >= 0 && t <= l2max) b0[q] = fcb[(d - 2 - t) * ld + i + 1];
+                    if (t <= l1max && l2max >= 0) b1[q] = fcb[(d - 2 - t) * ld + i + 1 + t];
                 }
             }
         }
 #pragma unroll
         for (int q = 0; q < NSEG; q++)
             if (tseg[q] >= 0) {
-                if (tseg[q] >= 4) accc += vfilt_fwd_any(tseg[q], L->shape_w + tseg[q] * (tseg[q] + 1) / 2, &gbuf[w][q][lane]);
+                if (tseg[q] >= 4) {
+                    const double* __restrict__ wt = L->shape_w + tseg[q] * (tseg[q] + 1) / 2;
+                    accc += masked ? vfilt_fwd_m(tseg[q], wt, &gbuf[w][q][lane], l1max, l2max) : vfilt_fwd_any(tseg[q], wt, &gbuf[w][q][lane]);
+                }
                 accb = fma(L->WB[tseg[q]], b0[q] + b1[q], accb);
             }
         if (!pairable) { accc = 0.0; accb = 0.0; }
@@ -279,7 +343,7 @@ __global__ __launch_bounds__(64 * W) void vlin_inside_diag(McBatch B, const VLin
     double fc = 0.0;
     if (pairable) {
         double hp = 0.0;
-        if (d >= 3) hp = hp_d * (d == 3 ? e_tau : e_tmh * e_tet);
+        if (d >= 3) hp = nick_in ? nick : hp_d * (d == 3 ? e_tau : e_tmh * e_tet);
         fc = e_txo * g + e_tau * gb + sm7 + hp + fm2 * e_tmc;
     }
     double fm1v = 0.0, fmsv = 0.0, fmv = 0.0;
@@ -299,7 +363,7 @@ __global__ __launch_bounds__(64 * W) void vlin_inside_diag(McBatch B, const VLin
 
 // ---------------------------------------------------------------------------------
 // outside (pull form) + posterior, diagonal d; last group: F5o~[d+1]
-template <int W, int BS>
+template <int W, int BS, bool CUT>
 __global__ __launch_bounds__(64 * W) void vlin_outside_diag(McBatch B, const VLinModel* __restrict__ L, int d, int pin, int* __restrict__ bad)
 {
     __shared__ double part[4][W][64];
@@ -311,7 +375,8 @@ __global__ __launch_bounds__(64 * W) void vlin_outside_diag(McBatch B, const VLi
     const int ncell = n - 1 - d;
     if (ncell < 1) return;
     const int ngroup = (ncell + 63) >> 6;
-    if (slot > ngroup) return;
+    const int cut = CUT ? B.cut[sq] : 0;   // CUT = false: one molecule per sequence, every gap test folds away
+    if (slot > ngroup + (CUT ? 2 : 0)) return;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int ld = B.ld;
     const size_t ts = B.tab_stride;
@@ -320,6 +385,46 @@ __global__ __launch_bounds__(64 * W) void vlin_outside_diag(McBatch B, const VLi
     const double* __restrict__ f5i = B.f5i + sq * ld;
     double* __restrict__ f5o = B.f5o + sq * ld;
 
+    if (slot > ngroup) {
+        // XPo~[b], b = cut+d+1 <= n-1, or XSo~[a], a = cut-d >= 2: outside counterparts of the exterior halves (pull form;
+        // the pairs around the missing gap that feed them have spans >= d+1 and are final)
+        const bool is_xp = slot == ngroup + 1;
+        const int b = cut + d + 1, a = cut - d;
+        if (is_xp ? b > n - 1 : a < 2) return;
+        const double* __restrict__ fco = tab + VL_FCO * ts;
+        const double* __restrict__ fca = tab + VL_FCA * ts;
+        double acc = 0.0, acc2 = 0.0;
+        if (is_xp) {
+            const double* __restrict__ xs = B.xs + (size_t)sq * ld;
+            const double* __restrict__ xpo = B.xpo + (size_t)sq * ld;
+            for (int i = 1 + threadIdx.x; i <= cut; i += 64 * W) {
+                if (b + 1 - i < 4 || !L->ptype[s[i] * 5 + s[b + 1]]) continue;
+                const int ix = 25 * (5 * s[i] + (GAPOK(i) ? s[i + 1] : 0)) + 5 * s[b + 1] + (GAPOK(b) ? s[b] : 0);
+                acc = fma(fco[(b - i) * ld + i] * L->TNC[ix], xs[i + 1], acc);
+            }
+            for (int bb = b + 2 + threadIdx.x; bb <= n; bb += 64 * W) acc2 = fma(xpo[bb], fca[(bb - b - 2) * ld + b + 1], acc2);
+        } else {
+            const double* __restrict__ xp = B.xp + (size_t)sq * ld;
+            const double* __restrict__ xso = B.xso + (size_t)sq * ld;
+            for (int j = cut + threadIdx.x; j <= n - 1; j += 64 * W) {
+                if (j + 1 - (a - 1) < 4 || !L->ptype[s[a - 1] * 5 + s[j + 1]]) continue;
+                const int ix = 25 * (5 * s[a - 1] + (GAPOK(a - 1) ? s[a] : 0)) + 5 * s[j + 1] + (GAPOK(j) ? s[j] : 0);
+                acc = fma(fco[(j - a + 1) * ld + a - 1] * L->TNC[ix], xp[j], acc);
+            }
+            for (int aa = 1 + threadIdx.x; aa <= a - 2; aa += 64 * W) acc2 = fma(xso[aa], fca[(a - 2 - aa) * ld + aa], acc2);
+        }
+        acc = wsum_vl(acc); acc2 = wsum_vl(acc2);
+        if (lane == 0) { part[0][w][0] = acc; part[1][w][0] = acc2; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0, t2 = 0.0;
+#pragma unroll
+            for (int q = 0; q < W; q++) { t += part[0][q][0]; t2 += part[1][q][0]; }
+            if (is_xp) { double* xpo = B.xpo + (size_t)sq * ld; xpo[b] = t + xpo[b + 1] * L->lam + t2 * L->lam2; }
+            else { double* xso = B.xso + (size_t)sq * ld; xso[a] = t + xso[a - 1] * L->lam + t2 * L->lam2; }
+        }
+        return;
+    }
     if (slot == ngroup) {
         const int k = d + 1;
         const double* __restrict__ fca = tab + VL_FCA * ts + (k + 1);
@@ -345,23 +450,31 @@ __global__ __launch_bounds__(64 * W) void vlin_outside_diag(McBatch B, const VLi
     const int type = L->ptype[s_i * 5 + s_jp1];
     const bool pairable = valid && type != 0;
     const bool guard_m = d >= 2;
+    // two-molecule form: the sides of an ENCLOSING loop (letters io..i and j+1..jo+1) may not cross the missing gap
+    const int l1max = (CUT && valid && cut <= i - 1) ? i - 2 - cut : 99;
+    const int l2max = (CUT && valid && cut >= j + 1) ? cut - j - 2 : 99;
+    const bool masked = CUT && __any(l1max < kMaxSingle || l2max < kMaxSingle);
 
     const size_t at = d * ld + i;
     const bool up_ok = i - 1 >= 1 && j + 1 <= n - 1;
     const int idx = 25 * (5 * s_i + s_ip1) + 5 * s_jp1 + s_j;
-    const int idd = 25 * (5 * s_jp1 + s_jp2) + 5 * s_i + s_im1;
+    const int idd = 25 * (5 * s_jp1 + (GAPOK(j + 1) ? s_jp2 : 0)) + 5 * s_i + (GAPOK(i - 1) ? s_im1 : 0);
+    const int idx_raw = 25 * (5 * s_jp1 + s_jp2) + 5 * s_i + s_im1;
     double e_txo = 0, e_tmc = 0, e_txi = 0, e_tsa = 0, e_tau = 1;
-    double o_fmso = 0, o_fm1o = 0, o_f5o = 0, o_f5i = 0, o_fm1o_up = 0, o_fc = 0, o_z = 1, sm7 = 0.0;
+    double o_fmso = 0, o_fm1o = 0, o_f5o = 0, o_f5i = 0, o_fm1o_up = 0, o_fc = 0, o_z = 1, sm7 = 0.0, o_x = 0.0;
     if (w == 0 && valid) {
         e_txo = L->TXO[idx]; e_tmc = L->TMC[idx];
-        e_txi = L->TXI[idd]; e_tsa = L->TSA[idd]; e_tau = L->E_tau[type];
+        e_txi = L->TXI[idx_raw]; e_tsa = L->TSA[idd]; e_tau = L->E_tau[type];
         if (guard_m) {
-            if (j + 1 <= n - 1) o_fmso = tab[VL_FMSO * ts + (d + 1) * ld + i];
-            if (i - 1 >= 1) o_fm1o = tab[VL_FM1O * ts + (d + 1) * ld + i - 1];
+            if (j + 1 <= n - 1 && GAPOK(j) && GAPOK(j + 1)) o_fmso = tab[VL_FMSO * ts + (d + 1) * ld + i];
+            if (i - 1 >= 1 && GAPOK(i - 1) && GAPOK(i)) o_fm1o = tab[VL_FM1O * ts + (d + 1) * ld + i - 1];
         }
         o_f5o = f5o[j + 1]; o_f5i = f5i[i - 1]; o_z = f5i[n];
         o_fc = tab[VL_FC * ts + at];
-        if (up_ok) o_fm1o_up = tab[VL_FM1O * ts + (d + 2) * ld + i - 1];
+        if (up_ok && GAPOK(i - 1) && GAPOK(j + 1)) o_fm1o_up = tab[VL_FM1O * ts + (d + 2) * ld + i - 1];
+        // stem of one of the exterior halves of the loop around the missing gap
+        if (CUT && i > cut) o_x = B.xpo[(size_t)sq * ld + j + 1] * B.xp[(size_t)sq * ld + i - 1];
+        if (CUT && j + 1 <= cut) o_x = B.xso[(size_t)sq * ld + i] * B.xs[(size_t)sq * ld + j + 2];
         if (pairable) {
             // the seven tabulated shapes: outer pair letters (io, jo+1) = (i-1-l1, j+2+l2), raw outside cell (io, jo)
             const double* __restrict__ fco = tab + VL_FCO * ts;
@@ -370,7 +483,7 @@ __global__ __launch_bounds__(64 * W) void vlin_outside_diag(McBatch B, const VLi
                 const int l1 = (k == 2 || k == 3 || k == 4) ? 1 : (k >= 5 ? 2 : 0);
                 const int l2 = (k == 1 || k == 3 || k == 5) ? 1 : ((k == 4 || k == 6) ? 2 : 0);
                 const int io = i - 1 - l1, jo = j + 1 + l2;
-                if (io >= 1 && jo <= n - 1) {
+                if (io >= 1 && jo <= n - 1 && l1 <= l1max && l2 <= l2max) {
                     const int to = L->ptype[s[io] * 5 + s[jo + 1]];
                     const double v = fco[(jo - io) * ld + io];
                     sm7 = fma(v, small_w(L, l1, l2, to, type, s[io + 1], s[jo], s_im1, s_jp2), sm7);
@@ -454,15 +567,18 @@ __global__ __launch_bounds__(64 * W) void vlin_outside_diag(McBatch B, const VLi
                     if (valid) {   // outer pair (i-1, j+2+t): bulge on the 3' side; (i-1-t, j+2): on the 5' side
                         const double* __restrict__ row = fcob + (d + 2 + t) * ld;
                         const int c0 = i - 1, c1 = i - 1 - t;
-                        b0[q] = (c0 >= 1 && c0 <= cmax) ? row[c0] : 0.0;
-                        b1[q] = (c1 >= 1 && c1 <= cmax) ? row[c1] : 0.0;
+                        b0[q] = (c0 >= 1 && c0 <= cmax && l1max >= 0 && t <= l2max) ? row[c0] : 0.0;
+                        b1[q] = (c1 >= 1 && c1 <= cmax && t <= l1max && l2max >= 0) ? row[c1] : 0.0;
                     }
                 }
             }
 #pragma unroll
             for (int q = 0; q < NSEG; q++)
                 if (tseg[q] >= 0) {
-                    if (tseg[q] >= 4) accc += vfilt_rev_any(tseg[q], L->shape_w + tseg[q] * (tseg[q] + 1) / 2, &gbuf[w][q][lane]);
+                    if (tseg[q] >= 4) {
+                        const double* __restrict__ wt = L->shape_w + tseg[q] * (tseg[q] + 1) / 2;
+                        accc += masked ? vfilt_rev_m(tseg[q], wt, &gbuf[w][q][lane], l1max, l2max) : vfilt_rev_any(tseg[q], wt, &gbuf[w][q][lane]);
+                    }
                     accb = fma(L->WB[tseg[q]], b0[q] + b1[q], accb);
                 }
             if (!pairable) { accc = 0.0; accb = 0.0; }
@@ -486,7 +602,7 @@ __global__ __launch_bounds__(64 * W) void vlin_outside_diag(McBatch B, const VLi
     }
     double fco = 0.0;
     if (pairable) {
-        const double ext = o_f5o * o_f5i * L->lam2;
+        const double ext = (o_f5o * o_f5i + o_x) * L->lam2;
         const double multi = o_fm1o_up * L->w_mp2;
         fco = e_tsa * (ext + multi) + e_txi * g + e_tau * gb + sm7;
     }
@@ -497,7 +613,7 @@ __global__ __launch_bounds__(64 * W) void vlin_outside_diag(McBatch B, const VLi
     tab[VL_FMSO * ts + at] = fmso;
     tab[VL_FM1O * ts + at] = fm1o;
     tab[VL_FM2O * ts + at] = fm2o;
-    double p = fco * o_fc / o_z;
+    double p = d >= kMinHairpin ? fco * o_fc / o_z : 0.0;
     if (!(p == p) || p > 1e300) { atomicOr(&bad[sq], 1); p = 0.0; }
     p = p > 1.0 ? 1.0 : (p < 0.0 ? 0.0 : p);
     B.bp[(size_t)sq * B.tri_stride + tri_off_vl(n, i) + (j + 1)] = p;
@@ -682,9 +798,10 @@ __global__ __launch_bounds__(256) void vlin_acc_final(McBatch B, const VLinModel
     *up = acc > 1.0 ? 1.0 : acc;
 }
 
-template __global__ void vlin_inside_diag<8, 16>(McBatch, const VLinModel*, int, double, int);
-template __global__ void vlin_outside_diag<8, 16>(McBatch, const VLinModel*, int, int, int*);
-template __global__ void vlin_inside_diag<8, 0>(McBatch, const VLinModel*, int, double, int);
-template __global__ void vlin_outside_diag<8, 0>(McBatch, const VLinModel*, int, int, int*);
+#define RH_VINST(BS, CUT)                                                                                \
+    template __global__ void vlin_inside_diag<8, BS, CUT>(McBatch, const VLinModel*, int, double, int);  \
+    template __global__ void vlin_outside_diag<8, BS, CUT>(McBatch, const VLinModel*, int, int, int*);
+RH_VINST(16, false) RH_VINST(0, false) RH_VINST(16, true) RH_VINST(0, true)
+#undef RH_VINST
 
 }  // namespace rh

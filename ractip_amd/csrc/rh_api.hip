@@ -58,10 +58,10 @@ __global__ void mcv_acc_gaps(McBatch B, const ViennaDx* __restrict__ V, double* 
 __global__ void mcv_acc_final(McBatch B, const ViennaDx* __restrict__ V, const double* __restrict__ gaps, int max_w);
 __global__ void mcv_finish(McBatch B, double* __restrict__ logz);
 __global__ void vlin_init(McBatch B, int* __restrict__ bad);
-template <int W, int BS> __global__ void vlin_inside_diag(McBatch B, const VLinModel* __restrict__ L, int d, double hp_d, int pin);
-template <int W, int BS> __global__ void vlin_outside_diag(McBatch B, const VLinModel* __restrict__ L, int d, int pin, int* __restrict__ bad);
+template <int W, int BS, bool CUT> __global__ void vlin_inside_diag(McBatch B, const VLinModel* __restrict__ L, int d, double hp_d, int pin);
+template <int W, int BS, bool CUT> __global__ void vlin_outside_diag(McBatch B, const VLinModel* __restrict__ L, int d, int pin, int* __restrict__ bad);
 __global__ void vlin_finish(McBatch B, const VLinModel* __restrict__ L, double* __restrict__ logz, int* __restrict__ bad);
-__global__ void mcv_extract_hp(McBatch B, double* __restrict__ hp, size_t hp_stride, int ldd, double* __restrict__ logz);
+__global__ void mcv_extract_hp(McBatch B, double* __restrict__ hp, size_t hp_stride, int ldd, double* __restrict__ logz, double lin_s, int* __restrict__ bad);
 }  // namespace rh
 
 using namespace rh;
@@ -282,6 +282,7 @@ struct rh_ctx {
     void* d_cotab = nullptr; size_t cap_cotab = 0;
     void* d_cof5 = nullptr;  size_t cap_cof5 = 0;    // f5i, f5o, xp, xs, xpo, xso
     void* d_cobp = nullptr;  size_t cap_cobp = 0;
+    void* d_cobad = nullptr; size_t cap_cobad = 0;
     double ms[4] = {0, 0, 0, 0};
     int n_launch[3] = {0, 0, 0};
     int n_far[3] = {0, 0, 0};      // of which block-product launches (mccaskill_far.hip)
@@ -477,6 +478,13 @@ int stage(rh_ctx* c, int ns, const char* const* seqs, const int* lens, bool with
             if ((rc = ensure(c, &c->d_cotab, &c->cap_cotab, sizeof(double) * C.seq_stride * np, false))) return rc;
             if ((rc = ensure(c, &c->d_cof5, &c->cap_cof5, sizeof(double) * 6 * C.ld * np, false))) return rc;
             if ((rc = ensure(c, &c->d_cobp, &c->cap_cobp, sizeof(double) * C.tri_stride * np, false))) return rc;
+            if ((rc = ensure(c, &c->d_cobad, &c->cap_cobad, sizeof(int) * np, false))) return rc;
+            if ((int)c->h_hplen.size() < C.ld) {   // hairpin length weights up to the joint length (see the single-molecule batch)
+                const VLinModel& H = *c->h_vlin;
+                c->h_hplen.resize((size_t)C.ld);
+                for (int d = 0; d < C.ld; d++)
+                    c->h_hplen[d] = (d <= 30 ? H.E_hairpin[d] : std::exp(H.hairpin30 - H.lxc * std::log(d / 30.0))) * std::exp(-H.s * d);
+            }
             HIP_TRY(c, hipMemcpyAsync(c->d_coseq, cc.data(), cc.size(), hipMemcpyHostToDevice, c->s_dx));
             HIP_TRY(c, hipMemcpyAsync(c->d_con, nn.data(), sizeof(int) * nn.size(), hipMemcpyHostToDevice, c->s_dx));
             HIP_TRY(c, hipStreamSynchronize(c->s_dx));
@@ -540,26 +548,33 @@ int launch_mc_vienna(rh_ctx* c, int pin)
     return RH_OK;
 }
 
-// ---- Vienna-BL McCaskill sweeps, scaled linear-space path (mccaskill_vlin.hip) with the block products of mccaskill_far.hip
+// ---- Vienna-BL McCaskill sweeps, scaled linear-space path (mccaskill_vlin.hip) with the block products of mccaskill_far.hip.
+// co = false: the single-molecule batch on the McCaskill stream (+ accessibility); co = true: the s1+s2 batch of the
+// two-molecule hybridization matrix on the duplex stream (two more groups per launch for the exterior halves XS / XP)
 template <int BS>
-int launch_mc_vlin(rh_ctx* c, int pin, int phase)
+int launch_mc_vlin(rh_ctx* c, int pin, int phase, bool co)
 {
     constexpr int W = 8;
-    const McBatch& B = c->mc;
-    int* bad = (int*)c->d_bad;
+    const McBatch& B = co ? c->co : c->mc;
+    hipStream_t st = co ? c->s_dx : c->s_mc;
+    int* bad = (int*)(co ? c->d_cobad : c->d_bad);
+    int* nl = co ? &c->n_launch[2] : (phase == 0 ? &c->n_launch[0] : &c->n_launch[1]);
+    int* nf = co ? &c->n_far[2] : (phase == 0 ? &c->n_far[0] : &c->n_far[1]);
+    const int extra = co ? 3 : 1;   // F5 (+ XP, XS)
     const int last_block = BS > 0 ? (B.nmax - 1) / BS : 0;
     if (phase == 0) {
-        hipLaunchKernelGGL(vlin_init, dim3((B.ns + 63) / 64), dim3(64), 0, c->s_mc, B, bad);
+        hipLaunchKernelGGL(vlin_init, dim3((B.ns + 63) / 64), dim3(64), 0, st, B, bad);
         for (int d = 0; d <= B.nmax - 1; d++) {
-            const int groups = (std::max(B.nmax - 1 - d, 0) + 63) / 64 + 1;
+            const int groups = (std::max(B.nmax - 1 - d, 0) + 63) / 64 + extra;
             const double hp_d = c->h_hplen[d];
-            KLAUNCH(c, 0, (vlin_inside_diag<W, BS>), pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(64 * W), c->s_mc, B, c->d_vlin, d, hp_d, pin);
-            c->n_launch[0]++;
+            if (co) KLAUNCH(c, 0, (vlin_inside_diag<W, BS, true>), pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(64 * W), st, B, c->d_vlin, d, hp_d, pin);
+            else KLAUNCH(c, 0, (vlin_inside_diag<W, BS, false>), pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(64 * W), st, B, c->d_vlin, d, hp_d, pin);
+            (*nl)++;
             if (BS > 0 && (d + 1) % BS == 0) {
                 const int D = (d + 1) / BS + 1;
                 if (D >= 4 && D <= last_block) {
-                    KLAUNCH(c, 1, lin_far_inside_mfma, dim3(last_block - D + 1, B.ns), dim3(256), c->s_mc, B, D);
-                    c->n_launch[0]++; c->n_far[0]++;
+                    KLAUNCH(c, 1, lin_far_inside_mfma, dim3(last_block - D + 1, B.ns), dim3(256), st, B, D);
+                    (*nl)++; (*nf)++;
                 }
             }
         }
@@ -567,29 +582,36 @@ int launch_mc_vlin(rh_ctx* c, int pin, int phase)
     }
     if (BS > 0)
         for (int D = last_block; D >= 0 && (D + 1) * BS - 1 > B.nmax - 2; D--) {
-            KLAUNCH(c, 3, lin_far_outside_mfma, dim3(last_block - D + 1, B.ns, 2), dim3(256), c->s_mc, B, D);
-            c->n_launch[1]++; c->n_far[1]++;
+            KLAUNCH(c, 3, lin_far_outside_mfma, dim3(last_block - D + 1, B.ns, 2), dim3(256), st, B, D);
+            (*nl)++; (*nf)++;
         }
     for (int d = B.nmax - 2; d >= 0; d--) {
         if (BS > 0 && (d + 1) % BS == 0) {
             const int D = (d + 1) / BS - 1;
             if (D >= 0 && D <= last_block) {
-                KLAUNCH(c, 3, lin_far_outside_mfma, dim3(last_block - D + 1, B.ns, 2), dim3(256), c->s_mc, B, D);
-                c->n_launch[1]++; c->n_far[1]++;
+                KLAUNCH(c, 3, lin_far_outside_mfma, dim3(last_block - D + 1, B.ns, 2), dim3(256), st, B, D);
+                (*nl)++; (*nf)++;
             }
         }
-        const int groups = (B.nmax - 1 - d + 63) / 64 + 1;
-        KLAUNCH(c, 2, (vlin_outside_diag<W, BS>), pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(64 * W), c->s_mc, B, c->d_vlin, d, pin, bad);
-        c->n_launch[1]++;
+        const int groups = (B.nmax - 1 - d + 63) / 64 + extra;
+        if (co) KLAUNCH(c, 2, (vlin_outside_diag<W, BS, true>), pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(64 * W), st, B, c->d_vlin, d, pin, bad);
+        else KLAUNCH(c, 2, (vlin_outside_diag<W, BS, false>), pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(64 * W), st, B, c->d_vlin, d, pin, bad);
+        (*nl)++;
     }
-    hipLaunchKernelGGL(vlin_finish, dim3((B.ns + 63) / 64), dim3(64), 0, c->s_mc, B, c->d_vlin, (double*)c->d_mclogz, bad);
+    if (co) {
+        const DxBatch& D = c->dx;
+        hipLaunchKernelGGL(mcv_extract_hp, dim3((D.n1max * D.n2max + 255) / 256, B.ns), dim3(256), 0, st, B, D.hp, D.tab_stride, D.ldd, D.logz,
+                           c->h_vlin->s, bad);
+        return RH_OK;
+    }
+    hipLaunchKernelGGL(vlin_finish, dim3((B.ns + 63) / 64), dim3(64), 0, st, B, c->d_vlin, (double*)c->d_mclogz, bad);
     // accessibility P(i..i+w unpaired), w < max_w
     const int tiles = (B.ld + 31) / 32;
-    hipLaunchKernelGGL(vlin_acc_prep, dim3(tiles * tiles, B.ns), dim3(256), 0, c->s_mc, B, c->d_vlin, (const double*)c->d_hplen);
-    hipLaunchKernelGGL(mcv_acc_hscan, dim3((B.nmax + 1 + 255) / 256, B.ns), dim3(256), 0, c->s_mc, B, 10 /* VL_FM2F */);
-    hipLaunchKernelGGL(vlin_acc_hsum, dim3((B.nmax + 3) / 4, B.ns), dim3(256), 0, c->s_mc, B, c->max_w);
-    hipLaunchKernelGGL(vlin_acc_gaps, dim3((B.nmax + 255) / 256, B.ns, 60), dim3(256), 0, c->s_mc, B, c->d_vlin, (double*)c->d_gaps);
-    hipLaunchKernelGGL(vlin_acc_final, dim3((B.nmax + 255) / 256, B.ns, c->max_w), dim3(256), 0, c->s_mc, B, c->d_vlin, (const double*)c->d_gaps, c->max_w);
+    hipLaunchKernelGGL(vlin_acc_prep, dim3(tiles * tiles, B.ns), dim3(256), 0, st, B, c->d_vlin, (const double*)c->d_hplen);
+    hipLaunchKernelGGL(mcv_acc_hscan, dim3((B.nmax + 1 + 255) / 256, B.ns), dim3(256), 0, st, B, 10 /* VL_FM2F */);
+    hipLaunchKernelGGL(vlin_acc_hsum, dim3((B.nmax + 3) / 4, B.ns), dim3(256), 0, st, B, c->max_w);
+    hipLaunchKernelGGL(vlin_acc_gaps, dim3((B.nmax + 255) / 256, B.ns, 60), dim3(256), 0, st, B, c->d_vlin, (double*)c->d_gaps);
+    hipLaunchKernelGGL(vlin_acc_final, dim3((B.nmax + 255) / 256, B.ns, c->max_w), dim3(256), 0, st, B, c->d_vlin, (const double*)c->d_gaps, c->max_w);
     c->n_launch[1] += 5;
     return RH_OK;
 }
@@ -611,7 +633,8 @@ int launch_cofold(rh_ctx* c)
         KLAUNCH(c, 4, mcv_outside_diag, pin ? dim3(B.ns, (waves + 3) / 4) : dim3((waves + 3) / 4, B.ns), dim3(256), c->s_dx, B, c->d_vienna, d, pin);
         c->n_launch[2]++;
     }
-    hipLaunchKernelGGL(mcv_extract_hp, dim3((D.n1max * D.n2max + 255) / 256, B.ns), dim3(256), 0, c->s_dx, B, D.hp, D.tab_stride, D.ldd, D.logz);
+    hipLaunchKernelGGL(mcv_extract_hp, dim3((D.n1max * D.n2max + 255) / 256, B.ns), dim3(256), 0, c->s_dx, B, D.hp, D.tab_stride, D.ldd, D.logz,
+                       -1.0, (int*)nullptr);
     return RH_OK;
 }
 
@@ -776,7 +799,13 @@ size_t shape_key(const rh_ctx* c, int which)
 {
     auto mix = [](size_t h, size_t v) { return (h ^ v) * 0x100000001b3ull + 0x9e3779b97f4a7c15ull; };
     size_t h = 1469598103934665603ull + which;
-    if (which <= 1) {
+    if (which == 3) {
+        const McBatch& B = c->co;
+        for (size_t v : {(size_t)B.ns, (size_t)B.nmax, (size_t)B.ld, (size_t)B.lds, (size_t)B.tab, (size_t)B.seq, (size_t)B.n, (size_t)B.f5i,
+                         (size_t)B.bp, (size_t)c->d_cobad, (size_t)c->lin_bs, (size_t)B.tri_stride, (size_t)c->dx.hp, (size_t)c->dx.logz,
+                         (size_t)c->dx.ldd, (size_t)c->dx.tab_stride, (size_t)c->dx.n1max, (size_t)c->dx.n2max})
+            h = mix(h, v);
+    } else if (which <= 1) {
         const McBatch& B = c->mc;
         for (size_t v : {(size_t)B.ns, (size_t)B.nmax, (size_t)B.ld, (size_t)B.lds, (size_t)B.tab, (size_t)B.seq, (size_t)B.n,
                          (size_t)B.f5i, (size_t)B.bp, (size_t)B.up, (size_t)c->d_bad, (size_t)c->d_mclogz, (size_t)c->lin_w,
@@ -809,8 +838,27 @@ int compute(rh_ctx* c)
     bool dx_lin_launched = false;
     if (c->has_dx && !skip_dx && c->model == RH_MODEL_VIENNA_BL && c->hybrid == RH_HYBRID_COFOLD) {
         HIP_TRY(c, hipMemsetAsync(c->d_cobp, 0, sizeof(double) * c->co.tri_stride * c->co.ns, c->s_dx));
-        if ((rc = launch_cofold(c))) return rc;
-        c->last_dx_path = 2;
+        bool co_log = c->mode == RH_MODE_LOG;
+        if (!co_log) {   // scaled linear sweeps over s1+s2; out-of-range values send the batch to the log-space kernels
+            const int cpin = c->co.ns % 8 == 0 ? 1 : 0;
+            const bool far = c->lin_bs != 0;
+            if ((rc = run_graphed(c, c->g_dx, shape_key(c, 3), c->s_dx, &c->n_launch[2], &c->n_far[2], [&] {
+                    int r = far ? launch_mc_vlin<16>(c, cpin, 0, true) : launch_mc_vlin<0>(c, cpin, 0, true);
+                    return r ? r : (far ? launch_mc_vlin<16>(c, cpin, 1, true) : launch_mc_vlin<0>(c, cpin, 1, true));
+                }))) return rc;
+            c->last_dx_path = 1;
+            if (c->mode == RH_MODE_AUTO) {
+                std::vector<int> bad(c->co.ns);
+                HIP_TRY(c, hipMemcpyAsync(bad.data(), c->d_cobad, sizeof(int) * c->co.ns, hipMemcpyDeviceToHost, c->s_dx));
+                HIP_TRY(c, hipStreamSynchronize(c->s_dx));
+                for (int b : bad) co_log |= (b != 0);
+                if (co_log) { c->last_dx_path = 3; c->n_launch[2] = 0; c->n_far[2] = 0; HIP_TRY(c, hipEventRecord(c->ev[3], c->s_dx)); }
+            }
+        }
+        if (co_log) {
+            if ((rc = launch_cofold(c))) return rc;
+            if (c->last_dx_path != 3) c->last_dx_path = 2;
+        }
     } else if (c->has_dx && !skip_dx && c->model == RH_MODEL_VIENNA_BL) {
         const DxBatch& D = c->dx;
         const int steps = (D.n1max + D.n2max) / 2;
@@ -841,10 +889,10 @@ int compute(rh_ctx* c)
         if (!log_path) {   // scaled linear sweeps; a sequence that leaves the double range sends the batch to the log-space kernels
             const bool far = c->lin_bs != 0;
             if ((rc = run_graphed(c, c->g_in, shape_key(c, 0), c->s_mc, &c->n_launch[0], &c->n_far[0],
-                                  [&] { return far ? launch_mc_vlin<16>(c, pin, 0) : launch_mc_vlin<0>(c, pin, 0); }))) return rc;
+                                  [&] { return far ? launch_mc_vlin<16>(c, pin, 0, false) : launch_mc_vlin<0>(c, pin, 0, false); }))) return rc;
             HIP_TRY(c, hipEventRecord(c->ev[1], c->s_mc));
             if ((rc = run_graphed(c, c->g_out, shape_key(c, 1), c->s_mc, &c->n_launch[1], &c->n_far[1],
-                                  [&] { return far ? launch_mc_vlin<16>(c, pin, 1) : launch_mc_vlin<0>(c, pin, 1); }))) return rc;
+                                  [&] { return far ? launch_mc_vlin<16>(c, pin, 1, false) : launch_mc_vlin<0>(c, pin, 1, false); }))) return rc;
             c->last_path = 1;
             if (c->mode == RH_MODE_AUTO) {
                 std::vector<int> bad(c->mc.ns);
@@ -1030,7 +1078,7 @@ void rh_destroy(rh_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    void* bufs[] = {c->d_seq, c->d_n, c->d_mctab, c->d_f5, c->d_bp, c->d_up, c->d_dxtab, c->d_hp, c->d_logz, c->d_scal, c->d_mclogz, c->d_bad, c->d_cnt, c->d_cand, c->d_dxbad, c->d_zbar, c->d_gaps, c->d_coseq, c->d_con, c->d_cotab, c->d_cof5, c->d_cobp, c->d_vlin, c->d_hplen, c->d_model, c->d_lin, c->d_dxlin, c->d_vienna};
+    void* bufs[] = {c->d_seq, c->d_n, c->d_mctab, c->d_f5, c->d_bp, c->d_up, c->d_dxtab, c->d_hp, c->d_logz, c->d_scal, c->d_mclogz, c->d_bad, c->d_cnt, c->d_cand, c->d_dxbad, c->d_zbar, c->d_gaps, c->d_coseq, c->d_con, c->d_cotab, c->d_cof5, c->d_cobp, c->d_cobad, c->d_vlin, c->d_hplen, c->d_model, c->d_lin, c->d_dxlin, c->d_vienna};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (GraphSlot* g : {&c->g_in, &c->g_out, &c->g_dx}) if (g->exec) (void)hipGraphExecDestroy(g->exec);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -1278,6 +1326,7 @@ int rh_set_mode(rh_ctx* c, int mode)
 }
 
 int rh_last_path(const rh_ctx* c) { return c ? c->last_path : RH_ERR_ARG; }
+int rh_last_hybrid_path(const rh_ctx* c) { return c ? c->last_dx_path : RH_ERR_ARG; }
 
 int rh_batch_kernels(rh_ctx* c, const char* fine[3], const char* far[3], int n_far[3])
 {
@@ -1287,9 +1336,11 @@ int rh_batch_kernels(rh_ctx* c, const char* fine[3], const char* far[3], int n_f
     const std::string w = std::to_string(c->lin_w == 16 ? 16 : 8), bs = std::to_string(c->lin_bs == 0 || c->lin_bs == 32 ? c->lin_bs : 16);
     const bool vienna = c->model == RH_MODEL_VIENNA_BL, lin = c->last_path == 1;
     const std::string pre = vienna ? "vlin_" : "lin_";
-    names[0] = !c->has_mc ? "" : lin ? pre + "inside_diag<" + w + ", " + bs + ">" : vienna ? "mcv_inside_diag" : "mc_inside_diag";
-    names[1] = !c->has_mc ? "" : lin ? pre + "outside_diag<" + w + ", " + bs + ">" : vienna ? "mcv_outside_diag" : "mc_outside_diag";
-    names[2] = !c->has_dx ? "" : vienna ? (c->hybrid == RH_HYBRID_COFOLD ? "mcv_inside_diag / mcv_outside_diag (s1+s2)" : "dxv_sweep_diag") : c->last_dx_path == 1 ? "dxl_sweep<" + std::to_string(c->dx_w == 2 || c->dx_w == 8 ? c->dx_w : 4) + ">" : "dx_sweep_diag";
+    const std::string targs = vienna ? bs + ", false" : bs;
+    names[0] = !c->has_mc ? "" : lin ? pre + "inside_diag<" + w + ", " + targs + ">" : vienna ? "mcv_inside_diag" : "mc_inside_diag";
+    names[1] = !c->has_mc ? "" : lin ? pre + "outside_diag<" + w + ", " + targs + ">" : vienna ? "mcv_outside_diag" : "mc_outside_diag";
+    names[2] = !c->has_dx ? "" : vienna ? (c->hybrid == RH_HYBRID_COFOLD ? (c->last_dx_path == 1 ? "vlin_inside_diag<8, 16, true> + vlin_outside_diag<8, 16, true> (s1+s2)"
+                                                                                         : "mcv_inside_diag + mcv_outside_diag (s1+s2)") : "dxv_sweep_diag") : c->last_dx_path == 1 ? "dxl_sweep<" + std::to_string(c->dx_w == 2 || c->dx_w == 8 ? c->dx_w : 4) + ">" : "dx_sweep_diag";
     const bool mfma = c->far_mfma && c->lin_bs != 0 && c->lin_bs != 32;
     names[3] = (c->has_mc && lin && c->n_far[0]) ? (mfma ? "lin_far_inside_mfma" : "lin_far_inside<" + bs + ">") : "";
     names[4] = (c->has_mc && lin && c->n_far[1]) ? (mfma ? "lin_far_outside_mfma" : "lin_far_outside<" + bs + ">") : "";

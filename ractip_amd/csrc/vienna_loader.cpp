@@ -156,6 +156,7 @@ void build_vlin_model(const ViennaDx& V, double s, VLinModel* L)
             L->TXO[idx] = std::exp(V.mmI[ti * 25 + x1 * 5 + y]);
             L->TMC[idx] = std::exp(V.ml_close + V.d3x[rt * 5 + x1] + V.d5x[rt * 5 + y]);
             L->TMH[idx] = std::exp(V.mmH[ti * 25 + x1 * 5 + y]);
+            L->TNC[idx] = std::exp(V.d3x[rt * 5 + x1] + V.d5x[rt * 5 + y]);
         }
         const int to = V.ptype[y1 * 5 + x];          // seen from outside: letters (i, j+1) = (y1, x)
         if (to) {

@@ -64,6 +64,7 @@ struct VLinModel {
     double TMH[625];      // hairpin mismatchH[type][x1][y]
     double TXI[625];      // enclosed pair of a generic interior loop: mismatchI[rt][x1][y]
     double TSA[625];      // stem of a multi / exterior loop: dangle5[type][y] + dangle3[type][x1] (TerminalAU inside dangle3)
+    double TNC[625];      // pair closing the exterior-like loop around the gap between two molecules: dangle3[rt][x1] + dangle5[rt][y]
     double E_tau[8];      // TerminalAU by pair type (1 for CG/GC)
     double E_stack[64], E_bulge1[64];
     double E_int11[64 * 25], E_int21[64 * 125], E_int22[64 * 625];

@@ -18,7 +18,7 @@ EXPORTS = [
     "rh_create", "rh_destroy", "rh_last_error", "rh_set_mode", "rh_last_path", "rh_bpp", "rh_unpaired", "rh_fold", "rh_duplex",
     "rh_batch_upload", "rh_batch_compute", "rh_batch_results", "rh_batch_candidates",
     "rh_batch_timings", "rh_batch_device_views", "rh_batch_logz", "rh_batch_candidates_all", "rh_batch_layout",
-    "rh_batch_results_all", "rh_set_max_w", "rh_get_max_w", "rh_set_overlap", "rh_batch_kernels", "rh_set_hybrid",
+    "rh_batch_results_all", "rh_set_max_w", "rh_get_max_w", "rh_set_overlap", "rh_batch_kernels", "rh_set_hybrid", "rh_last_hybrid_path",
 ]
 
 
@@ -53,6 +53,8 @@ def load_library():
     L.rh_set_mode.restype = ci
     L.rh_last_path.argtypes = [vp]
     L.rh_set_overlap.argtypes = [vp, ci]
+    L.rh_last_hybrid_path.argtypes = [vp]
+    L.rh_last_hybrid_path.restype = ci
     L.rh_set_hybrid.argtypes = [vp, ci]
     L.rh_set_hybrid.restype = ci
     L.rh_batch_kernels.argtypes = [vp, vp, vp, vp]
@@ -129,6 +131,9 @@ class Context:
     def set_hybrid(self, cofold):
         """Vienna-BL model: hp from pf_duplex (False, default) or from the two-molecule ensemble of co_pf_fold (True)."""
         self._check(self.L.rh_set_hybrid(self.h, 1 if cofold else 0))
+
+    def last_hybrid_path(self):
+        return self.L.rh_last_hybrid_path(self.h)
 
     def set_max_w(self, max_w):
         self._check(self.L.rh_set_max_w(self.h, max_w))

@@ -399,6 +399,9 @@ def test_vienna_bl_cofold_hybridization(vctx, golden):
             o = vo.cofold(s1, s2)
             assert abs(z - o["logZ"]) < 1e-9 * max(1.0, abs(z)), (len(s1), len(s2))
             assert_prob_close(hp, o["hp"], rel=REL, what="cofold hp %d/%d" % (len(s1), len(s2)))
+            assert vctx.last_hybrid_path() in ((1, 3) if vctx.path_name == "auto" else (2,))
+        hp, z = vctx.duplex(*cases[-1])                   # random 90/75: stays inside the double range on the linear path
+        assert vctx.last_hybrid_path() == (1 if vctx.path_name == "auto" else 2)
         # batched: bp/up of the single molecules are untouched by the choice of hp source
         pairs = cases[:3] + [(rnd(rng, 70), rnd(rng, 52))]
         vctx.batch_upload(pairs)
