@@ -183,8 +183,9 @@ __global__ __launch_bounds__(64 * W) void lin_inside_diag(McBatch B, const LinMo
     // ---- FM2[i,d] = sum_{m=1}^{d-1} FM1[m][i] * FM[d-m][i+m]          (ipp:3384-3411)
     double acc2 = 0.0;
     {
-        const double* __restrict__ fm1 = tab + L_FM1 * ts + i;
-        const double* __restrict__ fm = tab + L_FM * ts + i;
+        const int ic = valid ? i : (ncell > 0 ? ncell : 1);   // invalid lanes read the last valid cell's operands
+        const double* __restrict__ fm1c = tab + L_FM1 * ts + ic;
+        const double* __restrict__ fmc = tab + L_FM * ts + ic;
         // near set of this cell in k = i+m: k < kA or k >= kB (everything when the tile has no far blocks)
         int kA = 1 << 30, kB = 0;
         if (BS > 0) {
@@ -200,16 +201,21 @@ __global__ __launch_bounds__(64 * W) void lin_inside_diag(McBatch B, const LinMo
         for (int part_i = 0; part_i < 2; part_i++) {
             const int lo = part_i ? lo1 : lo0, hi = part_i ? hi1 : hi0;
             for (int m = lo + w; m <= hi; m += UF * W) {
+                // branch-free: every load is issued (a lane or term that is out of range reads a clamped, valid address)
+                // so that all 2*UF loads are in flight together; the product is masked afterwards
                 double a[UF], b[UF];
+#pragma unroll
+                for (int u = 0; u < UF; u++) {
+                    const int mm = m + u * W, mc = mm <= hi ? mm : hi;
+                    a[u] = fm1c[mc * ld];
+                    b[u] = fmc[(d - mc) * ld + mc];
+                }
 #pragma unroll
                 for (int u = 0; u < UF; u++) {
                     const int mm = m + u * W, k = i + mm;
                     const bool ok = valid && mm <= hi && (k < kA || k >= kB);
-                    a[u] = ok ? fm1[mm * ld] : 0.0;
-                    b[u] = ok ? fm[(d - mm) * ld + mm] : 0.0;
+                    acc2 = fma(ok ? a[u] : 0.0, b[u], acc2);
                 }
-#pragma unroll
-                for (int u = 0; u < UF; u++) acc2 = fma(a[u], b[u], acc2);
             }
         }
         if (BS > 0 && valid && kB > 0) acc2 += (w == 0) ? tab[L_FM2F * ts + d * ld + i] : 0.0;
@@ -224,21 +230,28 @@ __global__ __launch_bounds__(64 * W) void lin_inside_diag(McBatch B, const LinMo
         const int tmax = d - 2 < kMaxSingle ? d - 2 : kMaxSingle;
         const int i0 = 1 + slot * 64;
         const double* __restrict__ fcx = tab + L_FCX * ts;
-        // pass 1: stage every segment this wavefront filters (all row loads in flight at once)
+        // pass 1: stage every segment this wavefront filters.  Straight-line code: all row loads are issued back to
+        // back (clamped addresses, no branches -- a branch per load makes the compiler wait for each load in turn), then
+        // written to LDS
         constexpr int NSEG = 2 * ((kMaxSingle / 2 + W) / W);     // <= 4 for W = 8
         int tseg[NSEG];
+        double r0[NSEG], r1[NSEG];
+        const int col0 = i0 + 1;                                  // lane k of a segment = column col0+k of row d-2-t
+        const int c0 = col0 + lane < ld ? col0 + lane : ld - 1, c1 = col0 + 64 + (lane & 31) < ld ? col0 + 64 + (lane & 31) : ld - 1;
 #pragma unroll
         for (int q = 0; q < NSEG; q++) {
             const int g = w + (q >> 1) * W;
             const int t = (q & 1) ? kMaxSingle - g : g;
             const bool on = g <= kMaxSingle / 2 && !((q & 1) && t == g) && t <= tmax;   // wave-uniform
             tseg[q] = on ? t : -1;
-            if (on) {
-                const int col0 = i0 + 1;                      // lane k of the segment = column col0+k of row d-2-t
-                const double* __restrict__ row = fcx + (d - 2 - t) * ld + col0;
-                gbuf[w][q][lane] = col0 + lane < ld ? row[lane] : 0.0;
-                if (lane < 32) gbuf[w][q][64 + lane] = col0 + 64 + lane < ld ? row[64 + lane] : 0.0;
-            }
+            const double* __restrict__ row = fcx + (on ? d - 2 - t : 0) * ld;
+            r0[q] = row[c0];
+            r1[q] = row[c1];
+        }
+#pragma unroll
+        for (int q = 0; q < NSEG; q++) {
+            gbuf[w][q][lane] = col0 + lane < ld ? r0[q] : 0.0;
+            if (lane < 32) gbuf[w][q][64 + lane] = col0 + 64 + lane < ld ? r1[q] : 0.0;
         }
         // pass 2: the filters
 #pragma unroll
@@ -484,7 +497,7 @@ __global__ void lin_finish(McBatch B, const LinModel* __restrict__ L, double* __
     template __global__ void lin_inside_diag<W, BS>(McBatch, const LinModel*, int, double, int);  \
     template __global__ void lin_outside_diag<W, BS>(McBatch, const LinModel*, int, int, int*);
 RH_INST(8, 0) RH_INST(16, 0)
-RH_INST(8, 16) RH_INST(16, 16)
+RH_INST(8, 16) RH_INST(16, 16) RH_INST(4, 16)
 RH_INST(8, 32) RH_INST(16, 32)
 #undef RH_INST
 

@@ -243,7 +243,8 @@ struct rh_ctx {
     bool use_graphs = true;        // RH_NO_GRAPH=1 launches every kernel from the host instead
     GraphSlot g_in, g_out, g_dx;
     int mode = RH_MODE_AUTO;       // which McCaskill path rh_batch_compute takes
-    int lin_w = 8;                 // wavefronts per 64-cell group of the linear kernels
+    int lin_w = 8;                 // wavefronts per 64-cell group of the linear outside kernel
+    int lin_w_in = 4;              // ... of the inside kernel (fewer, longer wavefronts: less per-wavefront scalar overhead)
     int lin_bs = 16;               // block size of the far/near split of the O(n^3) terms (0 = off)
     int last_path = 0;             // 1 = linear, 2 = log-space, 3 = linear then log-space fallback
     int max_w = 1;                 // accessibility widths 1..max_w (src/ractip.cpp:370-375); the CONTRAfold path has width 1 only
@@ -700,8 +701,9 @@ int launch_mc_lin(rh_ctx* c, int pin, int phase)
 template <int BS>
 int launch_mc_lin_w(rh_ctx* c, int pin, int phase)
 {
-    switch (c->lin_w) {
+    switch (phase == 0 ? c->lin_w_in : c->lin_w) {
         case 16: return launch_mc_lin<16, BS>(c, pin, phase);
+        case 4: if (BS == 16) return launch_mc_lin<4, 16>(c, pin, phase); else return launch_mc_lin<8, BS>(c, pin, phase);
         default: return launch_mc_lin<8, BS>(c, pin, phase);
     }
 }
@@ -808,7 +810,7 @@ size_t shape_key(const rh_ctx* c, int which)
     } else if (which <= 1) {
         const McBatch& B = c->mc;
         for (size_t v : {(size_t)B.ns, (size_t)B.nmax, (size_t)B.ld, (size_t)B.lds, (size_t)B.tab, (size_t)B.seq, (size_t)B.n,
-                         (size_t)B.f5i, (size_t)B.bp, (size_t)B.up, (size_t)c->d_bad, (size_t)c->d_mclogz, (size_t)c->lin_w,
+                         (size_t)B.f5i, (size_t)B.bp, (size_t)B.up, (size_t)c->d_bad, (size_t)c->d_mclogz, (size_t)c->lin_w, (size_t)c->lin_w_in,
                          (size_t)c->lin_bs, (size_t)B.tri_stride, (size_t)c->far_mfma, (size_t)c->max_w, (size_t)c->d_gaps,
                          (size_t)c->d_hplen})
             h = mix(h, v);
@@ -1041,7 +1043,8 @@ rh_ctx* rh_create(int device, int model, const char* param_file)
     build_lin_model(host_model, 0.12, &c->h_lin);
     // duplex: log Z per unit of (i + L2+1-j) is 0.62..0.82 on the bundled pairs, 0.645 for random sequences
     build_dx_lin_model(host_model, 0.65, &c->h_dxlin);
-    if (const char* e = std::getenv("RH_LIN_W")) c->lin_w = std::atoi(e);
+    if (const char* e = std::getenv("RH_LIN_W")) c->lin_w = c->lin_w_in = std::atoi(e);
+    if (const char* e = std::getenv("RH_LIN_W_IN")) c->lin_w_in = std::atoi(e);
     if (const char* e = std::getenv("RH_LIN_BS")) c->lin_bs = std::atoi(e);
     if (const char* e = std::getenv("RH_NO_GRAPH")) c->use_graphs = std::atoi(e) == 0;
     if (const char* e = std::getenv("RH_FAR_MFMA")) c->far_mfma = std::atoi(e) != 0;
@@ -1333,11 +1336,11 @@ int rh_batch_kernels(rh_ctx* c, const char* fine[3], const char* far[3], int n_f
     if (!c) return RH_ERR_ARG;
     if (!c->computed) return fail(c, RH_ERR_ARG, "no computed batch");
     static thread_local std::string names[6];
-    const std::string w = std::to_string(c->lin_w == 16 ? 16 : 8), bs = std::to_string(c->lin_bs == 0 || c->lin_bs == 32 ? c->lin_bs : 16);
+    const std::string w = std::to_string(c->lin_w == 16 ? 16 : 8), w_in = std::to_string(c->lin_w_in == 16 ? 16 : (c->lin_w_in == 4 && c->lin_bs != 0 && c->lin_bs != 32 ? 4 : 8)), bs = std::to_string(c->lin_bs == 0 || c->lin_bs == 32 ? c->lin_bs : 16);
     const bool vienna = c->model == RH_MODEL_VIENNA_BL, lin = c->last_path == 1;
     const std::string pre = vienna ? "vlin_" : "lin_";
     const std::string targs = vienna ? bs + ", false" : bs;
-    names[0] = !c->has_mc ? "" : lin ? pre + "inside_diag<" + w + ", " + targs + ">" : vienna ? "mcv_inside_diag" : "mc_inside_diag";
+    names[0] = !c->has_mc ? "" : lin ? pre + "inside_diag<" + (vienna ? w : w_in) + ", " + targs + ">" : vienna ? "mcv_inside_diag" : "mc_inside_diag";
     names[1] = !c->has_mc ? "" : lin ? pre + "outside_diag<" + w + ", " + targs + ">" : vienna ? "mcv_outside_diag" : "mc_outside_diag";
     names[2] = !c->has_dx ? "" : vienna ? (c->hybrid == RH_HYBRID_COFOLD ? (c->last_dx_path == 1 ? "vlin_inside_diag<8, 16, true> + vlin_outside_diag<8, 16, true> (s1+s2)"
                                                                                          : "mcv_inside_diag + mcv_outside_diag (s1+s2)") : "dxv_sweep_diag") : c->last_dx_path == 1 ? "dxl_sweep<" + std::to_string(c->dx_w == 2 || c->dx_w == 8 ? c->dx_w : 4) + ">" : "dx_sweep_diag";
