@@ -61,6 +61,29 @@ def test_structures_from_reference_matrices_are_well_formed(golden):
         assert r1.count("[") == r2.count("]")
 
 
+def test_rip_tables_round_trip_and_give_the_same_structure(golden, tmp_path):
+    """RIP text tables (src/ractip.cpp:461-514): write -> read (float, sequence 2 reversed in the file) -> same matrices,
+    hence the same programme and structure a stock `ractip --rip FILE --min-w 0` would build from them."""
+    from ractip_amd import rip
+    a, b = "CopA", "CopT"
+    s1, s2 = str(golden["mc/%s/seq" % a]), str(golden["mc/%s/seq" % b])
+    bp1, bp2 = golden["mc/%s/post" % a], golden["mc/%s/post" % b]
+    hp = golden["dx/%s+%s/post" % (a, b)].reshape(len(s1) + 1, len(s2) + 1)
+    path = str(tmp_path / "pair.rip")
+    rip.write_rip(path, s1, s2, bp1, bp2, hp)
+    r1, r2, r3 = rip.read_rip(path, s1, s2)
+    assert np.array_equal(r1, bp1.astype(np.float32)) and np.array_equal(r2, bp2.astype(np.float32))
+    assert np.array_equal(r3, hp.astype(np.float32))
+    opt = ilp.Options(min_w=0)
+    assert ilp.solve(s1, s2, r1, r2, r3, None, None, opt)[:2] == ilp.solve(s1, s2, bp1, bp2, hp, None, None, opt)[:2]
+    # the reversal convention of table S: the file's (i, j) is s2's pair (L2-j+1, L2-i+1)
+    lines = open(path).read().split("Table S:")[1].split("Table I:")[0].split()
+    i, j, p = int(lines[0]), int(lines[1]), float(lines[2])
+    n2 = len(s2)
+    x, y = n2 - j + 1, n2 - i + 1
+    assert x < y and abs(bp2[x * (2 * (n2 + 1) - x - 1) // 2 + y] - p) < 1e-15
+
+
 @pytest.mark.gpu
 def test_identical_joint_structures_on_all_bundled_pairs(hotlib, golden):
     import ractip_amd
