@@ -837,7 +837,7 @@ int compute(rh_ctx* c)
     const char* skip = std::getenv("RH_EXP_SKIP");
     const bool skip_dx = skip && !std::strcmp(skip, "dx"), skip_mc = skip && !std::strcmp(skip, "mc");
     HIP_TRY(c, hipEventRecord(c->ev[3], c->s_dx));
-    bool dx_lin_launched = false;
+    bool dx_lin_launched = false, co_lin_launched = false;
     if (c->has_dx && !skip_dx && c->model == RH_MODEL_VIENNA_BL && c->hybrid == RH_HYBRID_COFOLD) {
         HIP_TRY(c, hipMemsetAsync(c->d_cobp, 0, sizeof(double) * c->co.tri_stride * c->co.ns, c->s_dx));
         bool co_log = c->mode == RH_MODE_LOG;
@@ -849,13 +849,7 @@ int compute(rh_ctx* c)
                     return r ? r : (far ? launch_mc_vlin<16>(c, cpin, 1, true) : launch_mc_vlin<0>(c, cpin, 1, true));
                 }))) return rc;
             c->last_dx_path = 1;
-            if (c->mode == RH_MODE_AUTO) {
-                std::vector<int> bad(c->co.ns);
-                HIP_TRY(c, hipMemcpyAsync(bad.data(), c->d_cobad, sizeof(int) * c->co.ns, hipMemcpyDeviceToHost, c->s_dx));
-                HIP_TRY(c, hipStreamSynchronize(c->s_dx));
-                for (int b : bad) co_log |= (b != 0);
-                if (co_log) { c->last_dx_path = 3; c->n_launch[2] = 0; c->n_far[2] = 0; HIP_TRY(c, hipEventRecord(c->ev[3], c->s_dx)); }
-            }
+            co_lin_launched = true;   // its overflow flags are read after the McCaskill stream has been fed (the two overlap)
         }
         if (co_log) {
             if ((rc = launch_cofold(c))) return rc;
@@ -936,6 +930,21 @@ int compute(rh_ctx* c)
         if (c->last_path == 0) c->last_path = 2;
     }
     HIP_TRY(c, hipEventRecord(c->ev[2], c->s_mc));
+    if (co_lin_launched && c->mode == RH_MODE_AUTO) {
+        std::vector<int> bad(c->co.ns);
+        HIP_TRY(c, hipMemcpyAsync(bad.data(), c->d_cobad, sizeof(int) * c->co.ns, hipMemcpyDeviceToHost, c->s_dx));
+        HIP_TRY(c, hipStreamSynchronize(c->s_dx));
+        bool redo = false;
+        for (int b : bad) redo |= (b != 0);
+        if (redo) {   // some pair left the double range: recompute the two-molecule sweeps in log space
+            c->n_launch[2] = 0; c->n_far[2] = 0;
+            HIP_TRY(c, hipEventRecord(c->ev[3], c->s_dx));
+            HIP_TRY(c, hipMemsetAsync(c->d_cobp, 0, sizeof(double) * c->co.tri_stride * c->co.ns, c->s_dx));
+            if ((rc = launch_cofold(c))) return rc;
+            HIP_TRY(c, hipEventRecord(c->ev[4], c->s_dx));
+            c->last_dx_path = 3;
+        }
+    }
     if (dx_lin_launched) {
         c->last_dx_path = 1;
         if (c->mode == RH_MODE_AUTO) {
