@@ -329,6 +329,36 @@ def test_vienna_bl_mccaskill_and_accessibility_vs_cpu_restatement(vctx, golden):
     vctx.set_max_w(15)
 
 
+def test_vienna_bl_full_size_pair(vctx):
+    """BASELINE config 3 under the default-CLI model: one n=500/500 pair (mt19937(12345) stream), rnafold x2 with
+    accessibility at width 15 + the two-molecule ensemble over N=1000 (several block-product tiles, the cut in the middle of
+    a 64-cell group), against the CPU restatement; plus size-independent properties."""
+    from _oracle import ViennaOracle
+    vo = ViennaOracle()
+    s1, s2 = random_pair(500)
+    vctx.set_hybrid(True)
+    try:
+        vctx.batch_upload([(s1, s2)])
+        vctx.batch_compute()
+        r = vctx.batch_results(0)
+    finally:
+        vctx.set_hybrid(False)
+    o1, oc = vo.mccaskill(s1, max_w=15), vo.cofold(s1, s2)
+    assert abs(r["logZ"][0] - o1["logZ"]) < 1e-9 * abs(o1["logZ"]) and abs(r["logZ"][2] - oc["logZ"]) < 1e-9 * abs(oc["logZ"])
+    assert_prob_close(r["bp1"], o1["post"], rel=REL, what="bp1 n=500")
+    assert_prob_close(r["up1"], o1["up"], rel=REL, abs_floor=1e-11, what="up1 n=500")
+    assert_prob_close(r["hp"], oc["hp"], rel=REL, what="hp n=500/500")
+    # every letter of s2 is unpaired or paired exactly once (width-1 accessibility + pair probabilities)
+    n = len(s2)
+    paired = np.zeros(n + 1)
+    for i in range(1, n + 1):
+        row = r["bp2"][tri_offset(n, i):tri_offset(n, i) + n + 1]
+        paired[i] += row[i + 1:].sum()
+        paired[i + 1:] += row[i + 1:]
+    assert np.abs(paired[1:] + r["up2"][:, 0] - 1).max() < 1e-9
+    assert (np.diff(r["up2"], axis=1) <= 1e-12).all()
+
+
 def test_vienna_bl_linear_path_falls_back_on_overflow(vctx):
     """A 1200-nt perfect GC helix has log Z ~ 2.5 per nucleotide: the scaled linear values leave the double range, the
     device flags it and the batch is recomputed in log space; results equal the log-space context's."""
