@@ -69,7 +69,11 @@ int rh_last_hybrid_path(const rh_ctx* ctx);
  * RactIP::contrafold up to GetPosterior (src/ractip.cpp:199-211:
  * ComputeInside/ComputeOutside/ComputePosterior/GetPosterior(0,...)) and, for
  * RH_MODEL_VIENNA_BL, pf_fold + export_bppm of RactIP::rnafold
- * (src/ractip.cpp:288-304, 351-367).  `constraint` must be NULL for now. */
+ * (src/ractip.cpp:288-304, 351-367).  `constraint` (RH_MODEL_VIENNA_BL only, or NULL): the string RactIP hands to
+ * pf_fold when use_constraint_ is set (src/ractip.cpp:271-291), in ViennaRNA's fold_constrained alphabet:
+ * 'x' never pairs, '<' / '>' pairs only with a later / earlier letter, matched '(' ')' keeps that pair and removes every
+ * pair inconsistent with it, '|' and '.' do not restrict the partition function; shorter strings are padded with '.'.
+ * A forced pair of non-complementary letters is rejected (RH_ERR_ARG). */
 int rh_bpp(rh_ctx* ctx, const char* seq, int n, const char* constraint,
            double* bp_tri, double* logZ);
 
@@ -98,6 +102,9 @@ int rh_set_hybrid(rh_ctx* ctx, int hybrid);
  * the accessibility overload of RactIP::rnafold (src/ractip.cpp:308-382).  bp_tri, up (n*max_w doubles, max_w as set
  * by rh_set_max_w) or logZ may be NULL. */
 int rh_fold(rh_ctx* ctx, const char* seq, int n, double* bp_tri, double* up, double* logZ);
+/* rh_fold under a structure constraint (see rh_bpp): the whole accessibility overload of RactIP::rnafold with
+ * use_constraint_ (src/ractip.cpp:308-382). */
+int rh_fold_constrained(rh_ctx* ctx, const char* seq, int n, const char* constraint, double* bp_tri, double* up, double* logZ);
 
 /* Hybridization probabilities of a pair.  Replaces RactIP::contraduplex
  * (src/ractip.cpp:225-245: DuplexEngine ComputeInside/Outside/Posterior) and, for

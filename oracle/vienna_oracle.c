@@ -338,7 +338,8 @@ double vo_bruteforce(const vo_model* P, const char* s1, int n1, const char* s2, 
 /* cut = 0: one molecule.  cut = n1 > 0: two molecules s1+s2 concatenated (co_pf_fold, src/ractip.cpp:400-458): the
  * backbone gap between letters cut and cut+1 does not exist.  A loop whose backbone holds that gap is an exterior-like
  * loop (only the stems' own dangle/TerminalAU terms count), dangles are never taken across it. */
-typedef struct { const vo_model* P; const int* S; int n; double sc; int cut; } mc_t;
+typedef struct { const vo_model* P; const int* S; int n; double sc; int cut; const unsigned char* allow; } mc_t;
+/* allow: (n+1)x(n+1) bytes, allow[a*(n+1)+b] != 0 iff letters a < b may pair (structure constraints of pf_fold); NULL = no constraint */
 #define GAP_OK(c, g) ((c)->cut == 0 || (g) != (c)->cut)   /* letters g and g+1 are neighbours on one strand */
 
 static int tetra_bonus(const vo_model* P, const int* S, int a)
@@ -389,6 +390,10 @@ static double e_nickclose(const mc_t* c, int a, int b)
 /* post: T(n) triangular (reference layout) or NULL; up: n*max_w row-major, up[i*max_w+w] = P(letters i+1..i+1+w
  * unpaired) (0 where the region runs off the end) or NULL; tabs: 8*T log-space tables FCi,FMi,FM1i,FCo,FMo,FM1o,
  * FMSi,FMSo + f5: 2*(n+1) (F5i, F5o) or NULL.  Returns log Z (inside); *logz_out = outside log Z. */
+/* structure constraints (fold_constrained): the next DP / enumeration call honours this mask (see mc_t::allow); set NULL to clear */
+static const unsigned char* vo_allow_mask = NULL;
+void vo_set_allow_mask(const unsigned char* m) { vo_allow_mask = m; }
+
 double vo_mccaskill_cut(const vo_model* P, const char* seq, int n, int cut, double* post, double* logz_out,
                         double* up, int max_w, double* tabs, double* f5);
 double vo_mccaskill(const vo_model* P, const char* seq, int n, double* post, double* logz_out,
@@ -411,11 +416,11 @@ double vo_mccaskill_cut(const vo_model* P, const char* seq, int n, int cut, doub
            *FMSi = buf + 6 * T, *FMSo = buf + 7 * T, *F5i = buf + 8 * T, *F5o = buf + 8 * T + (L + 1),
            *XP = buf + 8 * T + 2 * (L + 2), *XS = XP + (L + 2), *XPo = XS + (L + 2), *XSo = XPo + (L + 2);
     for (long k = 0; k < 8 * T + 6 * (L + 2); k++) buf[k] = -INFINITY;
-    mc_t c = {P, S, L, 10.0 / P->kT, cut};
+    mc_t c = {P, S, L, 10.0 / P->kT, cut, vo_allow_mask};
     if (cut > 0 && up) { free(buf); free(off); free(S); return NAN; }
 #define NICKED(i, j) (cut > 0 && (i) <= cut && cut <= (j))   /* the gap lies inside the pair (i, j+1) */
     const double sc = c.sc, mlb = -P->ML_base * sc, mli = -P->ML_intern * sc;
-#define PAIR(a, b) ((a) >= 1 && (b) <= L && ptype(S[a], S[b]))
+#define PAIR(a, b) ((a) >= 1 && (b) <= L && ptype(S[a], S[b]) && (!c.allow || c.allow[(size_t)(a) * (L + 1) + (b)]))
     /* inside */
     for (int i = L; i >= 0; i--) {
         if (cut > 0 && i == cut) {   /* rows > cut are final: exterior partition function of s2's prefixes cut+1..b */
@@ -675,6 +680,7 @@ static void sbf_rec(sbf_t* b, int pos)
     sbf_rec(b, pos + 1);
     for (int q = pos + 4; q <= n; q++) {
         if (b->pt[q] != 0 || !ptype(b->c.S[pos], b->c.S[q])) continue;
+        if (b->c.allow && !b->c.allow[(size_t)pos * (n + 1) + q]) continue;
         int ok = 1;
         for (int x = pos + 1; x < q && ok; x++) if (b->pt[x] > 0) ok = 0;
         if (!ok) continue;
@@ -694,7 +700,7 @@ double vo_fold_bruteforce_cut(const vo_model* P, const char* seq, int n, int cut
     int* S = (int*)calloc(n + 3, sizeof(int));
     for (int i = 1; i <= n; i++) S[i] = vcode(seq[i - 1]);
     sbf_t b;
-    b.c.P = P; b.c.S = S; b.c.n = n; b.c.sc = 10.0 / P->kT; b.c.cut = cut;
+    b.c.P = P; b.c.S = S; b.c.n = n; b.c.sc = 10.0 / P->kT; b.c.cut = cut; b.c.allow = vo_allow_mask;
     b.pt = (int*)calloc(n + 2, sizeof(int));
     b.Z = 0.0;
     const long T = (long)(n + 1) * (n + 2) / 2;

@@ -48,6 +48,9 @@ struct McBatch {
     // two-molecule form (co_pf_fold semantics, mccaskill_vienna.hip only): cut[sq] = n1 > 0 means the sequence is s1+s2
     // and the backbone gap after letter n1 does not exist; xp/xs = exterior partition functions of s2's prefixes
     // cut+1..b and s1's suffixes a..cut, xpo/xso their outside counterparts.  cut == nullptr: one molecule each.
+    // structure constraints (fold_constrained, Vienna-BL kernels only): allow[sq*ld*ld + a*ld + b] != 0 iff letters a < b may
+    // pair; nullptr = unconstrained
+    const uint8_t* allow;
     const int* cut;      // [NS] or nullptr
     double* xp;          // [NS][ld]
     double* xs;

@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void mcv_inside_diag(McBatch B, const ViennaDx
 
     const int i = wave + 1, j = i + d;
     const int s_im1 = s[i - 1], s_i = s[i], s_ip1 = s[i + 1], s_j = s[j], s_jp1 = s[j + 1], s_jp2 = s[j + 2];
-    const int type = V->ptype[s_i * 5 + s_jp1];
+    const int type = (B.allow && !B.allow[((size_t)sq * ld + i) * ld + (j + 1)]) ? 0 : V->ptype[s_i * 5 + s_jp1];   // 0: the pair is excluded by a structure constraint
     const bool pairable = type != 0;
     const int rt = V->rtype[type];
     const bool inner = d >= 2;
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void mcv_outside_diag(McBatch B, const ViennaD
     const int i = wave + 1, j = i + d;
     const int s_im1 = s[i - 1], s_i = s[i], s_ip1 = s[i + 1], s_j = s[j], s_jp1 = s[j + 1], s_jp2 = s[j + 2];
     const bool guard_m = d >= 2;
-    const int type = V->ptype[s_i * 5 + s_jp1];
+    const int type = (B.allow && !B.allow[((size_t)sq * ld + i) * ld + (j + 1)]) ? 0 : V->ptype[s_i * 5 + s_jp1];   // 0: the pair is excluded by a structure constraint
     const bool pairable = type != 0;
     const int rt = V->rtype[type];
     const double tau_here = type > 2 ? V->tau : 0.0;

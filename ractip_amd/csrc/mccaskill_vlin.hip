@@ -206,7 +206,7 @@ __global__ __launch_bounds__(64 * W) void vlin_inside_diag(McBatch B, const VLin
     const bool valid = i <= ncell;
     int s_im1 = 0, s_i = 0, s_ip1 = 0, s_j = 0, s_jp1 = 0, s_jp2 = 0;
     if (valid) { s_im1 = s[i - 1]; s_i = s[i]; s_ip1 = s[i + 1]; s_j = s[j]; s_jp1 = s[j + 1]; s_jp2 = s[j + 2]; }
-    const int type = L->ptype[s_i * 5 + s_jp1];
+    const int type = (B.allow && valid && !B.allow[((size_t)sq * ld + i) * ld + (j + 1)]) ? 0 : L->ptype[s_i * 5 + s_jp1];   // 0: excluded by a structure constraint
     const bool pairable = valid && type != 0;
     // two-molecule form: the missing gap inside the pair limits both sides of an enclosed loop to their own strand
     const bool nick_in = CUT && valid && i <= cut && cut <= j;
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(64 * W) void vlin_outside_diag(McBatch B, const VLi
     const bool valid = i <= ncell;
     int s_im1 = 0, s_i = 0, s_ip1 = 0, s_j = 0, s_jp1 = 0, s_jp2 = 0;
     if (valid) { s_im1 = s[i - 1]; s_i = s[i]; s_ip1 = s[i + 1]; s_j = s[j]; s_jp1 = s[j + 1]; s_jp2 = s[j + 2]; }
-    const int type = L->ptype[s_i * 5 + s_jp1];
+    const int type = (B.allow && valid && !B.allow[((size_t)sq * ld + i) * ld + (j + 1)]) ? 0 : L->ptype[s_i * 5 + s_jp1];   // 0: excluded by a structure constraint
     const bool pairable = valid && type != 0;
     const bool guard_m = d >= 2;
     // two-molecule form: the sides of an ENCLOSING loop (letters io..i and j+1..jo+1) may not cross the missing gap

@@ -273,6 +273,7 @@ struct rh_ctx {
     void* d_zbar = nullptr;  size_t cap_zbar = 0;
     void* d_cand = nullptr;  size_t cap_cand = 0;
     void* d_gaps = nullptr;  size_t cap_gaps = 0;
+    void* d_allow = nullptr; size_t cap_allow = 0;   // structure-constraint masks [ns][ld*ld] bytes (Vienna-BL, optional)
     void* d_hplen = nullptr; size_t cap_hplen = 0;   // lam^d x hairpin length weight, d = 0..nmax (linear Vienna path)
     std::vector<double> h_hplen;
     // two-molecule (co_pf_fold) form of the hybridization matrix: one concatenated sequence s1+s2 per pair
@@ -365,8 +366,46 @@ std::string default_param_path()
 inline size_t tri_size(int n) { return (size_t)(n + 1) * (n + 2) / 2; }
 inline size_t tri_offset(int n, int i) { return (size_t)i * (size_t)(2 * (n + 1) - i - 1) / 2; }
 
-// Stage `ns` sequences; pairs are (2p, 2p+1) when with_dx.  Allocates what is needed.
-int stage(rh_ctx* c, int ns, const char* const* seqs, const int* lens, bool with_mc, bool with_dx)
+// Allowed-pair mask of pf_fold under fold_constrained (ViennaRNA 1.8 make_ptypes), M[a*ld + b], 1 <= a < b <= n:
+//   'x' the letter never pairs; '<' it pairs only with a later letter, '>' only with an earlier one; a matched '(' ')'
+//   is kept and every pair inconsistent with it (crossing it, or sharing a letter) is removed; '|' and '.' do not
+//   restrict the partition function.  Returns false for unbalanced brackets or a forced pair of non-complementary letters.
+bool build_allow_mask(const char* seq, int n, const char* cons, int ld, uint8_t* M, std::string* why)
+{
+    for (int a = 0; a < ld; a++)
+        for (int b = 0; b < ld; b++) M[(size_t)a * ld + b] = (a >= 1 && a < b && b <= n) ? 1 : 0;
+    const size_t clen = std::strlen(cons);
+    std::vector<int> stack;
+    for (int j = 1; j <= n; j++) {
+        const char ch = (size_t)(j - 1) < clen ? cons[j - 1] : '.';
+        if (ch == 'x') {
+            for (int l = 1; l <= n; l++) { M[(size_t)l * ld + j] = 0; M[(size_t)j * ld + l] = 0; }
+        } else if (ch == '(' || ch == '<') {
+            if (ch == '(') stack.push_back(j);
+            for (int l = 1; l < j; l++) M[(size_t)l * ld + j] = 0;
+        } else if (ch == ')' || ch == '>') {
+            if (ch == ')') {
+                if (stack.empty()) { *why = "unbalanced ')' in the structure constraint"; return false; }
+                const int i = stack.back();
+                stack.pop_back();
+                const uint8_t keep = M[(size_t)i * ld + j];
+                for (int k = i; k <= j; k++) for (int l = j; l <= n; l++) M[(size_t)k * ld + l] = 0;
+                for (int k = 1; k <= i; k++) for (int l = i; l <= j; l++) M[(size_t)k * ld + l] = 0;
+                M[(size_t)i * ld + j] = keep;
+                const uint8_t x = vienna_code(seq[i - 1]), y = vienna_code(seq[j - 1]);
+                static const int T[5][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 5}, {0, 0, 0, 1, 0}, {0, 0, 2, 0, 3}, {0, 6, 0, 4, 0}};
+                if (keep && !T[x][y]) { *why = "a forced pair of non-complementary letters (pair type 7) is not supported"; return false; }
+            }
+            for (int l = j + 1; l <= n; l++) M[(size_t)j * ld + l] = 0;
+        }
+    }
+    if (!stack.empty()) { *why = "unbalanced '(' in the structure constraint"; return false; }
+    return true;
+}
+
+// Stage `ns` sequences; pairs are (2p, 2p+1) when with_dx.  Allocates what is needed.  cons: per-sequence structure
+// constraints (Vienna-BL, single-molecule batch only) or nullptr.
+int stage(rh_ctx* c, int ns, const char* const* seqs, const int* lens, bool with_mc, bool with_dx, const char* const* cons = nullptr)
 {
     HIP_TRY(c, hipSetDevice(c->device));
     if (ns <= 0) return fail(c, RH_ERR_ARG, "empty batch");
@@ -420,6 +459,17 @@ int stage(rh_ctx* c, int ns, const char* const* seqs, const int* lens, bool with
         const size_t bp_bytes = sizeof(double) * B.tri_stride * ns;
         if ((rc = ensure(c, &c->d_bp, &c->cap_bp, bp_bytes, false))) return rc;
         HIP_TRY(c, hipMemsetAsync(c->d_bp, 0, bp_bytes, c->s_mc));
+        B.allow = nullptr;
+        if (cons) {
+            std::vector<uint8_t> M((size_t)ns * B.ld * B.ld);
+            std::string why;
+            for (int k = 0; k < ns; k++)
+                if (!build_allow_mask(seqs[k], lens[k], cons[k] ? cons[k] : "", B.ld, M.data() + (size_t)k * B.ld * B.ld, &why))
+                    return fail(c, RH_ERR_ARG, "sequence %d: %s", k, why.c_str());
+            if ((rc = ensure(c, &c->d_allow, &c->cap_allow, M.size(), false))) return rc;
+            HIP_TRY(c, hipMemcpy(c->d_allow, M.data(), M.size(), hipMemcpyHostToDevice));
+            B.allow = (const uint8_t*)c->d_allow;
+        }
         B.seq = (const uint8_t*)c->d_seq; B.n = (const int*)c->d_n;
         B.tab = (double*)c->d_mctab;
         B.f5i = (double*)c->d_f5; B.f5o = (double*)c->d_f5 + (size_t)B.ld * ns;
@@ -812,7 +862,7 @@ size_t shape_key(const rh_ctx* c, int which)
         for (size_t v : {(size_t)B.ns, (size_t)B.nmax, (size_t)B.ld, (size_t)B.lds, (size_t)B.tab, (size_t)B.seq, (size_t)B.n,
                          (size_t)B.f5i, (size_t)B.bp, (size_t)B.up, (size_t)c->d_bad, (size_t)c->d_mclogz, (size_t)c->lin_w, (size_t)c->lin_w_in,
                          (size_t)c->lin_bs, (size_t)B.tri_stride, (size_t)c->far_mfma, (size_t)c->max_w, (size_t)c->d_gaps,
-                         (size_t)c->d_hplen})
+                         (size_t)c->d_hplen, (size_t)B.allow})
             h = mix(h, v);
     } else {
         const DxLinBatch& X = c->dxl;
@@ -1090,7 +1140,7 @@ void rh_destroy(rh_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    void* bufs[] = {c->d_seq, c->d_n, c->d_mctab, c->d_f5, c->d_bp, c->d_up, c->d_dxtab, c->d_hp, c->d_logz, c->d_scal, c->d_mclogz, c->d_bad, c->d_cnt, c->d_cand, c->d_dxbad, c->d_zbar, c->d_gaps, c->d_coseq, c->d_con, c->d_cotab, c->d_cof5, c->d_cobp, c->d_cobad, c->d_vlin, c->d_hplen, c->d_model, c->d_lin, c->d_dxlin, c->d_vienna};
+    void* bufs[] = {c->d_seq, c->d_n, c->d_mctab, c->d_f5, c->d_bp, c->d_up, c->d_dxtab, c->d_hp, c->d_logz, c->d_scal, c->d_mclogz, c->d_bad, c->d_cnt, c->d_cand, c->d_dxbad, c->d_zbar, c->d_gaps, c->d_coseq, c->d_con, c->d_cotab, c->d_cof5, c->d_cobp, c->d_cobad, c->d_allow, c->d_vlin, c->d_hplen, c->d_model, c->d_lin, c->d_dxlin, c->d_vienna};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (GraphSlot* g : {&c->g_in, &c->g_out, &c->g_dx}) if (g->exec) (void)hipGraphExecDestroy(g->exec);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -1105,11 +1155,12 @@ const char* rh_last_error(const rh_ctx* c) { return c ? c->err.c_str() : g_creat
 int rh_bpp(rh_ctx* c, const char* seq, int n, const char* constraint, double* bp_tri, double* logZ)
 {
     if (!c) return RH_ERR_ARG;
-    if (constraint) return fail(c, RH_ERR_UNSUPPORTED, "structure constraints are not supported yet");
+    if (constraint && c->model != RH_MODEL_VIENNA_BL)
+        return fail(c, RH_ERR_UNSUPPORTED, "structure constraints apply to the Vienna-BL model only (RactIP::contrafold takes none)");
     if (!seq || n < 0) return fail(c, RH_ERR_ARG, "bad sequence");
     if (n == 0) { if (bp_tri) bp_tri[0] = 0.0; if (logZ) *logZ = 0.0; return RH_OK; }
     int rc;
-    if ((rc = stage(c, 1, &seq, &n, true, false))) return rc;
+    if ((rc = stage(c, 1, &seq, &n, true, false, constraint ? &constraint : nullptr))) return rc;
     if ((rc = compute(c))) return rc;
     if (bp_tri && (rc = fetch_bp(c, 0, bp_tri))) return rc;
     if (logZ && (rc = fetch_logz(c, 0, logZ))) return rc;
@@ -1135,6 +1186,22 @@ int rh_fold(rh_ctx* c, const char* seq, int n, double* bp_tri, double* up, doubl
     if (n == 0) { if (bp_tri) bp_tri[0] = 0.0; if (logZ) *logZ = 0.0; return RH_OK; }
     int rc;
     if ((rc = stage(c, 1, &seq, &n, true, false))) return rc;
+    if ((rc = compute(c))) return rc;
+    if (bp_tri && (rc = fetch_bp(c, 0, bp_tri))) return rc;
+    if (up && (rc = fetch_up(c, 0, up))) return rc;
+    if (logZ && (rc = fetch_logz(c, 0, logZ))) return rc;
+    return RH_OK;
+}
+
+int rh_fold_constrained(rh_ctx* c, const char* seq, int n, const char* constraint, double* bp_tri, double* up, double* logZ)
+{
+    if (!c) return RH_ERR_ARG;
+    if (constraint && c->model != RH_MODEL_VIENNA_BL)
+        return fail(c, RH_ERR_UNSUPPORTED, "structure constraints apply to the Vienna-BL model only (RactIP::contrafold takes none)");
+    if (!seq || n < 0) return fail(c, RH_ERR_ARG, "bad sequence");
+    if (n == 0) { if (bp_tri) bp_tri[0] = 0.0; if (logZ) *logZ = 0.0; return RH_OK; }
+    int rc;
+    if ((rc = stage(c, 1, &seq, &n, true, false, constraint ? &constraint : nullptr))) return rc;
     if ((rc = compute(c))) return rc;
     if (bp_tri && (rc = fetch_bp(c, 0, bp_tri))) return rc;
     if (up && (rc = fetch_up(c, 0, up))) return rc;

@@ -55,7 +55,8 @@ int main(int argc, char** argv)
         } else if (mode == "rnafold") {   // rnafold SEQ MAX_W
             VF bp; VI off; VVF up;
             const unsigned mw = argc > 3 ? (unsigned)std::atoi(argv[3]) : 1u;
-            en.rnafold(argv[2], bp, off, up, mw);
+            if (argc > 4) en.rnafold(argv[2], argv[4], bp, off, up, mw);   // rnafold SEQ MAX_W STRUCTURE-LINE
+            else en.rnafold(argv[2], bp, off, up, mw);
             std::printf("offset %zu\n", off.size());
             for (int o : off) std::printf("%d\n", o);
             std::printf("bp %zu\n", bp.size());

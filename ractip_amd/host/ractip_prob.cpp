@@ -85,6 +85,23 @@ void ProbabilityEngine::rnafold(const std::string& seq, VF& bp, VI& offset, VVF&
         for (uint w = 0; w < max_w; ++w) up[i][w] = (float)dup[(size_t)i * max_w + w];
 }
 
+void ProbabilityEngine::rnafold(const std::string& seq, const std::string& str, VF& bp, VI& offset, VVF& up, uint max_w) const
+{
+    const uint L = seq.size();
+    std::string c(L, '.');   // src/ractip.cpp:275-287
+    for (uint i = 0; i != str.size() && i != L; ++i) c[i] = (str[i] == '[' || str[i] == ']' || str[i] == 'e') ? 'x' : str[i];
+    std::vector<double> dbp((size_t)(L + 1) * (L + 2) / 2, 0.0), dup((size_t)L * max_w, 0.0);
+    offset = make_offsets(L);
+    rh_ctx* v = vienna();
+    if (L > 0 && (rh_set_max_w(v, (int)max_w) != RH_OK ||
+                  rh_fold_constrained(v, seq.c_str(), (int)L, c.c_str(), dbp.data(), dup.data(), nullptr) != RH_OK))
+        throw std::logic_error(std::string("ractip_amd::rnafold: ") + rh_last_error(v));
+    narrow_bp(dbp, bp);
+    up.assign(L, VF(max_w));
+    for (uint i = 0; i < L; ++i)
+        for (uint w = 0; w < max_w; ++w) up[i][w] = (float)dup[(size_t)i * max_w + w];
+}
+
 void ProbabilityEngine::rnaduplex_cofold(const std::string& seq1, const std::string& seq2, VVF& hp) const
 {
     const uint n1 = seq1.size(), n2 = seq2.size();

@@ -52,6 +52,9 @@ public:
     // first use.
     void rnafold(const std::string& seq, VF& bp, VI& offset) const;
     void rnafold(const std::string& seq, VF& bp, VI& offset, VVF& up, uint max_w) const;
+    // the same with use_constraint_ (:271-291): `str` is the FASTA structure line (Fasta::str()); '[' ']' 'e' become 'x',
+    // everything else is handed to pf_fold's fold_constrained unchanged
+    void rnafold(const std::string& seq, const std::string& str, VF& bp, VI& offset, VVF& up, uint max_w) const;
     // the DEFAULT branch of RactIP::rnaduplex (:400-458): co_pf_fold on s1+s2 with cut_point = |s1|+1, plist entries with
     // i < cut_point <= j and p > th_hy copied to hp[i][j-cut_point+1], everything else 0 (same model and caveats)
     void rnaduplex_cofold(const std::string& seq1, const std::string& seq2, VVF& hp) const;

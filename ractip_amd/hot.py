@@ -18,7 +18,7 @@ EXPORTS = [
     "rh_create", "rh_destroy", "rh_last_error", "rh_set_mode", "rh_last_path", "rh_bpp", "rh_unpaired", "rh_fold", "rh_duplex",
     "rh_batch_upload", "rh_batch_compute", "rh_batch_results", "rh_batch_candidates",
     "rh_batch_timings", "rh_batch_device_views", "rh_batch_logz", "rh_batch_candidates_all", "rh_batch_layout",
-    "rh_batch_results_all", "rh_set_max_w", "rh_get_max_w", "rh_set_overlap", "rh_batch_kernels", "rh_set_hybrid", "rh_last_hybrid_path",
+    "rh_batch_results_all", "rh_set_max_w", "rh_get_max_w", "rh_set_overlap", "rh_batch_kernels", "rh_set_hybrid", "rh_last_hybrid_path", "rh_fold_constrained",
 ]
 
 
@@ -68,6 +68,8 @@ def load_library():
     L.rh_bpp.argtypes = [vp, cp, ci, cp, vp, vp]
     L.rh_unpaired.argtypes = [vp, cp, ci, ci, vp]
     L.rh_fold.argtypes = [vp, cp, ci, vp, vp, vp]
+    L.rh_fold_constrained.argtypes = [vp, cp, ci, cp, vp, vp, vp]
+    L.rh_fold_constrained.restype = ci
     L.rh_duplex.argtypes = [vp, cp, ci, cp, ci, vp, vp]
     L.rh_batch_upload.argtypes = [vp, ci, ctypes.POINTER(cp), ctypes.POINTER(ci), ctypes.POINTER(cp), ctypes.POINTER(ci)]
     L.rh_batch_compute.argtypes = [vp]
@@ -143,11 +145,12 @@ class Context:
         return self.L.rh_get_max_w(self.h)
 
     # ---- single-problem calls
-    def bpp(self, seq):
+    def bpp(self, seq, constraint=None):
         n = len(seq)
         bp = np.zeros(tri_size(n))
         z = ctypes.c_double()
-        self._check(self.L.rh_bpp(self.h, seq.encode(), n, None, bp.ctypes.data, ctypes.addressof(z)))
+        self._check(self.L.rh_bpp(self.h, seq.encode(), n, constraint.encode() if constraint is not None else None,
+                                  bp.ctypes.data, ctypes.addressof(z)))
         return bp, z.value
 
     def unpaired(self, seq, max_w=1):
@@ -156,11 +159,15 @@ class Context:
         self._check(self.L.rh_unpaired(self.h, seq.encode(), n, max_w, up.ctypes.data))
         return up.reshape(n, max_w)
 
-    def fold(self, seq):
+    def fold(self, seq, constraint=None):
         n = len(seq)
         w = self.max_w
         bp, up, z = np.zeros(tri_size(n)), np.zeros(n * w), ctypes.c_double()
-        self._check(self.L.rh_fold(self.h, seq.encode(), n, bp.ctypes.data, up.ctypes.data, ctypes.addressof(z)))
+        if constraint is not None:
+            self._check(self.L.rh_fold_constrained(self.h, seq.encode(), n, constraint.encode(), bp.ctypes.data, up.ctypes.data,
+                                                   ctypes.addressof(z)))
+        else:
+            self._check(self.L.rh_fold(self.h, seq.encode(), n, bp.ctypes.data, up.ctypes.data, ctypes.addressof(z)))
         return bp, (up if w == 1 else up.reshape(n, w)), z.value
 
     def duplex(self, s1, s2):

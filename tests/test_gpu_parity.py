@@ -329,6 +329,50 @@ def test_vienna_bl_mccaskill_and_accessibility_vs_cpu_restatement(vctx, golden):
     vctx.set_max_w(15)
 
 
+def test_vienna_bl_structure_constraints(vctx, golden):
+    """use_constraint_ (src/ractip.cpp:271-291): pf_fold under fold_constrained.  The engine's allowed-pair mask (C++) and the
+    test's (numpy) are independent restatements of ViennaRNA-1.8 make_ptypes; the CPU restatement under the mask is itself
+    checked against brute force below."""
+    import ractip_amd
+    from _oracle import ViennaOracle, ractip_constraint
+    vo = ViennaOracle()
+    s = "GGGAAACCCAGGGAAACCCA"
+    for c in ("....................", "xxx.................", "(......)............", "<<<......>>>........", ".(......)......x....",
+              "((....))..(((...))).", ".|||....x...........", "(((...)))", ""):
+        o = vo.mccaskill(s, max_w=15, constraint=c)
+        b = vo.fold_bruteforce(s, max_w=15, constraint=c)
+        assert abs(o["logZ"] - b["logZ"]) < 1e-11 and np.abs(o["post"] - b["post"]).max() < 1e-11 and np.abs(o["up"] - b["up"]).max() < 1e-11
+        bp, up, z = vctx.fold(s, constraint=c)
+        assert abs(z - o["logZ"]) < 1e-9, c
+        assert_prob_close(bp, o["post"], rel=REL, what="constrained bp " + c)
+        assert_prob_close(up, o["up"], rel=REL, abs_floor=1e-11, what="constrained up " + c)
+    # a bundled RNA with a RactIP-style structure line: brackets of the interaction and 'e' become 'x'
+    seq = str(golden["mc/OxyS/seq"])
+    n = len(seq)
+    free = vo.mccaskill(seq)["post"]
+    # force a moderately likely pair (i,j) far from the block 43..52 that the interaction brackets / 'e' turn into 'x'
+    cand = [(free[tri_offset(n, i) + j], i, j) for i in range(1, 40) for j in range(i + 4, 41) if 0.05 < free[tri_offset(n, i) + j] < 0.6]
+    _, fi, fj = max(cand)
+    line = list("." * n)
+    line[fi - 1], line[fj - 1] = "(", ")"
+    line[42:47] = "[[[[["
+    line[47:52] = "eeeee"
+    line[60:62] = "<<"
+    cons = ractip_constraint("".join(line), n)
+    assert cons[42:52] == "x" * 10 and cons[fi - 1] == "("
+    o = vo.mccaskill(seq, max_w=15, constraint=cons)
+    bp, up, z = vctx.fold(seq, constraint=cons)
+    assert abs(z - o["logZ"]) < 1e-9 * abs(z) and abs(z - vo.mccaskill(seq)["logZ"]) > 1e-3
+    assert_prob_close(bp, o["post"], rel=REL, what="OxyS constrained bp")
+    assert_prob_close(up, o["up"], rel=REL, abs_floor=1e-11, what="OxyS constrained up")
+    assert up[42:52, 0].min() > 1 - 1e-12                       # 'x' letters are unpaired
+    assert bp[tri_offset(n, fi) + fi + 1:tri_offset(n, fi) + n + 1].sum() == bp[tri_offset(n, fi) + fj]   # fi pairs with fj or nothing
+    assert np.array_equal(vctx.bpp(seq)[0], vctx.fold(seq)[0])                                  # the mask does not linger
+    for bad in ("(((", ")", "(..)"):   # unbalanced; forced pair G-G
+        with pytest.raises(ractip_amd.RhError):
+            vctx.bpp("GGGAAACCC" if bad != "(..)" else "GAAG", constraint=bad)
+
+
 def test_vienna_bl_full_size_pair(vctx):
     """BASELINE config 3 under the default-CLI model: one n=500/500 pair (mt19937(12345) stream), rnafold x2 with
     accessibility at width 15 + the two-molecule ensemble over N=1000 (several block-product tiles, the cut in the middle of

@@ -122,3 +122,19 @@ def test_cofold_limits(vo, golden):
     hp = r["hp"]
     assert hp.min() >= 0 and hp.sum(axis=1).max() <= 1 + 1e-9 and hp.sum(axis=0).max() <= 1 + 1e-9
     assert hp.max() > 0.9     # fully complementary antisense pair
+
+
+def test_structure_constraints_equal_bruteforce(vo):
+    """fold_constrained (src/ractip.cpp:271-291): the DP under the allowed-pair mask of ViennaRNA-1.8 make_ptypes == the
+    enumeration of every structure that respects the mask."""
+    s = "GGGAAACCCAGGGAAACCCA"
+    for c in ("xxx.................", "(......)............", "<<<......>>>........", ".(......)......x....",
+              "((....))..(((...))).", ".|||....x...........", "(((...)))"):
+        a, b = vo.mccaskill(s, max_w=6, constraint=c), vo.fold_bruteforce(s, max_w=6, constraint=c)
+        assert abs(a["logZ"] - b["logZ"]) < 1e-11 and np.abs(a["post"] - b["post"]).max() < 1e-11, c
+        assert np.abs(a["up"] - b["up"]).max() < 1e-11, c
+    # a forced pair has the probability of "letter 1 is paired at all" and nothing crosses it
+    a = vo.mccaskill(s, constraint="(......)")
+    n = len(s)
+    off1 = 1 * (2 * (n + 1) - 1 - 1) // 2
+    assert a["post"][off1 + 2:off1 + n + 1].sum() == a["post"][off1 + 8]
