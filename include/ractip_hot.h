@@ -112,6 +112,13 @@ int rh_fold_constrained(rh_ctx* ctx, const char* seq, int n, const char* constra
 int rh_duplex(rh_ctx* ctx, const char* s1, int n1, const char* s2, int n2,
               double* hp, double* logZ);
 
+/* The two-molecule ensemble under a structure constraint: what the default branch of RactIP::rnaduplex hands to
+ * co_pf_fold when use_constraint_ is set (src/ractip.cpp:405-447): `constraint` has n1+n2 characters over s1+s2 in the
+ * fold_constrained alphabet of rh_bpp (RactIP writes '(' for '[' of s1, ')' for ']' of s2 and 'x' for every letter that
+ * is paired inside its own molecule).  RH_MODEL_VIENNA_BL only; independent of rh_set_hybrid. */
+int rh_cofold_constrained(rh_ctx* ctx, const char* s1, int n1, const char* s2, int n2, const char* constraint,
+                          double* hp, double* logZ);
+
 /* ---- batched, device-resident form (z-score loop src/ractip.cpp:1638-1657 and bench) ----
  * A batch is `npairs` independent (s1,s2) pairs; for each the engine computes
  * bp(s1), bp(s2), up(s1), up(s2) and hp(s1,s2) -- everything RactIP::solve needs

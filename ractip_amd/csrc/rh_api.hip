@@ -274,6 +274,7 @@ struct rh_ctx {
     void* d_cand = nullptr;  size_t cap_cand = 0;
     void* d_gaps = nullptr;  size_t cap_gaps = 0;
     void* d_allow = nullptr; size_t cap_allow = 0;   // structure-constraint masks [ns][ld*ld] bytes (Vienna-BL, optional)
+    void* d_coallow = nullptr; size_t cap_coallow = 0;   // the same for the s1+s2 batch
     void* d_hplen = nullptr; size_t cap_hplen = 0;   // lam^d x hairpin length weight, d = 0..nmax (linear Vienna path)
     std::vector<double> h_hplen;
     // two-molecule (co_pf_fold) form of the hybridization matrix: one concatenated sequence s1+s2 per pair
@@ -405,7 +406,8 @@ bool build_allow_mask(const char* seq, int n, const char* cons, int ld, uint8_t*
 
 // Stage `ns` sequences; pairs are (2p, 2p+1) when with_dx.  Allocates what is needed.  cons: per-sequence structure
 // constraints (Vienna-BL, single-molecule batch only) or nullptr.
-int stage(rh_ctx* c, int ns, const char* const* seqs, const int* lens, bool with_mc, bool with_dx, const char* const* cons = nullptr)
+int stage(rh_ctx* c, int ns, const char* const* seqs, const int* lens, bool with_mc, bool with_dx, const char* const* cons = nullptr,
+          const char* const* co_cons = nullptr)
 {
     HIP_TRY(c, hipSetDevice(c->device));
     if (ns <= 0) return fail(c, RH_ERR_ARG, "empty batch");
@@ -545,6 +547,18 @@ int stage(rh_ctx* c, int ns, const char* const* seqs, const int* lens, bool with
             const size_t fs = (size_t)C.ld * np;
             C.f5i = f; C.f5o = f + fs; C.xp = f + 2 * fs; C.xs = f + 3 * fs; C.xpo = f + 4 * fs; C.xso = f + 5 * fs;
             C.bp = (double*)c->d_cobp; C.up = nullptr;
+            if (co_cons) {   // constraints over the concatenation s1+s2 (one string of length n1+n2 per pair)
+                std::vector<uint8_t> M((size_t)np * C.ld * C.ld);
+                std::string why;
+                for (int p = 0; p < np; p++) {
+                    const std::string joint = std::string(seqs[2 * p], lens[2 * p]) + std::string(seqs[2 * p + 1], lens[2 * p + 1]);
+                    if (!build_allow_mask(joint.c_str(), (int)joint.size(), co_cons[p] ? co_cons[p] : "", C.ld, M.data() + (size_t)p * C.ld * C.ld, &why))
+                        return fail(c, RH_ERR_ARG, "pair %d: %s", p, why.c_str());
+                }
+                if ((rc = ensure(c, &c->d_coallow, &c->cap_coallow, M.size(), false))) return rc;
+                HIP_TRY(c, hipMemcpy(c->d_coallow, M.data(), M.size(), hipMemcpyHostToDevice));
+                C.allow = (const uint8_t*)c->d_coallow;
+            }
         }
         X.seq = D.seq; X.n = D.n; X.tab = D.tab; X.hp = D.hp; X.hp_stride = D.tab_stride;
     }
@@ -855,7 +869,7 @@ size_t shape_key(const rh_ctx* c, int which)
         const McBatch& B = c->co;
         for (size_t v : {(size_t)B.ns, (size_t)B.nmax, (size_t)B.ld, (size_t)B.lds, (size_t)B.tab, (size_t)B.seq, (size_t)B.n, (size_t)B.f5i,
                          (size_t)B.bp, (size_t)c->d_cobad, (size_t)c->lin_bs, (size_t)B.tri_stride, (size_t)c->dx.hp, (size_t)c->dx.logz,
-                         (size_t)c->dx.ldd, (size_t)c->dx.tab_stride, (size_t)c->dx.n1max, (size_t)c->dx.n2max})
+                         (size_t)c->dx.ldd, (size_t)c->dx.tab_stride, (size_t)c->dx.n1max, (size_t)c->dx.n2max, (size_t)B.allow})
             h = mix(h, v);
     } else if (which <= 1) {
         const McBatch& B = c->mc;
@@ -1140,7 +1154,7 @@ void rh_destroy(rh_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    void* bufs[] = {c->d_seq, c->d_n, c->d_mctab, c->d_f5, c->d_bp, c->d_up, c->d_dxtab, c->d_hp, c->d_logz, c->d_scal, c->d_mclogz, c->d_bad, c->d_cnt, c->d_cand, c->d_dxbad, c->d_zbar, c->d_gaps, c->d_coseq, c->d_con, c->d_cotab, c->d_cof5, c->d_cobp, c->d_cobad, c->d_allow, c->d_vlin, c->d_hplen, c->d_model, c->d_lin, c->d_dxlin, c->d_vienna};
+    void* bufs[] = {c->d_seq, c->d_n, c->d_mctab, c->d_f5, c->d_bp, c->d_up, c->d_dxtab, c->d_hp, c->d_logz, c->d_scal, c->d_mclogz, c->d_bad, c->d_cnt, c->d_cand, c->d_dxbad, c->d_zbar, c->d_gaps, c->d_coseq, c->d_con, c->d_cotab, c->d_cof5, c->d_cobp, c->d_cobad, c->d_allow, c->d_coallow, c->d_vlin, c->d_hplen, c->d_model, c->d_lin, c->d_dxlin, c->d_vienna};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (GraphSlot* g : {&c->g_in, &c->g_out, &c->g_dx}) if (g->exec) (void)hipGraphExecDestroy(g->exec);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -1219,6 +1233,23 @@ int rh_duplex(rh_ctx* c, const char* s1, int n1, const char* s2, int n2, double*
     if ((rc = stage(c, 2, seqs, lens, false, true))) return rc;
     if ((rc = compute(c))) return rc;
     return fetch_hp(c, 0, hp, logZ);
+}
+
+int rh_cofold_constrained(rh_ctx* c, const char* s1, int n1, const char* s2, int n2, const char* constraint, double* hp, double* logZ)
+{
+    if (!c) return RH_ERR_ARG;
+    if (c->model != RH_MODEL_VIENNA_BL) return fail(c, RH_ERR_UNSUPPORTED, "the two-molecule ensemble needs RH_MODEL_VIENNA_BL");
+    if (!s1 || !s2 || n1 < 1 || n2 < 1) return fail(c, RH_ERR_ARG, "bad sequence");
+    const char* seqs[2] = {s1, s2};
+    const int lens[2] = {n1, n2};
+    const int keep = c->hybrid;
+    c->hybrid = RH_HYBRID_COFOLD;
+    int rc = stage(c, 2, seqs, lens, false, true, nullptr, constraint ? &constraint : nullptr);
+    if (!rc) rc = compute(c);
+    if (!rc) rc = fetch_hp(c, 0, hp, logZ);
+    c->hybrid = keep;
+    c->ns = 0; c->computed = false;   // the staged batch belongs to the other hybridization mode
+    return rc;
 }
 
 int rh_batch_upload(rh_ctx* c, int npairs, const char* const* s1, const int* n1, const char* const* s2, const int* n2)

@@ -66,7 +66,10 @@ int main(int argc, char** argv)
         } else if (mode == "contraduplex") {
             VVF hp; en.contraduplex(argv[2], argv[3], hp); dump_hp(hp);
         } else if (mode == "cofold") {
-            VVF hp; en.rnaduplex_cofold(argv[2], argv[3], hp); dump_hp(hp);
+            VVF hp;
+            if (argc > 5) en.rnaduplex_cofold(argv[2], argv[4], argv[3], argv[5], hp);   // cofold S1 S2 STR1 STR2
+            else en.rnaduplex_cofold(argv[2], argv[3], hp);
+            dump_hp(hp);
         } else if (mode == "rnaduplex") {
             VVF hp; en.rnaduplex(argv[2], argv[3], hp); dump_hp(hp);
         } else if (mode == "solve") {

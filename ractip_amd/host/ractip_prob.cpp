@@ -121,6 +121,36 @@ void ProbabilityEngine::rnaduplex_cofold(const std::string& seq1, const std::str
         }
 }
 
+void ProbabilityEngine::rnaduplex_cofold(const std::string& seq1, const std::string& str1, const std::string& seq2,
+                                         const std::string& str2, VVF& hp) const
+{
+    const uint n1 = seq1.size(), n2 = seq2.size();
+    hp.assign(n1 + 1, VF(n2 + 1, 0.0f));
+    if (n1 == 0 || n2 == 0) return;
+    std::string c(n1 + n2, '.');   // src/ractip.cpp:409-440
+    for (uint i = 0; i != str1.size() && i != n1; ++i)
+        switch (str1[i]) {
+            case '[': c[i] = '('; break;
+            case '(': case ')': case 'l': case 'x': c[i] = 'x'; break;
+            default: break;
+        }
+    for (uint i = 0; i != str2.size() && i != n2; ++i)
+        switch (str2[i]) {
+            case ']': c[n1 + i] = ')'; break;
+            case '(': case ')': case 'l': case 'x': c[n1 + i] = 'x'; break;
+            default: break;
+        }
+    rh_ctx* v = vienna();
+    std::vector<double> d((size_t)(n1 + 1) * (n2 + 1));
+    if (rh_cofold_constrained(v, seq1.c_str(), (int)n1, seq2.c_str(), (int)n2, c.c_str(), d.data(), nullptr) != RH_OK)
+        throw std::logic_error(std::string("ractip_amd::rnaduplex: ") + rh_last_error(v));
+    for (uint i = 1; i <= n1; ++i)
+        for (uint j = 1; j <= n2; ++j) {
+            const float p = (float)d[(size_t)i * (n2 + 1) + j];
+            if (p > th_hy_) hp[i][j] = p;
+        }
+}
+
 void ProbabilityEngine::contraduplex(const std::string& seq1, const std::string& seq2, VVF& hp) const
 {
     const uint n1 = seq1.size(), n2 = seq2.size();

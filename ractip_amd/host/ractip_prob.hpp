@@ -58,6 +58,9 @@ public:
     // the DEFAULT branch of RactIP::rnaduplex (:400-458): co_pf_fold on s1+s2 with cut_point = |s1|+1, plist entries with
     // i < cut_point <= j and p > th_hy copied to hp[i][j-cut_point+1], everything else 0 (same model and caveats)
     void rnaduplex_cofold(const std::string& seq1, const std::string& seq2, VVF& hp) const;
+    // ... with use_constraint_ (:409-440): str1 / str2 are the FASTA structure lines; '[' of s1 becomes '(' and ']' of s2
+    // becomes ')' (the interaction is forced), and '(' ')' 'l' 'x' become 'x' (letters paired inside their own molecule)
+    void rnaduplex_cofold(const std::string& seq1, const std::string& str1, const std::string& seq2, const std::string& str2, VVF& hp) const;
 
     // batched form for the z-score loop (:1638-1657): all DPs of all pairs in one device pass
     std::vector<PairProbabilities> solve_probabilities(const std::vector<std::pair<std::string, std::string>>& pairs) const;

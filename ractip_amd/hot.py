@@ -18,7 +18,7 @@ EXPORTS = [
     "rh_create", "rh_destroy", "rh_last_error", "rh_set_mode", "rh_last_path", "rh_bpp", "rh_unpaired", "rh_fold", "rh_duplex",
     "rh_batch_upload", "rh_batch_compute", "rh_batch_results", "rh_batch_candidates",
     "rh_batch_timings", "rh_batch_device_views", "rh_batch_logz", "rh_batch_candidates_all", "rh_batch_layout",
-    "rh_batch_results_all", "rh_set_max_w", "rh_get_max_w", "rh_set_overlap", "rh_batch_kernels", "rh_set_hybrid", "rh_last_hybrid_path", "rh_fold_constrained",
+    "rh_batch_results_all", "rh_set_max_w", "rh_get_max_w", "rh_set_overlap", "rh_batch_kernels", "rh_set_hybrid", "rh_last_hybrid_path", "rh_fold_constrained", "rh_cofold_constrained",
 ]
 
 
@@ -70,6 +70,8 @@ def load_library():
     L.rh_fold.argtypes = [vp, cp, ci, vp, vp, vp]
     L.rh_fold_constrained.argtypes = [vp, cp, ci, cp, vp, vp, vp]
     L.rh_fold_constrained.restype = ci
+    L.rh_cofold_constrained.argtypes = [vp, cp, ci, cp, ci, cp, vp, vp]
+    L.rh_cofold_constrained.restype = ci
     L.rh_duplex.argtypes = [vp, cp, ci, cp, ci, vp, vp]
     L.rh_batch_upload.argtypes = [vp, ci, ctypes.POINTER(cp), ctypes.POINTER(ci), ctypes.POINTER(cp), ctypes.POINTER(ci)]
     L.rh_batch_compute.argtypes = [vp]
@@ -174,6 +176,14 @@ class Context:
         hp = np.zeros((len(s1) + 1, len(s2) + 1))
         z = ctypes.c_double()
         self._check(self.L.rh_duplex(self.h, s1.encode(), len(s1), s2.encode(), len(s2), hp.ctypes.data, ctypes.addressof(z)))
+        return hp, z.value
+
+    def cofold(self, s1, s2, constraint=None):
+        """hp and log Z of the two-molecule ensemble, optionally under a constraint over s1+s2 (Vienna-BL model)."""
+        hp = np.zeros((len(s1) + 1, len(s2) + 1))
+        z = ctypes.c_double()
+        self._check(self.L.rh_cofold_constrained(self.h, s1.encode(), len(s1), s2.encode(), len(s2),
+                                                 constraint.encode() if constraint is not None else None, hp.ctypes.data, ctypes.addressof(z)))
         return hp, z.value
 
     # ---- batched calls

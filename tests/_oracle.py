@@ -223,7 +223,15 @@ class ViennaOracle:
                                 tabs.ctypes.data if tables else None, f5.ctypes.data if tables else None)
         return dict(logZ=z, logZ_out=zo.value, post=post, up=up, tables=tabs, f5=f5)
 
-    def cofold(self, s1, s2, bruteforce=False):
+    def cofold(self, s1, s2, bruteforce=False, constraint=None):
+        mask = constraint_mask(constraint, len(s1) + len(s2)) if constraint is not None else None
+        self.L.vo_set_allow_mask(mask.ctypes.data if mask is not None else None)
+        try:
+            return self._cofold(s1, s2, bruteforce)
+        finally:
+            self.L.vo_set_allow_mask(None)
+
+    def _cofold(self, s1, s2, bruteforce=False):
         """co_pf_fold semantics on s1+s2 (cut after s1): logZ of the two-molecule ensemble, the full pair matrix of the
         concatenation (triangular, reference layout) and the intermolecular block hp[i][j] = P(s1[i] pairs s2[j]),
         (n1+1) x (n2+1), 1-based, the layout of src/ractip.cpp:451-454."""

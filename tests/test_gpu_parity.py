@@ -373,6 +373,33 @@ def test_vienna_bl_structure_constraints(vctx, golden):
             vctx.bpp("GGGAAACCC" if bad != "(..)" else "GAAG", constraint=bad)
 
 
+def test_vienna_bl_constrained_two_molecule_ensemble(vctx, golden):
+    """co_pf_fold under the constraint string RactIP builds with use_constraint_ (src/ractip.cpp:405-447): forced
+    intermolecular pairs '(' ')' across the cut, 'x' for letters paired inside their own molecule."""
+    from _oracle import ViennaOracle
+    vo = ViennaOracle()
+    s1, s2 = "GGGAAACCCAGG", "CCUGGGAAACCC"
+    for c in ("........................", "(......................)", "((....................))", "xxx.....................",
+              "......(((......)))......"):
+        o, b = vo.cofold(s1, s2, constraint=c), vo.cofold(s1, s2, bruteforce=True, constraint=c)
+        assert abs(o["logZ"] - b["logZ"]) < 1e-11 and np.abs(o["post"] - b["post"]).max() < 1e-11
+        hp, z = vctx.cofold(s1, s2, constraint=c)
+        assert abs(z - o["logZ"]) < 1e-9, c
+        assert_prob_close(hp, o["hp"], rel=REL, what="constrained cofold " + c)
+    a, b = str(golden["mc/CopA/seq"]), str(golden["mc/CopT/seq"])
+    n1, n2 = len(a), len(b)
+    c = list("." * (n1 + n2))
+    c[20], c[n1 + n2 - 21] = "(", ")"          # CopA[21] with CopT[n2-20]: complementary antisense letters
+    c[0:5] = "xxxxx"
+    c = "".join(c)
+    o = vo.cofold(a, b, constraint=c)
+    hp, z = vctx.cofold(a, b, constraint=c)
+    assert abs(z - o["logZ"]) < 1e-9 * abs(z)
+    assert_prob_close(hp, o["hp"], rel=REL, what="CopA/CopT constrained")
+    assert hp[1:6].max() == 0 and abs(hp[21, n2 - 20] - hp[21].sum()) < 1e-15
+    assert np.array_equal(vctx.cofold(a, b)[0], vctx.cofold(a, b, constraint="." * (n1 + n2))[0])
+
+
 def test_vienna_bl_full_size_pair(vctx):
     """BASELINE config 3 under the default-CLI model: one n=500/500 pair (mt19937(12345) stream), rnafold x2 with
     accessibility at width 15 + the two-molecule ensemble over N=1000 (several block-product tiles, the cut in the middle of
