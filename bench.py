@@ -27,6 +27,23 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def compulsory_bytes(pairs, vienna, cofold):
+    """16 B per cell of every DP table the path keeps in HBM (one store + one load), plus the result matrices: the floor for a
+    kernel that held everything else on chip."""
+    tabs = 16 if vienna else 13          # diagonal-major tables per sequence on the linear path (incl. block-product sums)
+    tot = 0
+    for s1, s2 in pairs:
+        for n in (len(s1), len(s2)):
+            tot += 16 * tabs * (n * (n + 1) // 2) + 8 * (n + 1) * (n + 2) // 2 + 8 * n * (15 if vienna else 1)
+        if cofold:
+            N = len(s1) + len(s2)
+            tot += 16 * tabs * (N * (N + 1) // 2) + 8 * (N + 1) * (N + 2) // 2
+        else:
+            tot += 16 * (6 if vienna else 4) * len(s1) * len(s2)
+        tot += 8 * (len(s1) + 1) * (len(s2) + 1)
+    return tot
+
+
 def cpu_baseline_vienna(pairs, budget_s=12.0, cofold=True):
     """Vienna-BL workload: our CPU restatement (oracle/vienna_oracle.c, kind "port"; ViennaRNA itself is absent), 1 thread."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -283,6 +300,8 @@ def main():
                                    "where the duplex stream overlaps the McCaskill stream",
                          "kernels": kernels,
                          "whole_path": {"alg_GB_per_pair": b["total"] / 1e9 / batch,
+                                        # every DP table written once and read once (SURVEY 8d's "compulsory bytes")
+                                        "compulsory_GB_per_pair": compulsory_bytes(pairs, vienna, cofold) / 1e9 / batch,
                                         "achieved_GBs": b["total"] / 1e9 / (ms_mean[3] / 1e3),
                                         "frac": b["total"] / 1e9 / (ms_mean[3] / 1e3) / HBM_PEAK_GBS},
                          "phases": phases},
