@@ -63,6 +63,54 @@ def cpu_baseline_vienna(pairs, budget_s=12.0, cofold=True):
                 done, len(pairs[0][0]), len(pairs[0][1]), dt, "co_pf_fold" if cofold else "pf_duplex")}
 
 
+def cpu_baseline_all_cores(n, vienna, cofold, per_worker=2):
+    """every host core runs the single-threaded CPU path on its own pairs (one process per core,
+    no GPU use); whole-host pairs/s with the core count stated.  Bounded: `per_worker` pairs per process."""
+    import subprocess
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # a one-GPU job owns a 16-core share of its host whatever the affinity mask says; more workers only oversubscribe
+    cores = min(cores, int(os.environ.get("RACTIP_BENCH_CPU_WORKERS", "16")))
+    code = (
+        "import sys, os, time; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from ractip_amd.seqgen import random_pairs\n"
+        "k, cnt, n, vienna, cofold = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4] == '1', sys.argv[5] == '1'\n"
+        "pairs = random_pairs((k + 1) * cnt, n, seed=12345)[k * cnt:]\n"
+        "if vienna:\n"
+        "    from _oracle import ViennaOracle; e = ViennaOracle()\n"
+        "    for a, b in pairs: e.mccaskill(a, max_w=15); e.mccaskill(b, max_w=15); (e.cofold if cofold else e.pf_duplex)(a, b)\n"
+        "else:\n"
+        "    from _oracle import Oracle, Reference\n"
+        "    try: e = Reference()\n"
+        "    except (FileNotFoundError, OSError): e = Oracle()\n"
+        "    for a, b in pairs: e.inference(a); e.inference(b); e.duplex(a, b)\n"
+    ) % (ROOT, os.path.join(ROOT, "tests"))
+    t0 = time.perf_counter()
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(k), str(per_worker), str(n), "1" if vienna else "0", "1" if cofold else "0"],
+                              env=dict(os.environ, OMP_NUM_THREADS="1")) for k in range(cores)]
+    ok = all(p.wait() == 0 for p in procs)
+    dt = time.perf_counter() - t0
+    if not ok:
+        return None
+    return {"value": cores * per_worker / dt, "unit": "pairs/s", "cores": cores,
+            "sample": "%d processes x %d pair(s) of n=%d, %.1f s wall (incl. process start)" % (cores, per_worker, n, dt)}
+
+
+def copy_bandwidth_GBs(torch, nbytes=1 << 30, reps=5):
+    """Device-to-device copy rate (read + write bytes per second) of this GPU: the achievable-HBM figure BASELINE.md asks to
+    state beside the nominal 8 TB/s."""
+    a = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    b = torch.empty_like(a)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * nbytes * reps / (e0.elapsed_time(e1) / 1e3) / 1e9
+
+
 def cpu_baseline(pairs, budget_s=20.0):
     """Time the CPU path on a bounded sample of the same workload (rank 0, N=1 only).
 
@@ -292,6 +340,7 @@ def main():
                                    % ("co_pf_fold(s1+s2)" if cofold else "pf_duplex")) if vienna
                                   else "CONTRAfold complementary (708 weights)"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "peak_copy_measured": copy_bandwidth_GBs(torch) if world == 1 else None,
                          "frac": ach / HBM_PEAK_GBS if ach else None, "traffic": traffic,
                          "alg_bytes_per_launch": kernels[dom]["alg_bytes_per_launch"],
                          "avg_launch_us": kernels[dom]["avg_launch_us"],
@@ -324,6 +373,8 @@ def main():
                 line["cpu_baseline"] = cpu_baseline_vienna(all_pairs, budget_s=12.0 if n <= 600 else 1.0, cofold=cofold)
             else:
                 line["cpu_baseline"] = cpu_baseline(all_pairs, budget_s=12.0 if n <= 600 else 1.0)
+            if n <= 600 and args.workload == "pairs":
+                line["cpu_baseline_all_cores"] = cpu_baseline_all_cores(n, vienna, cofold, per_worker=1 if vienna and cofold else 2)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
