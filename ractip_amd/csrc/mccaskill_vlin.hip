@@ -677,9 +677,13 @@ __global__ __launch_bounds__(256) void vlin_acc_prep(McBatch B, const VLinModel*
 }
 
 // gap probabilities of interior loops, one THREAD per (letter, own gap length g >= 1), lanes over the letter:
-//   z = 0: GL[p][g] = sum over loops with outer 5' letter p and g unpaired letters p+1..p+g:  loop over the outer span D and l2
-//   z = 1: GR[q][g] = the same for the 3' gap q-g..q-1 of the outer 3' letter q:              loop over D and l1
-// A loop is at most as probable as its outer pair: pairs below 1e-25 are skipped.
+//   z <  30: GL[p][g] = sum over loops with outer 5' letter p and g unpaired letters p+1..p+g
+//   z >= 30: GR[q][g] = the same for the 3' gap q-g..q-1 of the outer 3' letter q
+// For a fixed thread the inner pair's 5' letter k = p+1+g (left) resp. 3' letter l = q-1-g (right) is fixed and the
+// loops are (inner span r, other gap o): inner cell (k, k+r) resp. (l-1-r, l-1), outer span D = r+2+g+o.  The outer
+// values needed for r+1 are those of r shifted by one o: they live in a 31-entry register window, one new load per r
+// (instead of 31), the generic weights w(g,o) in scalar registers.  Bulges and the tabulated small loops are a handful
+// of (g,o) combinations and are added with direct loads.
 __global__ __launch_bounds__(256) void vlin_acc_gaps(McBatch B, const VLinModel* __restrict__ L, double* __restrict__ gaps)
 {
     const int sq = blockIdx.y;
@@ -687,7 +691,7 @@ __global__ __launch_bounds__(256) void vlin_acc_gaps(McBatch B, const VLinModel*
     const int g = blockIdx.z % 30 + 1;
     const bool right = blockIdx.z >= 30;
     const int pos = blockIdx.x * blockDim.x + threadIdx.x + 1;   // p (left) or q (right)
-    if (pos > n) return;
+    const bool live = pos <= n;
     const uint8_t* __restrict__ s = B.seq + (size_t)sq * B.lds;
     const double* __restrict__ tab = B.tab + (size_t)sq * B.seq_stride;
     const size_t ts = B.tab_stride;
@@ -698,36 +702,79 @@ __global__ __launch_bounds__(256) void vlin_acc_gaps(McBatch B, const VLinModel*
     const double* __restrict__ FC = tab + VL_FC * ts;
     const double* __restrict__ FCX = tab + VL_FCX * ts;
     const double* __restrict__ FCB = tab + VL_FCB * ts;
+    constexpr int NW = kMaxSingle + 1;
+    // generic weights of (own gap g, other gap o); 0 for bulges, tabulated shapes and o beyond the loop budget
+    double wt[NW];
+#pragma unroll
+    for (int o = 0; o < NW; o++) {
+        const int t = g + o;
+        wt[o] = t <= kMaxSingle ? L->shape_w[t * (t + 1) / 2 + (right ? o : g)] : 0.0;
+    }
+    // outer cell of (r, o): span D = r+2+g+o, column p (left) resp. q-1-D (right); 0 outside the interior
+    auto outer_at = [&](const double* __restrict__ T, int D) -> double {
+        const int pc = right ? pos - 1 - D : pos;
+        return (live && pc >= 1 && pc + D <= n - 1) ? T[(size_t)D * ld + pc] : 0.0;
+    };
+    double win[NW];
+#pragma unroll
+    for (int o = 0; o < NW; o++) win[o] = outer_at(FCOX, 2 + g + o);
+    const int kl = right ? pos - 1 - g : pos + 1 + g;   // inner 3' letter l (right) resp. inner 5' letter k (left)
+    const int rmax = right ? kl - 2 : n - 1 - kl;       // inner spans 0..rmax are interior
     double acc = 0.0;
-    for (int D = g + 2; D <= n - 2; D++) {     // outer cell (p, p+D), pair letters (p, q = p+D+1)
-        const int p = right ? pos - D - 1 : pos;
-        if (p < 1 || p + D > n - 1) { if (right) break; else if (p + D > n - 1) break; else continue; }
-        const size_t oc = (size_t)D * ld + p;
-        const double fco = FCO[oc];
-        if (!(fco * FC[oc] > 1e-25 * Z)) continue;
-        const int q = p + D + 1;
-        const int to = L->ptype[s[p] * 5 + s[q]];
-        const double fcox = FCOX[oc], fcob = FCOB[oc];
-        const int omax = kMaxSingle - g < D - 2 - g ? kMaxSingle - g : D - 2 - g;   // other gap length
-        for (int o = 0; o <= omax; o++) {
-            const int l1 = right ? o : g, l2 = right ? g : o;
-            const int t = l1 + l2;
-            const int k = p + 1 + l1;                       // inner 5' letter; inner cell (k, l-1), l = q-1-l2
-            const size_t ic = (size_t)(D - 2 - t) * ld + k;
-            const int nl = l1 > l2 ? l1 : l2, ns = l1 > l2 ? l2 : l1;
-            if (ns == 0) {
-                if (nl >= 2) acc = fma(fcob * L->WB[nl], FCB[ic], acc);
-                else {                                      // 1-bulge: joint table
-                    const int l = q - 1 - l2;
-                    acc = fma(fco * small_w(L, l1, l2, to, L->ptype[s[k] * 5 + s[l]], s[p + 1], s[q - 1], s[k - 1], s[l + 1]), FC[ic], acc);
+    // largest interior inner span of any thread of this block (threads are consecutive letters)
+    const int pos_lo = blockIdx.x * blockDim.x + 1, pos_hi = pos_lo + (int)blockDim.x - 1 < n ? pos_lo + (int)blockDim.x - 1 : n;
+    const int rlim = right ? pos_hi - 1 - g - 2 : n - 1 - (pos_lo + 1 + g);
+    constexpr int UR = 4;   // inner spans per batch of loads (all loads of a batch are issued before any arithmetic)
+    for (int r0 = 0; r0 <= rlim; r0 += UR) {
+        double xs[UR], wn[UR], bo[UR], bi[UR];
+        bool ok[UR];
+        size_t ics[UR];
+#pragma unroll
+        for (int u = 0; u < UR; u++) {
+            const int r = r0 + u;
+            ok[u] = live && r <= rmax && kl >= 1;
+            const int kc = right ? kl - 1 - r : kl;          // inner cell column
+            ics[u] = (size_t)r * ld + (ok[u] ? kc : 1);
+            xs[u] = ok[u] ? FCX[ics[u]] : 0.0;
+            wn[u] = outer_at(FCOX, r + 1 + 2 + g + (NW - 1));   // enters the window after inner span r
+            bo[u] = (ok[u] && g >= 2) ? outer_at(FCOB, r + 2 + g) : 0.0;   // bulge (own gap g >= 2, other gap 0)
+            bi[u] = (ok[u] && g >= 2) ? FCB[ics[u]] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < UR; u++) {
+            const int r = r0 + u;
+            double sum = 0.0;
+#pragma unroll
+            for (int o = 0; o < NW; o++) sum = fma(wt[o], win[o], sum);
+            acc = fma(xs[u], sum, acc);
+            acc = fma(bo[u] * L->WB[g], bi[u], acc);
+            // the tabulated shapes that involve this gap length
+            if (ok[u] && g <= 2) {
+                const double fc = FC[ics[u]];
+                if (fc != 0.0) {
+                    const int k = right ? kl - 1 - r : kl, l = k + r + 1;      // inner pair letters
+                    const int ti = L->ptype[s[k] * 5 + s[l]];
+                    for (int o = 0; o <= 2; o++) {
+                        const int l1 = right ? o : g, l2 = right ? g : o;
+                        const bool tabulated = (l1 <= 2 && l2 <= 2) && !(l1 + l2 == 2 && (l1 == 0 || l2 == 0));   // 0x2 / 2x0 are bulges
+                        if (!tabulated) continue;
+                        const int D = r + 2 + g + o;
+                        const int p = k - 1 - l1, q = p + D + 1;
+                        if (p < 1 || q > n) continue;
+                        const double fo = FCO[(size_t)D * ld + p];
+                        if (fo == 0.0) continue;
+                        const int to = L->ptype[s[p] * 5 + s[q]];
+                        acc = fma(fo * small_w(L, l1, l2, to, ti, s[p + 1], s[q - 1], s[k - 1], s[l + 1]), fc, acc);
+                    }
                 }
-            } else if (nl <= 2) {                           // 1x1, 1x2, 2x1, 2x2
-                const int l = q - 1 - l2;
-                acc = fma(fco * small_w(L, l1, l2, to, L->ptype[s[k] * 5 + s[l]], s[p + 1], s[q - 1], s[k - 1], s[l + 1]), FC[ic], acc);
-            } else acc = fma(fcox * L->shape_w[t * (t + 1) / 2 + l1], FCX[ic], acc);
+            }
+            // slide the window: the outer values of r+1 are those of r one o further
+#pragma unroll
+            for (int o = 0; o + 1 < NW; o++) win[o] = win[o + 1];
+            win[NW - 1] = wn[u];
         }
     }
-    gaps[((size_t)(2 * sq + (right ? 1 : 0)) * ld + pos) * 32 + g] = acc / Z;
+    if (live) gaps[((size_t)(2 * sq + (right ? 1 : 0)) * ld + pos) * 32 + g] = acc / Z;
 }
 
 // up[(a-1)*max_w + w] = H part: sum_{p<a, q>a+w} Hp[p][q] from the column prefix sums C (square scratch); one wavefront per letter
