@@ -142,7 +142,7 @@ __global__ void vlin_init(McBatch B, int* __restrict__ bad)
 // ---------------------------------------------------------------------------------
 // inside, diagonal d.  hp_d = lam^d * hairpin length weight of a loop of d unpaired letters.
 template <int W, int BS, bool CUT>
-__global__ __launch_bounds__(64 * W) void vlin_inside_diag(McBatch B, const VLinModel* __restrict__ L, int d, double hp_d, int pin)
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(6, 8))) void vlin_inside_diag(McBatch B, const VLinModel* __restrict__ L, int d, double hp_d, int pin)
 {
     __shared__ double part[3][W][64];
     __shared__ double gbuf[W][2 * ((kMaxSingle / 2 + W) / W)][96];
@@ -219,43 +219,6 @@ __global__ __launch_bounds__(64 * W) void vlin_inside_diag(McBatch B, const VLin
     // seen from outside; a neighbour on the other molecule gives no dangle (letter code 0)
     const int idd = 25 * (5 * s_jp1 + (GAPOK(j + 1) ? s_jp2 : 0)) + 5 * s_i + (GAPOK(i - 1) ? s_im1 : 0);
     const int idx_raw = 25 * (5 * s_jp1 + s_jp2) + 5 * s_i + s_im1;
-    double e_txo = 0, e_tmc = 0, e_tmh = 0, e_txi = 0, e_tsa = 0, e_tau = 1, e_tet = 1, nick = 0.0;
-    double o_fca = 0, o_fm1 = 0, o_fms = 0, sm7 = 0.0;
-    if (w == 0 && valid) {
-        e_txo = L->TXO[idx]; e_tmc = L->TMC[idx]; e_tmh = L->TMH[idx];
-        e_txi = L->TXI[idx_raw]; e_tsa = L->TSA[idd]; e_tau = L->E_tau[type];
-        if (nick_in && pairable && d >= kMinHairpin)
-            nick = B.xs[(size_t)sq * ld + i + 1] * B.xp[(size_t)sq * ld + j] *
-                   L->TNC[25 * (5 * s_i + (GAPOK(i) ? s_ip1 : 0)) + 5 * s_jp1 + (GAPOK(j) ? s_j : 0)];
-        if (d == 4 && pairable) {   // tetraloop bonus: closing pair + 4 loop letters
-            int code = 0; bool ok = true;
-#pragma unroll
-            for (int k = 0; k < 6; k++) { const int c = s[i + k]; ok = ok && c != 0; code = code * 4 + (c - 1); }
-            if (ok) e_tet = L->E_tetra[code];
-        }
-        if (d >= 2) {   // a multiloop element may not touch the missing gap
-            if (GAPOK(i) && GAPOK(j)) o_fca = tab[VL_FCA * ts + (d - 2) * ld + i + 1];
-            if (GAPOK(i) && GAPOK(i + 1)) o_fm1 = tab[VL_FM1 * ts + (d - 1) * ld + i + 1];
-            if (GAPOK(j - 1) && GAPOK(j)) o_fms = tab[VL_FMS * ts + (d - 1) * ld + i];
-        }
-        if (pairable && d >= 2) {
-            // the seven tabulated shapes: inner pair letters (p, q) = (i+1+l1, j-l2), raw table cell (p, q-1)
-            const double* __restrict__ fc = tab + VL_FC * ts;
-#pragma unroll
-            for (int k = 0; k < 7; k++) {
-                const int l1 = (k == 2 || k == 3 || k == 4) ? 1 : (k >= 5 ? 2 : 0);
-                const int l2 = (k == 1 || k == 3 || k == 5) ? 1 : ((k == 4 || k == 6) ? 2 : 0);
-                const int t = l1 + l2;
-                if (d - 2 - t >= 0 && l1 <= l1max && l2 <= l2max) {
-                    const int p = i + 1 + l1, q = j - l2;
-                    const int t2 = L->ptype[s[p] * 5 + s[q]];
-                    const double v = fc[(d - 2 - t) * ld + p];
-                    sm7 = fma(v, small_w(L, l1, l2, type, t2, s_ip1, s_j, s[p - 1], s[q + 1]), sm7);
-                }
-            }
-        }
-    }
-
     // ---- FM2[i,d] = sum_{m=1}^{d-1} FM1[m][i] * FM[d-m][i+m]: near terms here, far blocks from FM2F
     double acc2 = 0.0;
     {
@@ -336,6 +299,43 @@ __global__ __launch_bounds__(64 * W) void vlin_inside_diag(McBatch B, const VLin
     part[2][w][lane] = accb;
     __syncthreads();
     if (w != 0 || !valid) return;
+    double e_txo = 0, e_tmc = 0, e_tmh = 0, e_txi = 0, e_tsa = 0, e_tau = 1, e_tet = 1, nick = 0.0;
+    double o_fca = 0, o_fm1 = 0, o_fms = 0, sm7 = 0.0;
+    {   // epilogue operands: loaded here, after the term loops, so that they do not occupy registers during them
+        e_txo = L->TXO[idx]; e_tmc = L->TMC[idx]; e_tmh = L->TMH[idx];
+        e_txi = L->TXI[idx_raw]; e_tsa = L->TSA[idd]; e_tau = L->E_tau[type];
+        if (nick_in && pairable && d >= kMinHairpin)
+            nick = B.xs[(size_t)sq * ld + i + 1] * B.xp[(size_t)sq * ld + j] *
+                   L->TNC[25 * (5 * s_i + (GAPOK(i) ? s_ip1 : 0)) + 5 * s_jp1 + (GAPOK(j) ? s_j : 0)];
+        if (d == 4 && pairable) {   // tetraloop bonus: closing pair + 4 loop letters
+            int code = 0; bool ok = true;
+#pragma unroll
+            for (int k = 0; k < 6; k++) { const int c = s[i + k]; ok = ok && c != 0; code = code * 4 + (c - 1); }
+            if (ok) e_tet = L->E_tetra[code];
+        }
+        if (d >= 2) {   // a multiloop element may not touch the missing gap
+            if (GAPOK(i) && GAPOK(j)) o_fca = tab[VL_FCA * ts + (d - 2) * ld + i + 1];
+            if (GAPOK(i) && GAPOK(i + 1)) o_fm1 = tab[VL_FM1 * ts + (d - 1) * ld + i + 1];
+            if (GAPOK(j - 1) && GAPOK(j)) o_fms = tab[VL_FMS * ts + (d - 1) * ld + i];
+        }
+        if (pairable && d >= 2) {
+            // the seven tabulated shapes: inner pair letters (p, q) = (i+1+l1, j-l2), raw table cell (p, q-1)
+            const double* __restrict__ fc = tab + VL_FC * ts;
+#pragma unroll
+            for (int k = 0; k < 7; k++) {
+                const int l1 = (k == 2 || k == 3 || k == 4) ? 1 : (k >= 5 ? 2 : 0);
+                const int l2 = (k == 1 || k == 3 || k == 5) ? 1 : ((k == 4 || k == 6) ? 2 : 0);
+                const int t = l1 + l2;
+                if (d - 2 - t >= 0 && l1 <= l1max && l2 <= l2max) {
+                    const int p = i + 1 + l1, q = j - l2;
+                    const int t2 = L->ptype[s[p] * 5 + s[q]];
+                    const double v = fc[(d - 2 - t) * ld + p];
+                    sm7 = fma(v, small_w(L, l1, l2, type, t2, s_ip1, s_j, s[p - 1], s[q + 1]), sm7);
+                }
+            }
+        }
+    }
+
     double fm2 = 0.0, g = 0.0, gb = 0.0;
 #pragma unroll
     for (int k = 0; k < W; k++) { fm2 += part[0][k][lane]; g += part[1][k][lane]; gb += part[2][k][lane]; }
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(64 * W) void vlin_inside_diag(McBatch B, const VLin
 // ---------------------------------------------------------------------------------
 // outside (pull form) + posterior, diagonal d; last group: F5o~[d+1]
 template <int W, int BS, bool CUT>
-__global__ __launch_bounds__(64 * W) void vlin_outside_diag(McBatch B, const VLinModel* __restrict__ L, int d, int pin, int* __restrict__ bad)
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(6, 8))) void vlin_outside_diag(McBatch B, const VLinModel* __restrict__ L, int d, int pin, int* __restrict__ bad)
 {
     __shared__ double part[4][W][64];
     __shared__ double gbuf[W][2 * ((kMaxSingle / 2 + W) / W)][96];
@@ -460,38 +460,6 @@ __global__ __launch_bounds__(64 * W) void vlin_outside_diag(McBatch B, const VLi
     const int idx = 25 * (5 * s_i + s_ip1) + 5 * s_jp1 + s_j;
     const int idd = 25 * (5 * s_jp1 + (GAPOK(j + 1) ? s_jp2 : 0)) + 5 * s_i + (GAPOK(i - 1) ? s_im1 : 0);
     const int idx_raw = 25 * (5 * s_jp1 + s_jp2) + 5 * s_i + s_im1;
-    double e_txo = 0, e_tmc = 0, e_txi = 0, e_tsa = 0, e_tau = 1;
-    double o_fmso = 0, o_fm1o = 0, o_f5o = 0, o_f5i = 0, o_fm1o_up = 0, o_fc = 0, o_z = 1, sm7 = 0.0, o_x = 0.0;
-    if (w == 0 && valid) {
-        e_txo = L->TXO[idx]; e_tmc = L->TMC[idx];
-        e_txi = L->TXI[idx_raw]; e_tsa = L->TSA[idd]; e_tau = L->E_tau[type];
-        if (guard_m) {
-            if (j + 1 <= n - 1 && GAPOK(j) && GAPOK(j + 1)) o_fmso = tab[VL_FMSO * ts + (d + 1) * ld + i];
-            if (i - 1 >= 1 && GAPOK(i - 1) && GAPOK(i)) o_fm1o = tab[VL_FM1O * ts + (d + 1) * ld + i - 1];
-        }
-        o_f5o = f5o[j + 1]; o_f5i = f5i[i - 1]; o_z = f5i[n];
-        o_fc = tab[VL_FC * ts + at];
-        if (up_ok && GAPOK(i - 1) && GAPOK(j + 1)) o_fm1o_up = tab[VL_FM1O * ts + (d + 2) * ld + i - 1];
-        // stem of one of the exterior halves of the loop around the missing gap
-        if (CUT && i > cut) o_x = B.xpo[(size_t)sq * ld + j + 1] * B.xp[(size_t)sq * ld + i - 1];
-        if (CUT && j + 1 <= cut) o_x = B.xso[(size_t)sq * ld + i] * B.xs[(size_t)sq * ld + j + 2];
-        if (pairable) {
-            // the seven tabulated shapes: outer pair letters (io, jo+1) = (i-1-l1, j+2+l2), raw outside cell (io, jo)
-            const double* __restrict__ fco = tab + VL_FCO * ts;
-#pragma unroll
-            for (int k = 0; k < 7; k++) {
-                const int l1 = (k == 2 || k == 3 || k == 4) ? 1 : (k >= 5 ? 2 : 0);
-                const int l2 = (k == 1 || k == 3 || k == 5) ? 1 : ((k == 4 || k == 6) ? 2 : 0);
-                const int io = i - 1 - l1, jo = j + 1 + l2;
-                if (io >= 1 && jo <= n - 1 && l1 <= l1max && l2 <= l2max) {
-                    const int to = L->ptype[s[io] * 5 + s[jo + 1]];
-                    const double v = fco[(jo - io) * ld + io];
-                    sm7 = fma(v, small_w(L, l1, l2, to, type, s[io + 1], s[jo], s_im1, s_jp2), sm7);
-                }
-            }
-        }
-    }
-
     double accm = 0.0, acc1 = 0.0, accc = 0.0, accb = 0.0;
     if (guard_m) {
         constexpr int UO = 6;
@@ -590,6 +558,38 @@ __global__ __launch_bounds__(64 * W) void vlin_outside_diag(McBatch B, const VLi
     part[3][w][lane] = accb;
     __syncthreads();
     if (w != 0 || !valid) return;
+    double e_txo = 0, e_tmc = 0, e_txi = 0, e_tsa = 0, e_tau = 1;
+    double o_fmso = 0, o_fm1o = 0, o_f5o = 0, o_f5i = 0, o_fm1o_up = 0, o_fc = 0, o_z = 1, sm7 = 0.0, o_x = 0.0;
+    {   // epilogue operands: loaded after the term loops so that they do not occupy registers during them
+        e_txo = L->TXO[idx]; e_tmc = L->TMC[idx];
+        e_txi = L->TXI[idx_raw]; e_tsa = L->TSA[idd]; e_tau = L->E_tau[type];
+        if (guard_m) {
+            if (j + 1 <= n - 1 && GAPOK(j) && GAPOK(j + 1)) o_fmso = tab[VL_FMSO * ts + (d + 1) * ld + i];
+            if (i - 1 >= 1 && GAPOK(i - 1) && GAPOK(i)) o_fm1o = tab[VL_FM1O * ts + (d + 1) * ld + i - 1];
+        }
+        o_f5o = f5o[j + 1]; o_f5i = f5i[i - 1]; o_z = f5i[n];
+        o_fc = tab[VL_FC * ts + at];
+        if (up_ok && GAPOK(i - 1) && GAPOK(j + 1)) o_fm1o_up = tab[VL_FM1O * ts + (d + 2) * ld + i - 1];
+        // stem of one of the exterior halves of the loop around the missing gap
+        if (CUT && i > cut) o_x = B.xpo[(size_t)sq * ld + j + 1] * B.xp[(size_t)sq * ld + i - 1];
+        if (CUT && j + 1 <= cut) o_x = B.xso[(size_t)sq * ld + i] * B.xs[(size_t)sq * ld + j + 2];
+        if (pairable) {
+            // the seven tabulated shapes: outer pair letters (io, jo+1) = (i-1-l1, j+2+l2), raw outside cell (io, jo)
+            const double* __restrict__ fco = tab + VL_FCO * ts;
+#pragma unroll
+            for (int k = 0; k < 7; k++) {
+                const int l1 = (k == 2 || k == 3 || k == 4) ? 1 : (k >= 5 ? 2 : 0);
+                const int l2 = (k == 1 || k == 3 || k == 5) ? 1 : ((k == 4 || k == 6) ? 2 : 0);
+                const int io = i - 1 - l1, jo = j + 1 + l2;
+                if (io >= 1 && jo <= n - 1 && l1 <= l1max && l2 <= l2max) {
+                    const int to = L->ptype[s[io] * 5 + s[jo + 1]];
+                    const double v = fco[(jo - io) * ld + io];
+                    sm7 = fma(v, small_w(L, l1, l2, to, type, s[io + 1], s[jo], s_im1, s_jp2), sm7);
+                }
+            }
+        }
+    }
+
     double sm = 0.0, s1 = 0.0, g = 0.0, gb = 0.0;
 #pragma unroll
     for (int k = 0; k < W; k++) { sm += part[0][k][lane]; s1 += part[1][k][lane]; g += part[2][k][lane]; gb += part[3][k][lane]; }
