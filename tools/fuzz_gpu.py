@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Differential fuzzing on the GPU box: random inputs through the C ABI against the CPU oracles, both models, both
 arithmetic paths, ragged batches, cuts at every offset of the 64-cell groups / 16-letter blocks, random constraints.
-  python tools/fuzz_gpu.py [seconds] [seed]"""
+  python tools/fuzz_gpu.py [seconds] [seed] [length scale]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -11,6 +11,7 @@ from _oracle import Oracle, ViennaOracle, assert_prob_close
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+SCALE = int(sys.argv[3]) if len(sys.argv) > 3 else 1   # multiplies the length ranges (3: up to 540 letters, many block-product tiles)
 cf, vo = Oracle(), ViennaOracle()
 V = ractip_amd.hot.RH_MODEL_VIENNA_BL
 ctxs = {("cf", m): ractip_amd.Context(device=0) for m in (0, 1)}
@@ -40,7 +41,7 @@ while time.time() - t0 < budget:
     m = rng.randint(2)
     gc = rng.choice([0.3, 0.5, 0.7])
     if kind == 0:      # CONTRAfold ragged pair batch
-        pairs = [(rnd(rng.randint(1, 180), gc), rnd(rng.randint(1, 180), gc)) for _ in range(rng.randint(1, 5))]
+        pairs = [(rnd(rng.randint(1, 180 * SCALE), gc), rnd(rng.randint(1, 180 * SCALE), gc)) for _ in range(rng.randint(1, 5))]
         c = ctxs[("cf", m)]
         c.batch_upload(pairs); c.batch_compute()
         for p, (s1, s2) in enumerate(pairs):
@@ -51,7 +52,7 @@ while time.time() - t0 < budget:
             assert_prob_close(r["hp"], od["post"], what="cf hp %r %r" % (s1, s2))
             assert abs(r["logZ"][0] - o1["logZ"]) < 1e-8 and abs(r["logZ"][2] - od["logZ2"][0]) < 1e-8
     elif kind == 1:    # Vienna ragged pair batch, both hp sources
-        pairs = [(rnd(rng.randint(1, 150), gc), rnd(rng.randint(1, 150), gc)) for _ in range(rng.randint(1, 4))]
+        pairs = [(rnd(rng.randint(1, 150 * SCALE), gc), rnd(rng.randint(1, 150 * SCALE), gc)) for _ in range(rng.randint(1, 4))]
         co = bool(rng.randint(2))
         c = ctxs[("vi", m)]
         c.set_hybrid(co); c.set_max_w(int(rng.choice([1, 5, 15])))
@@ -65,14 +66,14 @@ while time.time() - t0 < budget:
             assert_prob_close(r["hp"], oh, what="vi hp co=%s %r %r" % (co, s1, s2))
         c.set_hybrid(False); c.set_max_w(15)
     elif kind == 2:    # two-molecule ensemble: the cut at every offset relative to groups and blocks
-        n1, n2 = rng.randint(1, 140), rng.randint(1, 140)
+        n1, n2 = rng.randint(1, 140 * SCALE), rng.randint(1, 140 * SCALE)
         s1, s2 = rnd(n1, gc), rnd(n2, gc)
         hp, z = ctxs[("vi", m)].cofold(s1, s2)
         o = vo.cofold(s1, s2)
         assert abs(z - o["logZ"]) < 1e-8 * max(1, abs(z)), (s1, s2)
         assert_prob_close(hp, o["hp"], what="cofold %r %r" % (s1, s2))
     elif kind == 3:    # constrained single fold
-        s = rnd(rng.randint(5, 120), gc)
+        s = rnd(rng.randint(5, 120 * SCALE), gc)
         cons = rand_constraint(s)
         o = vo.mccaskill(s, max_w=15, constraint=cons)
         bp, up, z = ctxs[("vi", m)].fold(s, constraint=cons)
