@@ -72,6 +72,18 @@ int main(int argc, char** argv)
             dump_hp(hp);
         } else if (mode == "rnaduplex") {
             VVF hp; en.rnaduplex(argv[2], argv[3], hp); dump_hp(hp);
+        } else if (mode == "solve_default") {   // solve_default MAX_W S1 S2 [S1 S2 ...]
+            const unsigned mw = (unsigned)std::atoi(argv[2]);
+            std::vector<std::pair<std::string, std::string>> pairs;
+            for (int k = 3; k + 1 < argc; k += 2) pairs.emplace_back(argv[k], argv[k + 1]);
+            for (const PairProbabilities& r : en.solve_probabilities_default(pairs, mw)) {
+                std::printf("pair %.17g %.17g %.17g\n", r.logZ1, r.logZ2, r.logZd);
+                std::printf("bp %zu\n", r.bp1.size());
+                for (float v : r.bp1) std::printf("%.9g\n", v);
+                std::printf("up %zu\n", r.up2.size() * mw);
+                for (const VF& row : r.up2) for (float v : row) std::printf("%.9g\n", v);
+                dump_hp(r.hp);
+            }
         } else if (mode == "solve") {
             std::vector<std::pair<std::string, std::string>> pairs;
             for (int k = 2; k + 1 < argc; k += 2) pairs.emplace_back(argv[k], argv[k + 1]);

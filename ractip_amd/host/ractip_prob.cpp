@@ -179,6 +179,23 @@ void ProbabilityEngine::rnaduplex(const std::string& seq1, const std::string& se
 std::vector<PairProbabilities> ProbabilityEngine::solve_probabilities(
     const std::vector<std::pair<std::string, std::string>>& pairs) const
 {
+    return batch(ctx_, pairs, 1, false);
+}
+
+std::vector<PairProbabilities> ProbabilityEngine::solve_probabilities_default(
+    const std::vector<std::pair<std::string, std::string>>& pairs, uint max_w, bool duplex) const
+{
+    rh_ctx* v = vienna();
+    if (rh_set_max_w(v, (int)std::max(1u, max_w)) != RH_OK || rh_set_hybrid(v, duplex ? RH_HYBRID_DUPLEX : RH_HYBRID_COFOLD) != RH_OK)
+        throw std::logic_error(std::string("ractip_amd::solve_probabilities_default: ") + rh_last_error(v));
+    std::vector<PairProbabilities> out = batch(v, pairs, std::max(1u, max_w), !duplex);
+    rh_set_hybrid(v, RH_HYBRID_DUPLEX);
+    return out;
+}
+
+std::vector<PairProbabilities> ProbabilityEngine::batch(rh_ctx* ctx, const std::vector<std::pair<std::string, std::string>>& pairs,
+                                                        uint max_w, bool threshold_hp) const
+{
     const int np = (int)pairs.size();
     std::vector<PairProbabilities> out(np);
     if (np == 0) return out;
@@ -188,14 +205,15 @@ std::vector<PairProbabilities> ProbabilityEngine::solve_probabilities(
         a[p] = pairs[p].first.c_str(); b[p] = pairs[p].second.c_str();
         na[p] = (int)pairs[p].first.size(); nb[p] = (int)pairs[p].second.size();
     }
-    if (rh_batch_upload(ctx_, np, a.data(), na.data(), b.data(), nb.data()) != RH_OK) raise("solve_probabilities");
-    if (rh_batch_compute(ctx_) != RH_OK) raise("solve_probabilities");
+    auto raise_ctx = [&](const char* where) { throw std::logic_error(std::string("ractip_amd::") + where + ": " + rh_last_error(ctx)); };
+    if (rh_batch_upload(ctx, np, a.data(), na.data(), b.data(), nb.data()) != RH_OK) raise_ctx("solve_probabilities");
+    if (rh_batch_compute(ctx) != RH_OK) raise_ctx("solve_probabilities");
     // three device-to-host copies for the whole batch, then unpack the padded layout on the host
     size_t tri_stride = 0, hp_stride = 0;
     int up_ld = 0, hp_ld = 0;
-    if (rh_batch_layout(ctx_, &tri_stride, &up_ld, &hp_stride, &hp_ld) != RH_OK) raise("solve_probabilities");
+    if (rh_batch_layout(ctx, &tri_stride, &up_ld, &hp_stride, &hp_ld) != RH_OK) raise_ctx("solve_probabilities");
     std::vector<double> bp((size_t)2 * np * tri_stride), up((size_t)2 * np * up_ld), hp((size_t)np * hp_stride), z((size_t)3 * np);
-    if (rh_batch_results_all(ctx_, bp.data(), up.data(), hp.data(), z.data()) != RH_OK) raise("solve_probabilities");
+    if (rh_batch_results_all(ctx, bp.data(), up.data(), hp.data(), z.data()) != RH_OK) raise_ctx("solve_probabilities");
     for (int p = 0; p < np; ++p) {
         const uint n1 = na[p], n2 = nb[p];
         PairProbabilities& r = out[p];
@@ -205,14 +223,19 @@ std::vector<PairProbabilities> ProbabilityEngine::solve_probabilities(
         r.bp2.resize((size_t)(n2 + 1) * (n2 + 2) / 2);
         std::transform(b1, b1 + r.bp1.size(), r.bp1.begin(), [](double v) { return (float)v; });
         std::transform(b2, b2 + r.bp2.size(), r.bp2.begin(), [](double v) { return (float)v; });
-        r.up1.assign(n1, VF(1)); r.up2.assign(n2, VF(1));
-        for (uint i = 0; i < n1; ++i) r.up1[i][0] = (float)up[(size_t)(2 * p) * up_ld + i];
-        for (uint i = 0; i < n2; ++i) r.up2[i][0] = (float)up[(size_t)(2 * p + 1) * up_ld + i];
+        r.up1.assign(n1, VF(max_w)); r.up2.assign(n2, VF(max_w));
+        for (uint i = 0; i < n1; ++i)
+            for (uint w = 0; w < max_w; ++w) r.up1[i][w] = (float)up[(size_t)(2 * p) * up_ld + (size_t)i * max_w + w];
+        for (uint i = 0; i < n2; ++i)
+            for (uint w = 0; w < max_w; ++w) r.up2[i][w] = (float)up[(size_t)(2 * p + 1) * up_ld + (size_t)i * max_w + w];
         r.offset1 = make_offsets(n1); r.offset2 = make_offsets(n2);
         r.hp.assign(n1 + 1, VF(n2 + 1));
         const double* h = hp.data() + (size_t)p * hp_stride;
         for (uint i = 0; i <= n1; ++i)
-            for (uint j = 0; j <= n2; ++j) r.hp[i][j] = (float)h[(size_t)i * hp_ld + j];
+            for (uint j = 0; j <= n2; ++j) {
+                const float v = (float)h[(size_t)i * hp_ld + j];
+                r.hp[i][j] = (!threshold_hp || v > th_hy_) ? v : 0.0f;   // plist entries with p > th_hy (:451-454)
+            }
         r.logZ1 = z[3 * p]; r.logZ2 = z[3 * p + 1]; r.logZd = z[3 * p + 2];
     }
     return out;

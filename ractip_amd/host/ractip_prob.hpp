@@ -64,12 +64,18 @@ public:
 
     // batched form for the z-score loop (:1638-1657): all DPs of all pairs in one device pass
     std::vector<PairProbabilities> solve_probabilities(const std::vector<std::pair<std::string, std::string>>& pairs) const;
+    // the same for the DEFAULT path (:544-548): rnafold(fa, bp, offset, up, max(1, max_w)) x2 + the co_pf_fold branch of
+    // rnaduplex (hp entries with p > th_hy, :451-454) for every pair, Vienna-BL model; duplex = true: the --duplex branch
+    std::vector<PairProbabilities> solve_probabilities_default(const std::vector<std::pair<std::string, std::string>>& pairs,
+                                                               uint max_w = 15, bool duplex = false) const;
 
     rh_ctx* raw() const { return ctx_; }
 
 private:
     [[noreturn]] void raise(const char* where) const;
     rh_ctx* vienna() const;
+    std::vector<PairProbabilities> batch(rh_ctx* ctx, const std::vector<std::pair<std::string, std::string>>& pairs, uint max_w,
+                                         bool threshold_hp) const;
     rh_ctx* ctx_;
     mutable rh_ctx* vctx_ = nullptr;
     int device_;

@@ -142,3 +142,27 @@ def test_default_cli_path_members_rnafold_and_cofold(cli, golden):
     ref[ref <= np.float32(0.1)] = 0            # p > th_hy_, src/ractip.cpp:452
     near = np.abs(vo.cofold(s1, s2)["hp"] - 0.1) < 1e-6   # entries within rounding of the threshold may fall either side
     assert np.all((np.abs(hp.astype(np.float32) - ref) <= 2e-6 * np.maximum(ref, 1e-6) + 1e-12) | near)
+
+
+def test_default_path_batch(cli, golden):
+    """solve_probabilities_default: everything RactIP::solve needs on its default path for several pairs in one device pass."""
+    from _oracle import ViennaOracle
+    vo = ViennaOracle()
+    pairs = [(str(golden["mc/DIS/seq"]), str(golden["mc/DIS/seq"])), (str(golden["mc/Tar/seq"]), str(golden["mc/Tarstar/seq"]))]
+    lines = run(cli, "solve_default", "7", *[x for p in pairs for x in p])
+    pos = 0
+    for s1, s2 in pairs:
+        hdr = lines[pos].split()
+        assert hdr[0] == "pair"
+        z = [float(v) for v in hdr[1:]]
+        bp, pos = take(lines, pos + 1, "bp")
+        up, pos = take(lines, pos, "up")
+        hp, pos = take(lines, pos, "hp")
+        o1, o2, oc = vo.mccaskill(s1, max_w=7), vo.mccaskill(s2, max_w=7), vo.cofold(s1, s2)
+        assert abs(z[0] - o1["logZ"]) < 1e-8 and abs(z[2] - oc["logZ"]) < 1e-8
+        close32(bp, o1["post"], "default bp1")
+        close32(up.reshape(len(s2), 7), o2["up"], "default up2")
+        ref = oc["hp"].astype(np.float32)
+        ref[ref <= np.float32(0.1)] = 0
+        near = np.abs(oc["hp"] - 0.1) < 1e-6
+        assert np.all((np.abs(hp.astype(np.float32) - ref) <= 2e-6 * np.maximum(ref, 1e-6) + 1e-12) | near)
