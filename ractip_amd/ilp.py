@@ -286,3 +286,66 @@ def solve(s1, s2, bp1, bp2, hp, up1=None, up2=None, opt=None):
                         assert r[i] == "." and r[j] == "."
                         r[i], r[j] = "(", ")"
     return "".join(r1), "".join(r2), ea
+
+
+def solve_ss(s, bp, opt=None, usable=None):
+    """RactIP::solve_ss (src/ractip.cpp:1355-1465): the single-sequence programme of the z-score loop -- pairs with
+    bp > th_ss, each letter in at most one pair, no isolated pairs; NO crossing constraint (as in the reference, whose
+    decoding then writes '(' ')' per selected pair).  Returns (structure, objective)."""
+    opt = opt or Options()
+    f32 = np.float32
+    n = len(s)
+    bp = np.asarray(bp, f32)
+    th_ss = f32(opt.th_ss)
+    u = usable if usable is not None else [True] * n
+    ip = IPModel()
+    x = -np.ones((n, n), dtype=np.int64)
+    for j in range(1, n):
+        if not u[j]:
+            continue
+        for i in range(j - 1, -1, -1):
+            if not u[i]:
+                continue
+            p = bp[_tri(n, i + 1) + (j + 1)]
+            if p > th_ss:
+                x[i][j] = x[j][i] = ip.make_variable(f32(p - th_ss))
+    for i in range(n):
+        r = ip.make_constraint(UP, 0, 1)
+        for j in range(n):
+            if x[i][j] >= 0:
+                ip.add_constraint(r, x[i][j], 1)
+    if opt.stacking_constraints:
+        for i in range(n):
+            r = ip.make_constraint(LO, 0, 0)
+            for j in range(i):
+                if x[j][i] >= 0:
+                    ip.add_constraint(r, x[j][i], -1)
+            if i > 0:
+                for j in range(i - 1):
+                    if x[j][i - 1] >= 0:
+                        ip.add_constraint(r, x[j][i - 1], 1)
+            if i + 1 < n:
+                for j in range(i + 1):
+                    if x[j][i + 1] >= 0:
+                        ip.add_constraint(r, x[j][i + 1], 1)
+        for i in range(n):
+            r = ip.make_constraint(LO, 0, 0)
+            for j in range(i + 1, n):
+                if x[i][j] >= 0:
+                    ip.add_constraint(r, x[i][j], -1)
+            if i > 0:
+                for j in range(i, n):
+                    if x[i - 1][j] >= 0:
+                        ip.add_constraint(r, x[i - 1][j], 1)
+            if i + 1 < n:
+                for j in range(i + 2, n):
+                    if x[i + 1][j] >= 0:
+                        ip.add_constraint(r, x[i + 1][j], 1)
+    ea = ip.solve()
+    r = ["."] * n
+    for i in range(n):
+        for j in range(i + 1, n):
+            if x[i][j] >= 0 and ip.get_value(x[i][j]) > 0.5:
+                r[i], r[j] = "(", ")"
+    return "".join(r), ea
+

@@ -84,6 +84,47 @@ def test_rip_tables_round_trip_and_give_the_same_structure(golden, tmp_path):
     assert x < y and abs(bp2[x * (2 * (n2 + 1) - x - 1) // 2 + y] - p) < 1e-15
 
 
+def _oracle_matrices(pairs):
+    from _oracle import ViennaOracle
+    vo = ViennaOracle()
+    out = []
+    for a, b in pairs:
+        fa, fb, co = vo.mccaskill(a, max_w=15), vo.mccaskill(b, max_w=15), vo.cofold(a, b)
+        out.append(dict(bp1=fa["post"], bp2=fb["post"], up1=fa["up"], up2=fb["up"], hp=co["hp"]))
+    return out
+
+
+def test_zscore_loop_on_cpu_matrices(golden):
+    """The z-score loop (src/ractip.cpp:1624-1670) end to end over the CPU restatement's matrices: energies are finite,
+    the shuffles keep the dinucleotide content, the statistic is reproducible."""
+    from ractip_amd import pipeline
+    s1, s2 = str(golden["mc/Tar/seq"]), str(golden["mc/Tarstar/seq"])
+    a = pipeline.zscore(s1, s2, mode=12, num_shuffling=4, seed=1, matrices=_oracle_matrices)
+    b = pipeline.zscore(s1, s2, mode=12, num_shuffling=4, seed=1, matrices=_oracle_matrices)
+    assert a == b and a["r1"].count("[") == a["r2"].count("]") > 0
+    assert all(np.isfinite(a[k]) for k in ("e1", "e2", "e3", "e1s", "e2s")) and a["e3"] < 0
+    assert np.isfinite(a["zscore"]) and a["zscore"] < 0      # the native Tar/Tar* kissing complex beats its shuffles
+
+
+def test_zscore_loop_is_finite_on_oxys_fhla(golden):
+    """BASELINE config 5's pair: shuffles whose single-sequence programme yields crossing pairs (bracket strings that match
+    unpairable letters) must still give finite energies, as they do under ViennaRNA's evaluator."""
+    from ractip_amd import pipeline
+    import os
+    fa = [l.strip() for l in open(os.path.join(os.path.dirname(pipeline.__file__), "data", "config5_OxyS_fhlA.fa")) if not l.startswith(">")]
+    z = pipeline.zscore(fa[0], fa[1], mode=12, num_shuffling=3, seed=1, matrices=_oracle_matrices)
+    assert all(np.isfinite(z[k]) for k in ("e1", "e2", "e3", "e1s", "e2s", "zscore", "zscore_s")), z
+
+
+@pytest.mark.gpu
+def test_zscore_loop_gpu_equals_cpu_matrices(hotlib, golden):
+    from ractip_amd import pipeline
+    s1, s2 = str(golden["mc/DIS/seq"]), str(golden["mc/Tar/seq"])
+    g = pipeline.zscore(s1, s2, mode=12, num_shuffling=5, seed=1)
+    c = pipeline.zscore(s1, s2, mode=12, num_shuffling=5, seed=1, matrices=_oracle_matrices)
+    assert g == c
+
+
 @pytest.mark.gpu
 def test_identical_joint_structures_on_all_bundled_pairs(hotlib, golden):
     import ractip_amd
