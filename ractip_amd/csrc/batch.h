@@ -60,7 +60,13 @@ struct McBatch {
     size_t tab_stride;   // doubles per table  (ld*ld)
     size_t seq_stride;   // doubles per sequence (T_COUNT*ld*ld)
     size_t tri_stride;   // doubles per bp table
+    // operand tiles of the block products (mccaskill_far.hip): kPkCopies re-laid copies of the 16x16 tiles (P <= Q) of
+    // FM1 / FM / FM2o, each tile 256 doubles in MFMA fragment order; [NS][kPkCopies][pk_stride]
+    double* pk;
+    size_t pk_stride;    // doubles per copy = nb*(nb+1)/2 * 256
+    int nb;              // 16-blocks per axis = (nmax-1)/16 + 1
 };
+constexpr int kPkCopies = 6;
 
 enum DxTable {
     D_IN = 0,  // inside[i][j]

@@ -19,6 +19,10 @@
 #include "batch.h"
 #include "lin_model.h"
 
+#ifndef RH_WPE_DX
+#define RH_WPE_DX
+#endif
+
 namespace rh {
 
 namespace {
@@ -29,11 +33,15 @@ __device__ __forceinline__ bool pairs(int a, int b) { return (kPairMaskD >> (a *
 template <int T>
 __device__ __forceinline__ double win_sum(const double* seg)
 {
+    // volatile: keeps every tap a plain ds_read_b64 (2 LDS cycles per wavefront, 256 B/clk/CU); merged into
+    // ds_read2_b64 by the compiler, two taps cost 8 cycles (128 B/clk/CU) on CDNA4
+    typedef const volatile __attribute__((address_space(3))) double* lds_vptr;
+    lds_vptr vs = (lds_vptr)seg;
     double s0 = 0.0, s1 = 0.0;
 #pragma unroll
     for (int k = 0; k <= T; k += 2) {
-        s0 += seg[k];
-        if (k + 1 <= T) s1 += seg[k + 1];
+        s0 += vs[k];
+        if (k + 1 <= T) s1 += vs[k + 1];
     }
     return s0 + s1;
 }
@@ -54,7 +62,7 @@ __device__ __forceinline__ double win_sum_any(int t, const double* seg)
 // {Smax-2*step-1, Smax-2*step} (Smax = L1+L2) -- blockIdx.z selects inside/outside,
 // blockIdx.x = (which of the two diagonals) * groups + (64-cell group).
 template <int W>
-__global__ __launch_bounds__(64 * W) void dxl_sweep(DxLinBatch B, const DxLinModel* __restrict__ L, int step, int groups)
+__global__ __launch_bounds__(64 * W) RH_WPE_DX void dxl_sweep(DxLinBatch B, const DxLinModel* __restrict__ L, int step, int groups)
 {
     __shared__ double buf[W][(26 + W - 1) / W][96];
     __shared__ double part[W][64];
@@ -123,14 +131,12 @@ __global__ __launch_bounds__(64 * W) void dxl_sweep(DxLinBatch B, const DxLinMod
     const double* __restrict__ src = tab + (outside ? DL_OUTX : DL_INX) * ts + kDxPad;
     double acc = 0.0;
     constexpr int NSEG = (26 + W - 1) / W;   // windows t = 3..28 dealt round-robin to the W wavefronts
-    int tseg[NSEG];
     // pass 1: stage every segment this wavefront sums (all row loads in flight at once)
 #pragma unroll
     for (int q = 0; q < NSEG; q++) {
         const int t = 3 + w + q * W;
         const int row = outside ? sd + 2 + t : sd - 2 - t;
         const bool on = t <= 28 && row >= 2 && row <= smax;   // wave-uniform
-        tseg[q] = on ? t : -1;
         if (on) {
             // segment start: inside a0-1-t (window = [a-1-t, a-1]); outside a0+1 (window = [a+1, a+1+t])
             const int c0 = outside ? a0 + 1 : a0 - 1 - t;
@@ -140,9 +146,14 @@ __global__ __launch_bounds__(64 * W) void dxl_sweep(DxLinBatch B, const DxLinMod
         }
     }
     // pass 2: the window sums
-#pragma unroll
-    for (int q = 0; q < NSEG; q++)
-        if (tseg[q] >= 0) acc = fma(L->lam_pow[tseg[q] + 2], win_sum_any(tseg[q], &buf[w][q][lane]), acc);
+    // rolled: ONE copy of the 26-way window switch (unrolled, the NSEG copies made the kernel larger than the
+    // instruction cache two CUs share)
+#pragma unroll 1
+    for (int q = 0; q < NSEG; q++) {
+        const int t = 3 + w + q * W;
+        const int row = outside ? sd + 2 + t : sd - 2 - t;
+        if (t <= 28 && row >= 2 && row <= smax) acc = fma(L->lam_pow[t + 2], win_sum_any(t, &buf[w][q][lane]), acc);
+    }
     part[w][lane] = acc;
     __syncthreads();
     if (w != 0) return;

@@ -249,6 +249,106 @@ __global__ __launch_bounds__(256) void lin_far_outside_mfma(McBatch B, int D)
     }
 }
 
+// ---------------------------------------------------------------------------------
+// Packed operand tiles.  Gathering a 16x16 chunk out of the diagonal-major tables costs 16 masked loads per wavefront
+// with their full latency, and every chunk is gathered again by each of the ~n/32 products that use it.  Instead each
+// tile is re-laid ONCE, when its block diagonal completes, into the register order of the MFMA operands:
+//   layout LA: element (u,v) at (u + 16*(v%4))*4 + v/4  -> lane l reads 4 consecutive doubles = A[l&15][4s + (l>>4)], s = 0..3
+//   layout LB: element (u,v) at (v + 16*(u%4))*4 + u/4  -> lane l reads B[4s + (l>>4)][l&15]
+// (a transposed operand is the other layout of the same tile), so a product step is two 32-byte loads per lane from two
+// contiguous 2 KB tiles and four v_mfma_f64_16x16x4_f64, with no LDS and every load of the K loop in flight at once.
+enum PkCopy { PK_FM1_A = 0, PK_FM1_B, PK_FM_A, PK_FM_B, PK_FM2O_A, PK_FM2O_B };
+__device__ __forceinline__ size_t pk_tile(int nb, int P, int Q) { return ((size_t)P * nb - (size_t)P * (P - 1) / 2 + (Q - P)) * 256; }
+
+// grid = (tiles P of block diagonal Dblk, sequences, tables); outside = 0: FM1 and FM (blockIdx.z), outside = 1: FM2o
+__global__ __launch_bounds__(256) void lin_pack_tiles(McBatch B, int Dblk, int outside)
+{
+    __shared__ double T[16][17];
+    const int sq = blockIdx.y;
+    const int n = B.n[sq];
+    const int P = blockIdx.x, Q = P + Dblk;
+    if (Q >= B.nb || Q * 16 > n - 1) return;   // no interior column: never read
+    const int slot = outside ? LF_FM2O : (blockIdx.z == 0 ? LF_FM1 : LF_FM);
+    const int copy = outside ? PK_FM2O_A : (blockIdx.z == 0 ? PK_FM1_A : PK_FM_A);
+    const double* __restrict__ src = B.tab + (size_t)sq * B.seq_stride + (size_t)slot * B.tab_stride;
+    {   // walk the chunk along its diagonals v-u = const (contiguous runs of the table)
+        const int u = threadIdx.x & 15;
+#pragma unroll
+        for (int pass = 0; pass < 2; pass++) {
+            const int v = u + (threadIdx.x >> 4) + 16 * pass - 15;
+            if (v >= 0 && v < 16) T[u][v] = cellv(src, B.ld, n, P * 16 + u, Q * 16 + v);
+        }
+    }
+    __syncthreads();
+    double* __restrict__ dst = B.pk + ((size_t)sq * kPkCopies + copy) * B.pk_stride + pk_tile(B.nb, P, Q);
+    const int s = threadIdx.x & 3, l = threadIdx.x >> 2, r = l & 15, q = l >> 4;
+    dst[threadIdx.x] = T[r][4 * s + q];                  // LA
+    dst[B.pk_stride + threadIdx.x] = T[4 * s + q][r];    // LB (the next copy)
+}
+
+__device__ __forceinline__ d4 mfma4(d4 a, d4 b, d4 acc)
+{
+#pragma unroll
+    for (int s = 0; s < 4; s++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s], acc, 0, 0, 0);
+    return acc;
+}
+
+// acc += sum over K = k_lo + w, k_lo + w + 4, ... <= k_hi of frag(pa + ta(K)) x frag(pb + tb(K)); two steps in flight
+template <class TA, class TB>
+__device__ __forceinline__ d4 pk_loop(const double* __restrict__ pa, const double* __restrict__ pb, int k_lo, int k_hi, TA ta, TB tb)
+{
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+    int K = k_lo + w;
+    for (; K + 4 <= k_hi; K += 8) {
+        const d4 a0 = *(const d4*)(pa + ta(K) + lane * 4), b0 = *(const d4*)(pb + tb(K) + lane * 4);
+        const d4 a1 = *(const d4*)(pa + ta(K + 4) + lane * 4), b1 = *(const d4*)(pb + tb(K + 4) + lane * 4);
+        acc = mfma4(a0, b0, acc);
+        acc = mfma4(a1, b1, acc);
+    }
+    if (K <= k_hi) {
+        const d4 a0 = *(const d4*)(pa + ta(K) + lane * 4), b0 = *(const d4*)(pb + tb(K) + lane * 4);
+        acc = mfma4(a0, b0, acc);
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(256) void lin_far_inside_pk(McBatch B, int D)
+{
+    __shared__ double red[4][256];
+    const int sq = blockIdx.y;
+    const int n = B.n[sq];
+    const int I = blockIdx.x, J = I + D;
+    if (J * 16 > n - 1) return;
+    const int nb = B.nb;
+    const double* __restrict__ pk = B.pk + (size_t)sq * kPkCopies * B.pk_stride;
+    // FM2F(I,J) = sum_K FM1(I,K) x FM(K,J)
+    const d4 acc = pk_loop(pk + PK_FM1_A * B.pk_stride, pk + PK_FM_B * B.pk_stride, I + 2, J - 2,
+                           [=](int K) { return pk_tile(nb, I, K); }, [=](int K) { return pk_tile(nb, K, J); });
+    reduce_store(red, acc, B.tab + (size_t)sq * B.seq_stride + (size_t)LF_FM2F * B.tab_stride, B.ld, n, I * 16, J * 16);
+}
+
+__global__ __launch_bounds__(256) void lin_far_outside_pk(McBatch B, int D)
+{
+    __shared__ double red[4][256];
+    const int sq = blockIdx.y;
+    const int n = B.n[sq];
+    const int I = blockIdx.x, J = I + D;
+    if (J * 16 > n - 1) return;
+    const int nb = B.nb;
+    const double* __restrict__ pk = B.pk + (size_t)sq * kPkCopies * B.pk_stride;
+    double* __restrict__ tab = B.tab + (size_t)sq * B.seq_stride;
+    if (blockIdx.z == 0) {   // FMOF(I,J) = sum_{K<=I-2} FM1(K,I)^T x FM2o(K,J)
+        const d4 acc = pk_loop(pk + PK_FM1_B * B.pk_stride, pk + PK_FM2O_B * B.pk_stride, 0, I - 2,
+                               [=](int K) { return pk_tile(nb, K, I); }, [=](int K) { return pk_tile(nb, K, J); });
+        reduce_store(red, acc, tab + (size_t)LF_FMOF * B.tab_stride, B.ld, n, I * 16, J * 16);
+    } else {                 // FM1OF(I,J) = sum_{K>=J+2} FM2o(I,K) x FM(J,K)^T
+        const d4 acc = pk_loop(pk + PK_FM2O_A * B.pk_stride, pk + PK_FM_A * B.pk_stride, J + 2, (n - 1) / 16,
+                               [=](int K) { return pk_tile(nb, I, K); }, [=](int K) { return pk_tile(nb, J, K); });
+        reduce_store(red, acc, tab + (size_t)LF_FM1OF * B.tab_stride, B.ld, n, I * 16, J * 16);
+    }
+}
+
 template __global__ void lin_far_inside<16>(McBatch, int);
 template __global__ void lin_far_inside<32>(McBatch, int);
 template __global__ void lin_far_outside<16>(McBatch, int);

@@ -20,6 +20,13 @@
 #include "batch.h"
 #include "lin_model.h"
 
+#ifndef RH_WPE_IN
+#define RH_WPE_IN
+#endif
+#ifndef RH_WPE_OUT
+#define RH_WPE_OUT
+#endif
+
 namespace rh {
 
 namespace {
@@ -112,7 +119,7 @@ __global__ void lin_init(McBatch B, int* __restrict__ bad)
 // BS > 0: the k-terms that lie in complete blocks (I+2 .. J-2) come from FM2F (mccaskill_far.hip); only the
 // <= 4*BS near terms are streamed here.  BS = 0: the whole sum is streamed.
 template <int W, int BS>
-__global__ __launch_bounds__(64 * W) void lin_inside_diag(McBatch B, const LinModel* __restrict__ L, int d, double lam_d, int pin)
+__global__ __launch_bounds__(64 * W) RH_WPE_IN void lin_inside_diag(McBatch B, const LinModel* __restrict__ L, int d, double lam_d, int pin)
 {
     __shared__ double part[2][W][64];
     __shared__ double gbuf[W][2 * ((kMaxSingle / 2 + W) / W)][96];
@@ -200,6 +207,9 @@ __global__ __launch_bounds__(64 * W) void lin_inside_diag(McBatch B, const LinMo
 #pragma unroll
         for (int part_i = 0; part_i < 2; part_i++) {
             const int lo = part_i ? lo1 : lo0, hi = part_i ? hi1 : hi0;
+#ifdef RH_EXP_NOFM2
+            if (d < 0)
+#endif
             for (int m = lo + w; m <= hi; m += UF * W) {
                 // branch-free: every load is issued (a lane or term that is out of range reads a clamped, valid address)
                 // so that all 2*UF loads are in flight together; the product is masked afterwards
@@ -208,7 +218,11 @@ __global__ __launch_bounds__(64 * W) void lin_inside_diag(McBatch B, const LinMo
                 for (int u = 0; u < UF; u++) {
                     const int mm = m + u * W, mc = mm <= hi ? mm : hi;
                     a[u] = fm1c[mc * ld];
+#ifdef RH_EXP_HALFFM2
+                    b[u] = 1.0;
+#else
                     b[u] = fmc[(d - mc) * ld + mc];
+#endif
                 }
 #pragma unroll
                 for (int u = 0; u < UF; u++) {
@@ -226,7 +240,11 @@ __global__ __launch_bounds__(64 * W) void lin_inside_diag(McBatch B, const LinMo
     // once and each lane runs a (t+1)-tap filter over it; shape weights are wave-uniform (scalar loads).
     // t and 30-t go to the same wavefront so that every wavefront filters ~62 taps.
     double accc = 0.0;
+#ifdef RH_EXP_NOFILT
+    if (d < 0) {
+#else
     if (d >= 2) {
+#endif
         const int tmax = d - 2 < kMaxSingle ? d - 2 : kMaxSingle;
         const int i0 = 1 + slot * 64;
         const double* __restrict__ fcx = tab + L_FCX * ts;
@@ -234,7 +252,6 @@ __global__ __launch_bounds__(64 * W) void lin_inside_diag(McBatch B, const LinMo
         // back (clamped addresses, no branches -- a branch per load makes the compiler wait for each load in turn), then
         // written to LDS
         constexpr int NSEG = 2 * ((kMaxSingle / 2 + W) / W);     // <= 4 for W = 8
-        int tseg[NSEG];
         double r0[NSEG], r1[NSEG];
         const int col0 = i0 + 1;                                  // lane k of a segment = column col0+k of row d-2-t
         const int c0 = col0 + lane < ld ? col0 + lane : ld - 1, c1 = col0 + 64 + (lane & 31) < ld ? col0 + 64 + (lane & 31) : ld - 1;
@@ -243,7 +260,6 @@ __global__ __launch_bounds__(64 * W) void lin_inside_diag(McBatch B, const LinMo
             const int g = w + (q >> 1) * W;
             const int t = (q & 1) ? kMaxSingle - g : g;
             const bool on = g <= kMaxSingle / 2 && !((q & 1) && t == g) && t <= tmax;   // wave-uniform
-            tseg[q] = on ? t : -1;
             const double* __restrict__ row = fcx + (on ? d - 2 - t : 0) * ld;
             r0[q] = row[c0];
             r1[q] = row[c1];
@@ -254,9 +270,15 @@ __global__ __launch_bounds__(64 * W) void lin_inside_diag(McBatch B, const LinMo
             if (lane < 32) gbuf[w][q][64 + lane] = col0 + 64 + lane < ld ? r1[q] : 0.0;
         }
         // pass 2: the filters
-#pragma unroll
-        for (int q = 0; q < NSEG; q++)
-            if (tseg[q] >= 0) accc += filt_fwd_any(tseg[q], L->shape_w + tseg[q] * (tseg[q] + 1) / 2, &gbuf[w][q][lane]);
+        // rolled: ONE copy of the 31-way filter switch (unrolled, the NSEG copies made the kernel larger than the
+        // instruction cache two CUs share)
+#pragma unroll 1
+        for (int q = 0; q < NSEG; q++) {
+            const int g = w + (q >> 1) * W;
+            const int t = (q & 1) ? kMaxSingle - g : g;
+            const bool on = g <= kMaxSingle / 2 && !((q & 1) && t == g) && t <= tmax;
+            if (on) accc += filt_fwd_any(t, L->shape_w + t * (t + 1) / 2, &gbuf[w][q][lane]);
+        }
         if (!pairable) accc = 0.0;
     }
 
@@ -290,7 +312,7 @@ __global__ __launch_bounds__(64 * W) void lin_inside_diag(McBatch B, const LinMo
 // ---------------------------------------------------------------------------------
 // outside (pull form) + posterior, diagonal d; last group: F5o~[d+1].
 template <int W, int BS>
-__global__ __launch_bounds__(64 * W) void lin_outside_diag(McBatch B, const LinModel* __restrict__ L, int d, int pin, int* __restrict__ bad)
+__global__ __launch_bounds__(64 * W) RH_WPE_OUT void lin_outside_diag(McBatch B, const LinModel* __restrict__ L, int d, int pin, int* __restrict__ bad)
 {
     __shared__ double part[3][W][64];
     __shared__ double gbuf[W][2 * ((kMaxSingle / 2 + W) / W)][96];
@@ -422,13 +444,11 @@ __global__ __launch_bounds__(64 * W) void lin_outside_diag(McBatch B, const LinM
             const int tmax = room < kMaxSingle ? room : kMaxSingle;
             const double* __restrict__ fcox = tab + L_FCOX * ts;
             constexpr int NSEG = 2 * ((kMaxSingle / 2 + W) / W);
-            int tseg[NSEG];
 #pragma unroll
             for (int q = 0; q < NSEG; q++) {
                 const int g = w + (q >> 1) * W;
                 const int t = (q & 1) ? kMaxSingle - g : g;
                 const bool on = g <= kMaxSingle / 2 && !((q & 1) && t == g) && t <= tmax;   // wave-uniform
-                tseg[q] = on ? t : -1;
                 if (on) {
                     const int col0 = i0 - 1 - t;                  // segment column of lane k: col0+k; window of cell i: [i-1-t, i-1]
                     const double* __restrict__ row = fcox + (d + 2 + t) * ld;
@@ -439,9 +459,13 @@ __global__ __launch_bounds__(64 * W) void lin_outside_diag(McBatch B, const LinM
                     if (lane < 32) gbuf[w][q][64 + lane] = (c2 >= 1 && c2 <= cmax) ? row[c2] : 0.0;
                 }
             }
-#pragma unroll
-            for (int q = 0; q < NSEG; q++)
-                if (tseg[q] >= 0) accc += filt_rev_any(tseg[q], L->shape_w + tseg[q] * (tseg[q] + 1) / 2, &gbuf[w][q][lane]);
+#pragma unroll 1
+            for (int q = 0; q < NSEG; q++) {   // rolled: one copy of the filter switch (see the inside kernel)
+                const int g = w + (q >> 1) * W;
+                const int t = (q & 1) ? kMaxSingle - g : g;
+                const bool on = g <= kMaxSingle / 2 && !((q & 1) && t == g) && t <= tmax;
+                if (on) accc += filt_rev_any(t, L->shape_w + t * (t + 1) / 2, &gbuf[w][q][lane]);
+            }
             if (!pairable) accc = 0.0;
         }
     }

@@ -38,6 +38,9 @@ template <int BS> __global__ void lin_far_inside(McBatch B, int D);
 template <int BS> __global__ void lin_far_outside(McBatch B, int D);
 __global__ void lin_far_inside_mfma(McBatch B, int D);
 __global__ void lin_far_outside_mfma(McBatch B, int D);
+__global__ void lin_pack_tiles(McBatch B, int Dblk, int outside);
+__global__ void lin_far_inside_pk(McBatch B, int D);
+__global__ void lin_far_outside_pk(McBatch B, int D);
 __global__ void lin_finish(McBatch B, const LinModel* __restrict__ L, double* __restrict__ logz, int* __restrict__ bad);
 template <int W> __global__ void dxl_sweep(DxLinBatch B, const DxLinModel* __restrict__ L, int step, int groups);
 __global__ void dxl_logz(DxLinBatch B, const DxLinModel* __restrict__ L, double* __restrict__ zbar, double* __restrict__ logz, int* __restrict__ bad);
@@ -240,6 +243,8 @@ struct rh_ctx {
     int dx_w = 4;                  // wavefronts per 64-cell group of the linear duplex kernel
     int last_dx_path = 0;
     bool far_mfma = true;          // block products on v_mfma_f64_16x16x4_f64 (BS = 16); RH_FAR_MFMA=0: LDS/FMA kernel
+    bool far_pk = true;            // ... on packed operand tiles (lin_pack_tiles + lin_far_*_pk); RH_FAR_PK=0: gather per product
+    bool exp_nofar = false;        // RH_EXP_NOFAR=1: timing experiment only (block products skipped, results wrong)
     bool use_graphs = true;        // RH_NO_GRAPH=1 launches every kernel from the host instead
     GraphSlot g_in, g_out, g_dx;
     int mode = RH_MODE_AUTO;       // which McCaskill path rh_batch_compute takes
@@ -259,6 +264,8 @@ struct rh_ctx {
     void* d_seq = nullptr;   size_t cap_seq = 0;
     void* d_n = nullptr;     size_t cap_n = 0;
     void* d_mctab = nullptr; size_t cap_mctab = 0;
+    void* d_pk = nullptr; size_t cap_pk = 0;        // operand tiles of the block products (single-molecule batch)
+    void* d_copk = nullptr; size_t cap_copk = 0;    // ... of the s1+s2 batch
     void* d_f5 = nullptr;    size_t cap_f5 = 0;
     void* d_bp = nullptr;    size_t cap_bp = 0;
     void* d_up = nullptr;    size_t cap_up = 0;
@@ -443,6 +450,10 @@ int stage(rh_ctx* c, int ns, const char* const* seqs, const int* lens, bool with
         B.seq_stride = B.tab_stride * (vienna ? (int)kViennaMcTables : (int)T_COUNT);
         B.tri_stride = (tri_size(nmax) + 1) & ~(size_t)1;
         if ((rc = ensure(c, &c->d_mctab, &c->cap_mctab, sizeof(double) * B.seq_stride * ns, false))) return rc;
+        B.nb = (nmax - 1) / 16 + 1;
+        B.pk_stride = (size_t)B.nb * (B.nb + 1) / 2 * 256;
+        if ((rc = ensure(c, &c->d_pk, &c->cap_pk, sizeof(double) * B.pk_stride * kPkCopies * ns, false))) return rc;
+        B.pk = (double*)c->d_pk;
         if ((rc = ensure(c, &c->d_f5, &c->cap_f5, sizeof(double) * 2 * B.ld * ns, false))) return rc;
         if ((rc = ensure(c, &c->d_up, &c->cap_up, sizeof(double) * B.ld * c->max_w * ns, false))) return rc;
         if (vienna && (rc = ensure(c, &c->d_gaps, &c->cap_gaps, sizeof(double) * 2 * 32 * B.ld * ns, false))) return rc;
@@ -529,6 +540,10 @@ int stage(rh_ctx* c, int ns, const char* const* seqs, const int* lens, bool with
             if ((rc = ensure(c, &c->d_coseq, &c->cap_coseq, cc.size(), false))) return rc;
             if ((rc = ensure(c, &c->d_con, &c->cap_con, sizeof(int) * nn.size(), false))) return rc;
             if ((rc = ensure(c, &c->d_cotab, &c->cap_cotab, sizeof(double) * C.seq_stride * np, false))) return rc;
+            C.nb = (cmax - 1) / 16 + 1;
+            C.pk_stride = (size_t)C.nb * (C.nb + 1) / 2 * 256;
+            if ((rc = ensure(c, &c->d_copk, &c->cap_copk, sizeof(double) * C.pk_stride * kPkCopies * np, false))) return rc;
+            C.pk = (double*)c->d_copk;
             if ((rc = ensure(c, &c->d_cof5, &c->cap_cof5, sizeof(double) * 6 * C.ld * np, false))) return rc;
             if ((rc = ensure(c, &c->d_cobp, &c->cap_cobp, sizeof(double) * C.tri_stride * np, false))) return rc;
             if ((rc = ensure(c, &c->d_cobad, &c->cap_cobad, sizeof(int) * np, false))) return rc;
@@ -613,6 +628,38 @@ int launch_mc_vienna(rh_ctx* c, int pin)
     return RH_OK;
 }
 
+// ---- block products (mccaskill_far.hip, BS = 16) on re-laid operand tiles: the tiles of block diagonal Dblk are packed once,
+// right after their last cell is final, and then read by every product that uses them as two contiguous 2 KB fragments.
+//   inside : far(D) uses FM1/FM tiles of block diagonals 2..D-2; block diagonal D-2 completes with fine diagonal (D-1)*16-1
+//   outside: far(D) uses FM2o tiles of block diagonals >= D+2 (final before fine diagonal (D+1)*16-1) and FM1/FM tiles of
+//            every block diagonal (the last two are packed when the outside phase starts)
+// returns the number of launches
+static int far_inside_step(rh_ctx* c, const McBatch& B, hipStream_t st, int D, int last_block)
+{
+    if (c->exp_nofar) return 0;
+    if (!c->far_pk) { KLAUNCH(c, 1, lin_far_inside_mfma, dim3(last_block - D + 1, B.ns), dim3(256), st, B, D); return 1; }
+    KLAUNCH(c, 1, lin_pack_tiles, dim3(B.nb - (D - 2), B.ns, 2), dim3(256), st, B, D - 2, 0);
+    KLAUNCH(c, 1, lin_far_inside_pk, dim3(last_block - D + 1, B.ns), dim3(256), st, B, D);
+    return 2;
+}
+static int far_outside_begin(rh_ctx* c, const McBatch& B, hipStream_t st, int last_block)
+{
+    if (c->exp_nofar || !c->far_pk) return 0;
+    int nl = 0;
+    for (int Dblk = std::max(2, last_block - 1); Dblk <= last_block; Dblk++, nl++)
+        KLAUNCH(c, 3, lin_pack_tiles, dim3(B.nb - Dblk, B.ns, 2), dim3(256), st, B, Dblk, 0);
+    return nl;
+}
+static int far_outside_step(rh_ctx* c, const McBatch& B, hipStream_t st, int D, int last_block)
+{
+    if (c->exp_nofar) return 0;
+    if (!c->far_pk) { KLAUNCH(c, 3, lin_far_outside_mfma, dim3(last_block - D + 1, B.ns, 2), dim3(256), st, B, D); return 1; }
+    int nl = 1;
+    if (D + 2 <= last_block) { KLAUNCH(c, 3, lin_pack_tiles, dim3(B.nb - (D + 2), B.ns, 1), dim3(256), st, B, D + 2, 1); nl++; }
+    KLAUNCH(c, 3, lin_far_outside_pk, dim3(last_block - D + 1, B.ns, 2), dim3(256), st, B, D);
+    return nl;
+}
+
 // ---- Vienna-BL McCaskill sweeps, scaled linear-space path (mccaskill_vlin.hip) with the block products of mccaskill_far.hip.
 // co = false: the single-molecule batch on the McCaskill stream (+ accessibility); co = true: the s1+s2 batch of the
 // two-molecule hybridization matrix on the duplex stream (two more groups per launch for the exterior halves XS / XP)
@@ -637,26 +684,19 @@ int launch_mc_vlin(rh_ctx* c, int pin, int phase, bool co)
             (*nl)++;
             if (BS > 0 && (d + 1) % BS == 0) {
                 const int D = (d + 1) / BS + 1;
-                if (D >= 4 && D <= last_block) {
-                    KLAUNCH(c, 1, lin_far_inside_mfma, dim3(last_block - D + 1, B.ns), dim3(256), st, B, D);
-                    (*nl)++; (*nf)++;
-                }
+                if (D >= 4 && D <= last_block) { (*nl) += far_inside_step(c, B, st, D, last_block); (*nf)++; }
             }
         }
         return RH_OK;
     }
-    if (BS > 0)
-        for (int D = last_block; D >= 0 && (D + 1) * BS - 1 > B.nmax - 2; D--) {
-            KLAUNCH(c, 3, lin_far_outside_mfma, dim3(last_block - D + 1, B.ns, 2), dim3(256), st, B, D);
-            (*nl)++; (*nf)++;
-        }
+    if (BS > 0) {
+        (*nl) += far_outside_begin(c, B, st, last_block);
+        for (int D = last_block; D >= 0 && (D + 1) * BS - 1 > B.nmax - 2; D--) { (*nl) += far_outside_step(c, B, st, D, last_block); (*nf)++; }
+    }
     for (int d = B.nmax - 2; d >= 0; d--) {
         if (BS > 0 && (d + 1) % BS == 0) {
             const int D = (d + 1) / BS - 1;
-            if (D >= 0 && D <= last_block) {
-                KLAUNCH(c, 3, lin_far_outside_mfma, dim3(last_block - D + 1, B.ns, 2), dim3(256), st, B, D);
-                (*nl)++; (*nf)++;
-            }
+            if (D >= 0 && D <= last_block) { (*nl) += far_outside_step(c, B, st, D, last_block); (*nf)++; }
         }
         const int groups = (B.nmax - 1 - d + 63) / 64 + extra;
         if (co) KLAUNCH(c, 2, (vlin_outside_diag<W, BS, true>), pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(64 * W), st, B, c->d_vlin, d, pin, bad);
@@ -723,33 +763,37 @@ int launch_mc_lin(rh_ctx* c, int pin, int phase)
         if (BS > 0 && (d + 1) % BS == 0) {
             const int D = (d + 1) / BS + 1;
             if (D >= 4 && D <= last_block) {
-                if (BS == 16 && c->far_mfma)
-                    KLAUNCH(c, 1, lin_far_inside_mfma, dim3(last_block - D + 1, B.ns), dim3(256), c->s_mc, B, D);
-                else
+                if (BS == 16 && c->far_mfma) c->n_launch[0] += far_inside_step(c, B, c->s_mc, D, last_block);
+                else if (!c->exp_nofar) {
                     KLAUNCH(c, 1, lin_far_inside<(BS > 0 ? BS : 16)>, dim3(last_block - D + 1, B.ns), dim3(256), c->s_mc, B, D);
-                c->n_launch[0]++; c->n_far[0]++;
+                    c->n_launch[0]++;
+                }
+                c->n_far[0]++;
             }
         }
     }
     return RH_OK;
     }
+    if (BS == 16 && c->far_mfma) c->n_launch[1] += far_outside_begin(c, B, c->s_mc, last_block);
     if (BS > 0)  // tiles whose first cell would come before the first outside diagonal: their far sums are empty
         for (int D = last_block; D >= 0 && (D + 1) * BS - 1 > B.nmax - 2; D--) {
-            if (BS == 16 && c->far_mfma)
-                KLAUNCH(c, 3, lin_far_outside_mfma, dim3(last_block - D + 1, B.ns, 2), dim3(256), c->s_mc, B, D);
-            else
+            if (BS == 16 && c->far_mfma) c->n_launch[1] += far_outside_step(c, B, c->s_mc, D, last_block);
+            else if (!c->exp_nofar) {
                 KLAUNCH(c, 3, lin_far_outside<(BS > 0 ? BS : 16)>, dim3(last_block - D + 1, B.ns, 2), dim3(256), c->s_mc, B, D);
-            c->n_launch[1]++; c->n_far[1]++;
+                c->n_launch[1]++;
+            }
+            c->n_far[1]++;
         }
     for (int d = B.nmax - 2; d >= 0; d--) {
         if (BS > 0 && (d + 1) % BS == 0) {
             const int D = (d + 1) / BS - 1;
             if (D >= 0 && D <= last_block) {
-                if (BS == 16 && c->far_mfma)
-                    KLAUNCH(c, 3, lin_far_outside_mfma, dim3(last_block - D + 1, B.ns, 2), dim3(256), c->s_mc, B, D);
-                else
+                if (BS == 16 && c->far_mfma) c->n_launch[1] += far_outside_step(c, B, c->s_mc, D, last_block);
+                else if (!c->exp_nofar) {
                     KLAUNCH(c, 3, lin_far_outside<(BS > 0 ? BS : 16)>, dim3(last_block - D + 1, B.ns, 2), dim3(256), c->s_mc, B, D);
-                c->n_launch[1]++; c->n_far[1]++;
+                    c->n_launch[1]++;
+                }
+                c->n_far[1]++;
             }
         }
         const int groups = (B.nmax - 1 - d + 63) / 64 + 1;
@@ -869,14 +913,15 @@ size_t shape_key(const rh_ctx* c, int which)
         const McBatch& B = c->co;
         for (size_t v : {(size_t)B.ns, (size_t)B.nmax, (size_t)B.ld, (size_t)B.lds, (size_t)B.tab, (size_t)B.seq, (size_t)B.n, (size_t)B.f5i,
                          (size_t)B.bp, (size_t)c->d_cobad, (size_t)c->lin_bs, (size_t)B.tri_stride, (size_t)c->dx.hp, (size_t)c->dx.logz,
-                         (size_t)c->dx.ldd, (size_t)c->dx.tab_stride, (size_t)c->dx.n1max, (size_t)c->dx.n2max, (size_t)B.allow})
+                         (size_t)c->dx.ldd, (size_t)c->dx.tab_stride, (size_t)c->dx.n1max, (size_t)c->dx.n2max, (size_t)B.allow, (size_t)B.pk,
+                         (size_t)c->far_pk})
             h = mix(h, v);
     } else if (which <= 1) {
         const McBatch& B = c->mc;
         for (size_t v : {(size_t)B.ns, (size_t)B.nmax, (size_t)B.ld, (size_t)B.lds, (size_t)B.tab, (size_t)B.seq, (size_t)B.n,
                          (size_t)B.f5i, (size_t)B.bp, (size_t)B.up, (size_t)c->d_bad, (size_t)c->d_mclogz, (size_t)c->lin_w, (size_t)c->lin_w_in,
                          (size_t)c->lin_bs, (size_t)B.tri_stride, (size_t)c->far_mfma, (size_t)c->max_w, (size_t)c->d_gaps,
-                         (size_t)c->d_hplen, (size_t)B.allow})
+                         (size_t)c->d_hplen, (size_t)B.allow, (size_t)B.pk, (size_t)c->far_pk})
             h = mix(h, v);
     } else {
         const DxLinBatch& X = c->dxl;
@@ -1121,6 +1166,8 @@ rh_ctx* rh_create(int device, int model, const char* param_file)
     if (const char* e = std::getenv("RH_LIN_BS")) c->lin_bs = std::atoi(e);
     if (const char* e = std::getenv("RH_NO_GRAPH")) c->use_graphs = std::atoi(e) == 0;
     if (const char* e = std::getenv("RH_FAR_MFMA")) c->far_mfma = std::atoi(e) != 0;
+    if (const char* e = std::getenv("RH_EXP_NOFAR")) c->exp_nofar = std::atoi(e) != 0;
+    if (const char* e = std::getenv("RH_FAR_PK")) c->far_pk = std::atoi(e) != 0;
     if (const char* e = std::getenv("RH_DX_W")) c->dx_w = std::atoi(e);
     bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&c->s_mc, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&c->s_dx, hipStreamNonBlocking) == hipSuccess &&
@@ -1154,7 +1201,7 @@ void rh_destroy(rh_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    void* bufs[] = {c->d_seq, c->d_n, c->d_mctab, c->d_f5, c->d_bp, c->d_up, c->d_dxtab, c->d_hp, c->d_logz, c->d_scal, c->d_mclogz, c->d_bad, c->d_cnt, c->d_cand, c->d_dxbad, c->d_zbar, c->d_gaps, c->d_coseq, c->d_con, c->d_cotab, c->d_cof5, c->d_cobp, c->d_cobad, c->d_allow, c->d_coallow, c->d_vlin, c->d_hplen, c->d_model, c->d_lin, c->d_dxlin, c->d_vienna};
+    void* bufs[] = {c->d_seq, c->d_n, c->d_mctab, c->d_f5, c->d_bp, c->d_up, c->d_dxtab, c->d_hp, c->d_logz, c->d_scal, c->d_mclogz, c->d_bad, c->d_cnt, c->d_cand, c->d_dxbad, c->d_zbar, c->d_gaps, c->d_coseq, c->d_con, c->d_cotab, c->d_pk, c->d_copk, c->d_cof5, c->d_cobp, c->d_cobad, c->d_allow, c->d_coallow, c->d_vlin, c->d_hplen, c->d_model, c->d_lin, c->d_dxlin, c->d_vienna};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (GraphSlot* g : {&c->g_in, &c->g_out, &c->g_dx}) if (g->exec) (void)hipGraphExecDestroy(g->exec);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);

@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "libractip_hot.so")
+LIB_PATH = os.environ.get("RACTIP_HOT_LIB") or os.path.join(PKG, "libractip_hot.so")   # override: tuning builds (tools/build_variant.py)
 
 RH_MODEL_CONTRAFOLD = 0
 RH_MODEL_VIENNA_BL = 1
