@@ -30,12 +30,12 @@ constexpr uint32_t kPairMaskD = (1u << (0 * 5 + 3)) | (1u << (3 * 5 + 0)) | (1u 
                                 (1u << (2 * 5 + 1)) | (1u << (2 * 5 + 3)) | (1u << (3 * 5 + 2));
 __device__ __forceinline__ bool pairs(int a, int b) { return (kPairMaskD >> (a * 5 + b)) & 1u; }
 // (T+1)-wide window sum over an LDS-resident segment, fully unrolled (no scalar loop control per tap)
+// volatile: keeps every tap a plain ds_read_b64 (2 LDS cycles per wavefront, 256 B/clk/CU); merged into
+// ds_read2_b64 by the compiler, two taps cost 8 cycles (128 B/clk/CU) on CDNA4
+typedef const volatile __attribute__((address_space(3))) double* lds_vptr;
 template <int T>
 __device__ __forceinline__ double win_sum(const double* seg)
 {
-    // volatile: keeps every tap a plain ds_read_b64 (2 LDS cycles per wavefront, 256 B/clk/CU); merged into
-    // ds_read2_b64 by the compiler, two taps cost 8 cycles (128 B/clk/CU) on CDNA4
-    typedef const volatile __attribute__((address_space(3))) double* lds_vptr;
     lds_vptr vs = (lds_vptr)seg;
     double s0 = 0.0, s1 = 0.0;
 #pragma unroll
@@ -49,7 +49,7 @@ __device__ __forceinline__ double win_sum_any(int t, const double* seg)
 {
     switch (t) {
 #define X(T) case T: return win_sum<T>(seg);
-        X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22)
+        X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22)
         X(23) X(24) X(25) X(26) X(27) X(28)
 #undef X
     }
@@ -58,55 +58,64 @@ __device__ __forceinline__ double win_sum_any(int t, const double* seg)
 }  // namespace
 
 // ---------------------------------------------------------------------------------
-// launch `step`: inside diagonals {2+2*step, 3+2*step} and outside diagonals
-// {Smax-2*step-1, Smax-2*step} (Smax = L1+L2) -- blockIdx.z selects inside/outside,
-// blockIdx.x = (which of the two diagonals) * groups + (64-cell group).
+// launch `step`: inside diagonals A = 2+2*step and B = A+1, outside diagonals A = Smax-2*step and B = A-1
+// (Smax = L1+L2) -- blockIdx.z selects inside/outside, blockIdx.x the 64-column group.  The two diagonals of a
+// direction do not depend on each other and are computed by the SAME workgroup, one cell of each per lane: the window of
+// length t on source row r belongs to diagonal A, and diagonal B reads the same row with length t+1 over the same columns
+// plus one -- so every staged row and every LDS tap but one serves both cells.
 template <int W>
 __global__ __launch_bounds__(64 * W) RH_WPE_DX void dxl_sweep(DxLinBatch B, const DxLinModel* __restrict__ L, int step, int groups)
 {
-    __shared__ double buf[W][(26 + W - 1) / W][96];
-    __shared__ double part[W][64];
+    __shared__ double buf[W][(27 + W - 1) / W][96];
+    __shared__ double part[2][W][64];
     const int pr = blockIdx.y;
     const int L1 = B.n[2 * pr], L2 = B.n[2 * pr + 1];
     const bool outside = blockIdx.z != 0;
-    const int which = blockIdx.x / groups, grp = blockIdx.x % groups;
+    const int grp = blockIdx.x;
     const int smax = L1 + L2;
-    const int sd = outside ? smax - 2 * step - 1 + which : 2 + 2 * step + which;
-    if (sd < 2 || sd > smax) return;
+    const int sdA = outside ? smax - 2 * step : 2 + 2 * step;
+    const int sdB = outside ? sdA - 1 : sdA + 1;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int a0 = grp * 64;
     if (a0 > B.n1max + 1) return;
     const int a = a0 + lane;
-    const int b = sd - a;
-    const int i = a, j = L2 + 1 - b;
-    const bool incell = a >= 1 && a <= L1 && b >= 1 && b <= L2;
     const int lda = B.lda;
     const size_t ts = B.tab_stride;
     double* __restrict__ tab = B.tab + (size_t)pr * B.pair_stride;
     const uint8_t* __restrict__ s1 = B.seq + (size_t)(2 * pr) * B.lds;
     const uint8_t* __restrict__ s2 = B.seq + (size_t)(2 * pr + 1) * B.lds;
-
-    const size_t at = (size_t)sd * lda + kDxPad + a;
-    {   // groups entirely outside this diagonal's cells [max(1, sd-L2), min(L1, sd-1)] only clear their columns
-        const int alo = sd - L2 > 1 ? sd - L2 : 1, ahi = sd - 1 < L1 ? sd - 1 : L1;
-        if (a0 + 63 < alo || a0 > ahi) {
-            if (w == 0 && a <= B.n1max + 1) {
+    const bool okA = sdA >= 2 && sdA <= smax, okB = sdB >= 2 && sdB <= smax;   // the diagonal exists
+    if (!okA && !okB) return;
+    // does this group hold cells [max(1, sd-L2), min(L1, sd-1)] of either diagonal?
+    const bool hasA = okA && !(a0 + 63 < (sdA - L2 > 1 ? sdA - L2 : 1) || a0 > (sdA - 1 < L1 ? sdA - 1 : L1));
+    const bool hasB = okB && !(a0 + 63 < (sdB - L2 > 1 ? sdB - L2 : 1) || a0 > (sdB - 1 < L1 ? sdB - 1 : L1));
+    if (!hasA && !hasB) {   // only clear the columns of the rows
+        if (w < 2 && a <= B.n1max + 1) {
+            const int sd = w == 0 ? sdA : sdB;
+            if (w == 0 ? okA : okB) {
+                const size_t at = (size_t)sd * lda + kDxPad + a;
                 tab[(outside ? DL_OUT : DL_IN) * ts + at] = 0.0;
                 tab[(outside ? DL_OUTX : DL_INX) * ts + at] = 0.0;
             }
-            return;
         }
+        return;
     }
+
+    // epilogue: wavefront 0 finishes diagonal A, wavefront 1 diagonal B; operands issued before the window work
+    const int sd = w == 1 ? sdB : sdA;
+    const bool mine = w == 0 ? okA : (w == 1 ? okB : false);
+    const int b = sd - a;
+    const int i = a, j = L2 + 1 - b;
+    const bool incell = mine && a >= 1 && a <= L1 && b >= 1 && b <= L2;
+    const size_t at = (size_t)sd * lda + kDxPad + a;
     int x = 4, xm = 4, xp = 4, y = 4, ym = 4, yp = 4;  // s1[i], s1[i-1], s1[i+1], s2[j], s2[j-1], s2[j+1]
     if (incell) { x = s1[i]; xm = s1[i - 1]; xp = s1[i + 1]; y = s2[j]; ym = s2[j - 1]; yp = s2[j + 1]; }
     const bool pairable = incell && pairs(x, y);
-
-    // epilogue operands (wave 0): issued before the window work so that their latency hides behind it
     const double* __restrict__ rawt = tab + (outside ? DL_OUT : DL_IN) * ts + kDxPad;
     const double* __restrict__ dect = tab + (outside ? DL_OUTX : DL_INX) * ts + kDxPad;
     double o_st = 0, o_01 = 0, o_10 = 0, o_02 = 0, o_11 = 0, o_20 = 0;
     double e_up = 0, e_dn = 0, e_ends = 0, e_st = 0, e_b01 = 0, e_b10 = 0, e_11 = 0;
-    if (w == 0 && pairable) {
+    if (pairable) {
         const int dir = outside ? 1 : -1;     // sources lie at rows sd + dir*(2+t), columns a + dir*(1+l1)
         const int r2 = sd + 2 * dir, r3 = sd + 3 * dir, r4 = sd + 4 * dir;
         if (r2 >= 2 && r2 <= smax) o_st = rawt[(size_t)r2 * lda + a + dir];
@@ -127,46 +136,54 @@ __global__ __launch_bounds__(64 * W) RH_WPE_DX void dxl_sweep(DxLinBatch B, cons
         }
     }
 
-    // ---- windows t = 3..28: sum_{l1=0..t} SRC[sd -/+ (2+t)][a -/+ (1+l1)] * lam^(t+2)
+    // ---- windows: source row r = sdA -/+ (2+t), t = 2..28, serves diagonal A with length t (3 <= t <= 28) over columns
+    // [a-1-t, a-1] (inside) / [a+1, a+1+t] (outside), and diagonal B with length t+1 (3 <= t+1 <= 28): one more column
+    // on the far side.  weight lam^(length+2)
     const double* __restrict__ src = tab + (outside ? DL_OUTX : DL_INX) * ts + kDxPad;
-    double acc = 0.0;
-    constexpr int NSEG = (26 + W - 1) / W;   // windows t = 3..28 dealt round-robin to the W wavefronts
+    double accA = 0.0, accB = 0.0;
+    constexpr int NSEG = (27 + W - 1) / W;   // rows t = 2..28 dealt round-robin to the W wavefronts
     // pass 1: stage every segment this wavefront sums (all row loads in flight at once)
 #pragma unroll
     for (int q = 0; q < NSEG; q++) {
-        const int t = 3 + w + q * W;
-        const int row = outside ? sd + 2 + t : sd - 2 - t;
+        const int t = 2 + w + q * W;
+        const int row = outside ? sdA + 2 + t : sdA - 2 - t;
         const bool on = t <= 28 && row >= 2 && row <= smax;   // wave-uniform
         if (on) {
-            // segment start: inside a0-1-t (window = [a-1-t, a-1]); outside a0+1 (window = [a+1, a+1+t])
-            const int c0 = outside ? a0 + 1 : a0 - 1 - t;
+            // segment start: inside a0-2-t (B's window = [a-2-t, a-1]); outside a0+1 (B's window = [a+1, a+2+t])
+            const int c0 = outside ? a0 + 1 : a0 - 2 - t;
             const double* __restrict__ r = src + (size_t)row * lda + c0;
             buf[w][q][lane] = r[lane];
             if (lane < 32) buf[w][q][64 + lane] = r[64 + lane];
         }
     }
-    // pass 2: the window sums
-    // rolled: ONE copy of the 26-way window switch (unrolled, the NSEG copies made the kernel larger than the
-    // instruction cache two CUs share)
+    // pass 2: the window sums; rolled: ONE copy of the window switch (unrolled, the NSEG copies made the kernel larger
+    // than the instruction cache two CUs share)
 #pragma unroll 1
     for (int q = 0; q < NSEG; q++) {
-        const int t = 3 + w + q * W;
-        const int row = outside ? sd + 2 + t : sd - 2 - t;
-        if (t <= 28 && row >= 2 && row <= smax) acc = fma(L->lam_pow[t + 2], win_sum_any(t, &buf[w][q][lane]), acc);
+        const int t = 2 + w + q * W;
+        const int row = outside ? sdA + 2 + t : sdA - 2 - t;
+        if (t <= 28 && row >= 2 && row <= smax) {
+            const double* seg = &buf[w][q][lane + (outside ? 0 : 1)];     // A's window = seg[0..t]
+            const double wa = win_sum_any(t, seg);
+            const double wb = wa + *(lds_vptr)(seg + (outside ? t + 1 : -1));
+            if (t >= 3) accA = fma(L->lam_pow[t + 2], wa, accA);
+            if (t <= 27) accB = fma(L->lam_pow[t + 3], wb, accB);
+        }
     }
-    part[w][lane] = acc;
+    part[0][w][lane] = accA;
+    part[1][w][lane] = accB;
     __syncthreads();
-    if (w != 0) return;
+    if (w > 1 || !mine) return;
     double g = 0.0;
 #pragma unroll
-    for (int k = 0; k < W; k++) g += part[k][lane];
+    for (int k = 0; k < W; k++) g += part[w][k][lane];
 
     double v = 0.0, vx = 0.0;
     if (pairable) {
         // inside : inside[i][j]  = open  + stack + down * (0x1/1x0/t=2 shapes + windows)   (DuplexEngine.ipp:1029-1064)
         // outside: outside[p][q] = close + stack + up   * (...)                             (DuplexEngine.ipp:1094-1129, pulled)
         const double l2 = L->lam_pow[2], l3 = L->lam_pow[3], l4 = L->lam_pow[4];
-        const double ends = (outside ? B.pw_out[which] : B.pw_in[which]) * e_ends;
+        const double ends = (outside ? B.pw_out[w == 0 ? 1 : 0] : B.pw_in[w]) * e_ends;
         const double sp = l3 * (e_b01 * o_01 + e_b10 * o_10) + l4 * (o_02 + e_11 * o_11 + o_20);
         const double own = outside ? e_up : e_dn;      // this cell's factor of every loop term
         v = ends + o_st * l2 * e_st + own * (sp + g);

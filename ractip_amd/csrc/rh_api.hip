@@ -886,7 +886,7 @@ int launch_dx_lin(rh_ctx* c)
         // inside diagonal sd = 2+2t+k: (lam e^eu)^(sd-2) lam^2 ; outside sd = Smax-2t-1+k: (lam e^eu)^(2t+1-k) lam^2
         X.pw_in[0] = std::pow(leu, 2.0 * t) * l2;      X.pw_in[1] = X.pw_in[0] * leu;
         X.pw_out[1] = std::pow(leu, 2.0 * t) * l2;     X.pw_out[0] = X.pw_out[1] * leu;
-        KLAUNCH(c, 4, dxl_sweep<W>, dim3(2 * groups, X.np, 2), dim3(64 * W), c->s_dx, X, c->d_dxlin, t, groups);
+        KLAUNCH(c, 4, dxl_sweep<W>, dim3(groups, X.np, 2), dim3(64 * W), c->s_dx, X, c->d_dxlin, t, groups);
         c->n_launch[2]++;
     }
     hipLaunchKernelGGL(dxl_logz, dim3(X.np), dim3(1024), 0, c->s_dx, X, c->d_dxlin, (double*)c->d_zbar, (double*)c->d_logz,
