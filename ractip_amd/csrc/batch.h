@@ -62,6 +62,7 @@ struct McBatch {
     size_t tri_stride;   // doubles per bp table
     // operand tiles of the block products (mccaskill_far.hip): kPkCopies re-laid copies of the 16x16 tiles (P <= Q) of
     // FM1 / FM / FM2o, each tile 256 doubles in MFMA fragment order; [NS][kPkCopies][pk_stride]
+    double* rowp;        // [NS][2][ld] look-ahead partial sums of the next inside diagonal (mccaskill_lin.hip, MODE 1 -> 2)
     double* pk;
     size_t pk_stride;    // doubles per copy = nb*(nb+1)/2 * 256
     int nb;              // 16-blocks per axis = (nmax-1)/16 + 1

@@ -118,11 +118,48 @@ __global__ void lin_init(McBatch B, int* __restrict__ bad)
 // the last cell group computes F5i~[d+1] with its first wavefront.
 // BS > 0: the k-terms that lie in complete blocks (I+2 .. J-2) come from FM2F (mccaskill_far.hip); only the
 // <= 4*BS near terms are streamed here.  BS = 0: the whole sum is streamed.
-template <int W, int BS>
-__global__ __launch_bounds__(64 * W) RH_WPE_IN void lin_inside_diag(McBatch B, const LinModel* __restrict__ L, int d, double lam_d, int pin)
+// MODE 0: one diagonal per launch.  MODE 1 / 2 = look-ahead pair: almost every operand of diagonal d+1 is already final
+// when diagonal d is computed (only the two FM2 terms that touch row d, and the epilogue, are not), and it is the SAME
+// data diagonal d reads -- FM1 row m serves both, the FM rows are the same cache lines one column on, and the filter of
+// length t+1 for d+1 runs over the staged row that the filter of length t for d runs over.  So the MODE 1 launch of an
+// even diagonal d also accumulates the partial sums of diagonal d+1 from the operands it has in registers / LDS and
+// leaves them in B.rowp; the MODE 2 launch of d+1 (one wavefront per group) adds the two fresh terms and runs the epilogue.
+template <int R>
+__device__ __forceinline__ void filt_pair(const double* __restrict__ wA, const double* __restrict__ wB, const double* seg, double& sa, double& sb)
+{   // sa = sum_{l<R} wA[l]*seg[l] (filter t = R-1 of diagonal d), sb = sum_{l<=R} wB[l]*seg[l] (filter t = R of diagonal d+1; none for R = 31)
+    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+#pragma unroll
+    for (int l = 0; l <= R; l += 2) {
+        const double x0 = seg[l];
+        if (l < R) a0 = fma(wA[l], x0, a0);
+        if (R <= kMaxSingle) b0 = fma(wB[l], x0, b0);
+        if (l + 1 <= R) {
+            const double x1 = seg[l + 1];
+            if (l + 1 < R) a1 = fma(wA[l + 1], x1, a1);
+            if (R <= kMaxSingle) b1 = fma(wB[l + 1], x1, b1);
+        }
+    }
+    sa = a0 + a1;
+    sb = b0 + b1;
+}
+__device__ __forceinline__ void filt_pair_any(int r, const double* __restrict__ wA, const double* __restrict__ wB, const double* seg, double& sa, double& sb)
 {
-    __shared__ double part[2][W][64];
-    __shared__ double gbuf[W][2 * ((kMaxSingle / 2 + W) / W)][96];
+    switch (r) {
+#define X(T) case T: filt_pair<T>(wA, wB, seg, sa, sb); return;
+        RH_T_CASES(X) X(31)
+#undef X
+    }
+    sa = 0.0; sb = 0.0;
+}
+
+template <int W, int BS, int MODE>
+__global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) RH_WPE_IN void lin_inside_diag(McBatch B, const LinModel* __restrict__ L, int d, double lam_d, int pin)
+{
+    constexpr int WR = MODE == 2 ? 1 : W;                       // wavefronts per group
+    constexpr int NQ = MODE == 1 ? 4 : 2;                       // per-wavefront partial sums
+    constexpr int NSEG = 2 * ((kMaxSingle / 2 + W) / W);       // rows g = 0..15 and LAST-g, dealt round-robin to the wavefronts
+    __shared__ double part[MODE == 2 ? 1 : NQ][WR][64];
+    __shared__ double gbuf[MODE == 2 ? 1 : W][MODE == 2 ? 1 : NSEG][MODE == 2 ? 1 : 96];
     int sq, slot;
     block_map(pin, &sq, &slot);
     if (sq >= B.ns) return;
@@ -137,21 +174,22 @@ __global__ __launch_bounds__(64 * W) RH_WPE_IN void lin_inside_diag(McBatch B, c
     const uint8_t* __restrict__ s = B.seq + (size_t)sq * B.lds;
     double* __restrict__ tab = B.tab + (size_t)sq * B.seq_stride;
     double* __restrict__ f5i = B.f5i + sq * ld;
+    double* __restrict__ rowp = B.rowp + (size_t)sq * 2 * ld;   // look-ahead partial sums of the next diagonal: FM2, filters
 
     if (slot == ngroup) {
         // F5i[jj] = F5i[jj-1]*ext_unpaired + sum_{k<=jj-2} F5i[k]*FCA[k+1,jj-1]*ext_paired   (ipp:3692-3717)
-        // all W wavefronts: the column of FCA is an anti-diagonal of the diagonal-major table (one line per term)
+        // all wavefronts: the column of FCA is an anti-diagonal of the diagonal-major table (one line per term)
         const int jj = d + 1;
         const double* __restrict__ fca = tab + L_FCA * ts;
         double acc = 0.0;
-        for (int k = threadIdx.x; k <= jj - 2; k += 64 * W) acc = fma(f5i[k], fca[(jj - 2 - k) * ld + (k + 1)], acc);
+        for (int k = threadIdx.x; k <= jj - 2; k += 64 * WR) acc = fma(f5i[k], fca[(jj - 2 - k) * ld + (k + 1)], acc);
         acc = wsum(acc);
         if (lane == 0) part[0][w][0] = acc;
         __syncthreads();
         if (threadIdx.x == 0) {
             double t = 0.0;
 #pragma unroll
-            for (int k = 0; k < W; k++) t += part[0][k][0];
+            for (int k = 0; k < WR; k++) t += part[0][k][0];
             f5i[jj] = f5i[jj - 1] * L->w_eu + t * L->w_ep2;
         }
         return;
@@ -187,19 +225,44 @@ __global__ __launch_bounds__(64 * W) RH_WPE_IN void lin_inside_diag(McBatch B, c
         }
     }
 
+    // near set of a cell (i, j) in k = i+m: k < kA or k >= kB (everything when the tile has no far blocks)
+    int kA = 1 << 30, kB = 0;
+    if (BS > 0) {
+        const int I = i / BS, J = j / BS;
+        if (J - I >= 4) { kA = (I + 2) * BS; kB = (J - 1) * BS; }
+    }
+    double acc2 = 0.0, accc = 0.0;
+    if constexpr (MODE == 2) {
+        // the look-ahead sums of the previous launch + the two terms that touch row d-1:  m = 1: FM1[1][i]*FM[d-1][i+1],
+        // m = d-1: FM1[d-1][i]*FM[1][i+d-1]
+        if (valid) {
+            acc2 = rowp[i];
+            accc = pairable ? rowp[ld + i] : 0.0;
+            if (d >= 2) {
+                const double* __restrict__ fm1c = tab + L_FM1 * ts + i;
+                const double* __restrict__ fmc = tab + L_FM * ts + i;
+                const int k1 = i + 1, k2 = i + d - 1;
+                if (k1 < kA || k1 >= kB) acc2 = fma(fm1c[ld], fmc[(d - 1) * ld + 1], acc2);
+                if (d >= 3 && (k2 < kA || k2 >= kB)) acc2 = fma(fm1c[(d - 1) * ld], fmc[ld + d - 1], acc2);
+            }
+            if (BS > 0 && kB > 0) acc2 += tab[L_FM2F * ts + d * ld + i];
+        }
+    } else {
     // ---- FM2[i,d] = sum_{m=1}^{d-1} FM1[m][i] * FM[d-m][i+m]          (ipp:3384-3411)
-    double acc2 = 0.0;
+    double acc2n = 0.0, acccn = 0.0;              // MODE 1: the same sums of diagonal d+1 without the terms that touch row d
+    const int d1 = d + 1;
+    const bool valid1 = MODE == 1 && i <= n - 1 - d1;
+    int kB1 = 0;                                  // kA is the same for (i, j+1)
+    if (MODE == 1 && BS > 0) {
+        const int I = i / BS, J1 = (j + 1) / BS;
+        if (J1 - I >= 4) kB1 = (J1 - 1) * BS;
+    }
+    const int kA1 = kB1 > 0 ? (i / (BS > 0 ? BS : 1) + 2) * BS : 1 << 30;
     {
         const int ic = valid ? i : (ncell > 0 ? ncell : 1);   // invalid lanes read the last valid cell's operands
         const double* __restrict__ fm1c = tab + L_FM1 * ts + ic;
         const double* __restrict__ fmc = tab + L_FM * ts + ic;
-        // near set of this cell in k = i+m: k < kA or k >= kB (everything when the tile has no far blocks)
-        int kA = 1 << 30, kB = 0;
-        if (BS > 0) {
-            const int I = i / BS, J = j / BS;
-            if (J - I >= 4) { kA = (I + 2) * BS; kB = (J - 1) * BS; }
-        }
-        constexpr int UF = 8;  // 2*UF row segments (512 B each) in flight per wavefront
+        constexpr int UF = MODE == 1 ? 6 : 8;  // 2*UF (3*UF) row segments (512 B each) in flight per wavefront
         // uniform m-ranges that cover every lane's near set: [1, d-1], or its two ends when far blocks exist
         const bool split = BS > 0 && d - 1 > 4 * BS;
         const int lo0 = 1, hi0 = split ? 2 * BS : d - 1;
@@ -207,13 +270,10 @@ __global__ __launch_bounds__(64 * W) RH_WPE_IN void lin_inside_diag(McBatch B, c
 #pragma unroll
         for (int part_i = 0; part_i < 2; part_i++) {
             const int lo = part_i ? lo1 : lo0, hi = part_i ? hi1 : hi0;
-#ifdef RH_EXP_NOFM2
-            if (d < 0)
-#endif
             for (int m = lo + w; m <= hi; m += UF * W) {
                 // branch-free: every load is issued (a lane or term that is out of range reads a clamped, valid address)
-                // so that all 2*UF loads are in flight together; the product is masked afterwards
-                double a[UF], b[UF];
+                // so that all loads are in flight together; the product is masked afterwards
+                double a[UF], b[UF], bn[UF];
 #pragma unroll
                 for (int u = 0; u < UF; u++) {
                     const int mm = m + u * W, mc = mm <= hi ? mm : hi;
@@ -223,12 +283,17 @@ __global__ __launch_bounds__(64 * W) RH_WPE_IN void lin_inside_diag(McBatch B, c
 #else
                     b[u] = fmc[(d - mc) * ld + mc];
 #endif
+                    if (MODE == 1) bn[u] = fmc[(d1 - mc) * ld + mc];   // FM[d+1-m][i+m]: row d-(m-1), final for m >= 2
                 }
 #pragma unroll
                 for (int u = 0; u < UF; u++) {
                     const int mm = m + u * W, k = i + mm;
                     const bool ok = valid && mm <= hi && (k < kA || k >= kB);
                     acc2 = fma(ok ? a[u] : 0.0, b[u], acc2);
+                    if (MODE == 1) {
+                        const bool ok1 = valid1 && mm <= hi && mm >= 2 && (k < kA1 || k >= kB1);
+                        acc2n = fma(ok1 ? a[u] : 0.0, bn[u], acc2n);
+                    }
                 }
             }
         }
@@ -239,11 +304,11 @@ __global__ __launch_bounds__(64 * W) RH_WPE_IN void lin_inside_diag(McBatch B, c
     // For one t the 64 cells of the group read overlapping windows of ONE row: the segment is staged in LDS
     // once and each lane runs a (t+1)-tap filter over it; shape weights are wave-uniform (scalar loads).
     // t and 30-t go to the same wavefront so that every wavefront filters ~62 taps.
-    double accc = 0.0;
+    // MODE 1: staged row r = 0..31 is table row d-1-r; it carries filter t = r-1 of diagonal d and filter t = r of d+1.
 #ifdef RH_EXP_NOFILT
     if (d < 0) {
 #else
-    if (d >= 2) {
+    if (MODE == 1 ? d >= 1 : d >= 2) {
 #endif
         const int tmax = d - 2 < kMaxSingle ? d - 2 : kMaxSingle;
         const int i0 = 1 + slot * 64;
@@ -251,16 +316,19 @@ __global__ __launch_bounds__(64 * W) RH_WPE_IN void lin_inside_diag(McBatch B, c
         // pass 1: stage every segment this wavefront filters.  Straight-line code: all row loads are issued back to
         // back (clamped addresses, no branches -- a branch per load makes the compiler wait for each load in turn), then
         // written to LDS
-        constexpr int NSEG = 2 * ((kMaxSingle / 2 + W) / W);     // <= 4 for W = 8
         double r0[NSEG], r1[NSEG];
-        const int col0 = i0 + 1;                                  // lane k of a segment = column col0+k of row d-2-t
+        const int col0 = i0 + 1;                                  // lane k of a segment = column col0+k of the row
         const int c0 = col0 + lane < ld ? col0 + lane : ld - 1, c1 = col0 + 64 + (lane & 31) < ld ? col0 + 64 + (lane & 31) : ld - 1;
+        constexpr int HALF = MODE == 1 ? (kMaxSingle + 1) / 2 : kMaxSingle / 2;   // rows g and LAST-g share a wavefront
+        constexpr int LAST = MODE == 1 ? kMaxSingle + 1 : kMaxSingle;
+        const int rmax = MODE == 1 ? (d - 1 < LAST ? d - 1 : LAST) : tmax;        // last staged row index that exists
 #pragma unroll
         for (int q = 0; q < NSEG; q++) {
             const int g = w + (q >> 1) * W;
-            const int t = (q & 1) ? kMaxSingle - g : g;
-            const bool on = g <= kMaxSingle / 2 && !((q & 1) && t == g) && t <= tmax;   // wave-uniform
-            const double* __restrict__ row = fcx + (on ? d - 2 - t : 0) * ld;
+            const int t = (q & 1) ? LAST - g : g;
+            const bool on = g <= HALF && !((q & 1) && t == g) && t <= rmax;   // wave-uniform
+            const int srow = MODE == 1 ? d - 1 - t : d - 2 - t;
+            const double* __restrict__ row = fcx + (on ? srow : 0) * ld;
             r0[q] = row[c0];
             r1[q] = row[c1];
         }
@@ -270,25 +338,49 @@ __global__ __launch_bounds__(64 * W) RH_WPE_IN void lin_inside_diag(McBatch B, c
             if (lane < 32) gbuf[w][q][64 + lane] = col0 + 64 + lane < ld ? r1[q] : 0.0;
         }
         // pass 2: the filters
-        // rolled: ONE copy of the 31-way filter switch (unrolled, the NSEG copies made the kernel larger than the
+        // rolled: ONE copy of the filter switch (unrolled, the NSEG copies made the kernel larger than the
         // instruction cache two CUs share)
 #pragma unroll 1
         for (int q = 0; q < NSEG; q++) {
             const int g = w + (q >> 1) * W;
-            const int t = (q & 1) ? kMaxSingle - g : g;
-            const bool on = g <= kMaxSingle / 2 && !((q & 1) && t == g) && t <= tmax;
-            if (on) accc += filt_fwd_any(t, L->shape_w + t * (t + 1) / 2, &gbuf[w][q][lane]);
+            const int t = (q & 1) ? LAST - g : g;
+            const bool on = g <= HALF && !((q & 1) && t == g) && t <= rmax;
+            if (!on) continue;
+            if constexpr (MODE == 1) {
+                double sa, sb;
+                filt_pair_any(t, L->shape_w + (t > 0 ? (t - 1) * t / 2 : 0), L->shape_w + (t <= kMaxSingle ? t * (t + 1) / 2 : 0), &gbuf[w][q][lane], sa, sb);
+                accc += sa;
+                acccn += sb;
+            } else {
+                accc += filt_fwd_any(t, L->shape_w + t * (t + 1) / 2, &gbuf[w][q][lane]);
+            }
         }
         if (!pairable) accc = 0.0;
     }
+    if constexpr (MODE == 1) { part[2][w][lane] = acc2n; part[3][w][lane] = acccn; }
+    }
 
-    part[0][w][lane] = acc2;
-    part[1][w][lane] = accc;
-    __syncthreads();
-    if (w != 0 || !valid) return;
-    double fm2 = 0.0, g = 0.0;
+    if constexpr (MODE != 2) {
+        part[0][w][lane] = acc2;
+        part[1][w][lane] = accc;
+        __syncthreads();
+        if constexpr (MODE == 1) {
+            if (w == 1 && i < ld) {   // the look-ahead sums of diagonal d+1 (any value where d+1 has no cell: never read)
+                double p2 = 0.0, pg = 0.0;
 #pragma unroll
-    for (int k = 0; k < W; k++) { fm2 += part[0][k][lane]; g += part[1][k][lane]; }
+                for (int k = 0; k < W; k++) { p2 += part[2][k][lane]; pg += part[3][k][lane]; }
+                rowp[i] = p2;
+                rowp[ld + i] = pg;
+            }
+        }
+    }
+    if (w != 0 || !valid) return;
+    double fm2 = acc2, g = accc;
+    if constexpr (MODE != 2) {
+        fm2 = 0.0; g = 0.0;
+#pragma unroll
+        for (int k = 0; k < W; k++) { fm2 += part[0][k][lane]; g += part[1][k][lane]; }
+    }
 
     double fc = 0.0;
     if (pairable) {
@@ -517,12 +609,14 @@ __global__ void lin_finish(McBatch B, const LinModel* __restrict__ L, double* __
 }
 
 // the host side instantiates the group width / block size it wants
-#define RH_INST(W, BS)                                                                             \
-    template __global__ void lin_inside_diag<W, BS>(McBatch, const LinModel*, int, double, int);  \
+#define RH_INST(W, BS)                                                                                \
+    template __global__ void lin_inside_diag<W, BS, 0>(McBatch, const LinModel*, int, double, int);  \
     template __global__ void lin_outside_diag<W, BS>(McBatch, const LinModel*, int, int, int*);
 RH_INST(8, 0) RH_INST(16, 0)
 RH_INST(8, 16) RH_INST(16, 16) RH_INST(4, 16)
 RH_INST(8, 32) RH_INST(16, 32)
 #undef RH_INST
+template __global__ void lin_inside_diag<4, 16, 1>(McBatch, const LinModel*, int, double, int);   // look-ahead pair
+template __global__ void lin_inside_diag<4, 16, 2>(McBatch, const LinModel*, int, double, int);
 
 }  // namespace rh

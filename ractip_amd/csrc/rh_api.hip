@@ -32,7 +32,7 @@ __global__ void dx_sweep_diag(DxBatch B, const ScoreModel* __restrict__ M, int t
 __global__ void dx_logz(DxBatch B, const ScoreModel* __restrict__ M);
 __global__ void dx_posterior(DxBatch B);
 __global__ void lin_init(McBatch B, int* __restrict__ bad);
-template <int W, int BS> __global__ void lin_inside_diag(McBatch B, const LinModel* __restrict__ L, int d, double lam_d, int pin);
+template <int W, int BS, int MODE> __global__ void lin_inside_diag(McBatch B, const LinModel* __restrict__ L, int d, double lam_d, int pin);
 template <int W, int BS> __global__ void lin_outside_diag(McBatch B, const LinModel* __restrict__ L, int d, int pin, int* __restrict__ bad);
 template <int BS> __global__ void lin_far_inside(McBatch B, int D);
 template <int BS> __global__ void lin_far_outside(McBatch B, int D);
@@ -243,6 +243,7 @@ struct rh_ctx {
     int dx_w = 4;                  // wavefronts per 64-cell group of the linear duplex kernel
     int last_dx_path = 0;
     bool far_mfma = true;          // block products on v_mfma_f64_16x16x4_f64 (BS = 16); RH_FAR_MFMA=0: LDS/FMA kernel
+    bool lookahead = true;         // inside sweep in look-ahead pairs (lin_inside_diag MODE 1/2); RH_LOOKAHEAD=0: one full launch per diagonal
     bool far_pk = true;            // ... on packed operand tiles (lin_pack_tiles + lin_far_*_pk); RH_FAR_PK=0: gather per product
     bool exp_nofar = false;        // RH_EXP_NOFAR=1: timing experiment only (block products skipped, results wrong)
     bool use_graphs = true;        // RH_NO_GRAPH=1 launches every kernel from the host instead
@@ -264,6 +265,7 @@ struct rh_ctx {
     void* d_seq = nullptr;   size_t cap_seq = 0;
     void* d_n = nullptr;     size_t cap_n = 0;
     void* d_mctab = nullptr; size_t cap_mctab = 0;
+    void* d_rowp = nullptr; size_t cap_rowp = 0;    // look-ahead partial sums of the next inside diagonal
     void* d_pk = nullptr; size_t cap_pk = 0;        // operand tiles of the block products (single-molecule batch)
     void* d_copk = nullptr; size_t cap_copk = 0;    // ... of the s1+s2 batch
     void* d_f5 = nullptr;    size_t cap_f5 = 0;
@@ -454,6 +456,8 @@ int stage(rh_ctx* c, int ns, const char* const* seqs, const int* lens, bool with
         B.pk_stride = (size_t)B.nb * (B.nb + 1) / 2 * 256;
         if ((rc = ensure(c, &c->d_pk, &c->cap_pk, sizeof(double) * B.pk_stride * kPkCopies * ns, false))) return rc;
         B.pk = (double*)c->d_pk;
+        if ((rc = ensure(c, &c->d_rowp, &c->cap_rowp, sizeof(double) * 2 * B.ld * ns, false))) return rc;
+        B.rowp = (double*)c->d_rowp;
         if ((rc = ensure(c, &c->d_f5, &c->cap_f5, sizeof(double) * 2 * B.ld * ns, false))) return rc;
         if ((rc = ensure(c, &c->d_up, &c->cap_up, sizeof(double) * B.ld * c->max_w * ns, false))) return rc;
         if (vienna && (rc = ensure(c, &c->d_gaps, &c->cap_gaps, sizeof(double) * 2 * 32 * B.ld * ns, false))) return rc;
@@ -757,8 +761,20 @@ int launch_mc_lin(rh_ctx* c, int pin, int phase)
     hipLaunchKernelGGL(lin_init, dim3((B.ns + 63) / 64), dim3(64), 0, c->s_mc, B, bad);
     for (int d = 0; d <= B.nmax - 1; d++) {
         const int groups = (std::max(B.nmax - 1 - d, 0) + 63) / 64 + 1;
-        KLAUNCH(c, 0, (lin_inside_diag<W, BS>), pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(64 * W), c->s_mc, B,
-                           c->d_lin, d, std::exp(-c->h_lin.s * d), pin);
+        if constexpr (W == 4 && BS == 16) {
+            if (c->lookahead && (d & 1) == 0)      // even diagonal: also accumulates the look-ahead sums of d+1 ...
+                KLAUNCH(c, 0, (lin_inside_diag<4, 16, 1>), pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(64 * W), c->s_mc, B, c->d_lin, d,
+                        std::exp(-c->h_lin.s * d), pin);
+            else if (c->lookahead)                 // ... which then needs one wavefront per group
+                KLAUNCH(c, 0, (lin_inside_diag<4, 16, 2>), pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(64), c->s_mc, B, c->d_lin, d,
+                        std::exp(-c->h_lin.s * d), pin);
+            else
+                KLAUNCH(c, 0, (lin_inside_diag<W, BS, 0>), pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(64 * W), c->s_mc, B, c->d_lin, d,
+                        std::exp(-c->h_lin.s * d), pin);
+        } else {
+            KLAUNCH(c, 0, (lin_inside_diag<W, BS, 0>), pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(64 * W), c->s_mc, B, c->d_lin, d,
+                    std::exp(-c->h_lin.s * d), pin);
+        }
         c->n_launch[0]++;
         if (BS > 0 && (d + 1) % BS == 0) {
             const int D = (d + 1) / BS + 1;
@@ -921,7 +937,7 @@ size_t shape_key(const rh_ctx* c, int which)
         for (size_t v : {(size_t)B.ns, (size_t)B.nmax, (size_t)B.ld, (size_t)B.lds, (size_t)B.tab, (size_t)B.seq, (size_t)B.n,
                          (size_t)B.f5i, (size_t)B.bp, (size_t)B.up, (size_t)c->d_bad, (size_t)c->d_mclogz, (size_t)c->lin_w, (size_t)c->lin_w_in,
                          (size_t)c->lin_bs, (size_t)B.tri_stride, (size_t)c->far_mfma, (size_t)c->max_w, (size_t)c->d_gaps,
-                         (size_t)c->d_hplen, (size_t)B.allow, (size_t)B.pk, (size_t)c->far_pk})
+                         (size_t)c->d_hplen, (size_t)B.allow, (size_t)B.pk, (size_t)c->far_pk, (size_t)B.rowp, (size_t)c->lookahead})
             h = mix(h, v);
     } else {
         const DxLinBatch& X = c->dxl;
@@ -1168,6 +1184,7 @@ rh_ctx* rh_create(int device, int model, const char* param_file)
     if (const char* e = std::getenv("RH_FAR_MFMA")) c->far_mfma = std::atoi(e) != 0;
     if (const char* e = std::getenv("RH_EXP_NOFAR")) c->exp_nofar = std::atoi(e) != 0;
     if (const char* e = std::getenv("RH_FAR_PK")) c->far_pk = std::atoi(e) != 0;
+    if (const char* e = std::getenv("RH_LOOKAHEAD")) c->lookahead = std::atoi(e) != 0;
     if (const char* e = std::getenv("RH_DX_W")) c->dx_w = std::atoi(e);
     bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&c->s_mc, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&c->s_dx, hipStreamNonBlocking) == hipSuccess &&
@@ -1201,7 +1218,7 @@ void rh_destroy(rh_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    void* bufs[] = {c->d_seq, c->d_n, c->d_mctab, c->d_f5, c->d_bp, c->d_up, c->d_dxtab, c->d_hp, c->d_logz, c->d_scal, c->d_mclogz, c->d_bad, c->d_cnt, c->d_cand, c->d_dxbad, c->d_zbar, c->d_gaps, c->d_coseq, c->d_con, c->d_cotab, c->d_pk, c->d_copk, c->d_cof5, c->d_cobp, c->d_cobad, c->d_allow, c->d_coallow, c->d_vlin, c->d_hplen, c->d_model, c->d_lin, c->d_dxlin, c->d_vienna};
+    void* bufs[] = {c->d_seq, c->d_n, c->d_mctab, c->d_f5, c->d_bp, c->d_up, c->d_dxtab, c->d_hp, c->d_logz, c->d_scal, c->d_mclogz, c->d_bad, c->d_cnt, c->d_cand, c->d_dxbad, c->d_zbar, c->d_gaps, c->d_coseq, c->d_con, c->d_cotab, c->d_pk, c->d_copk, c->d_rowp, c->d_cof5, c->d_cobp, c->d_cobad, c->d_allow, c->d_coallow, c->d_vlin, c->d_hplen, c->d_model, c->d_lin, c->d_dxlin, c->d_vienna};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (GraphSlot* g : {&c->g_in, &c->g_out, &c->g_dx}) if (g->exec) (void)hipGraphExecDestroy(g->exec);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
