@@ -155,8 +155,10 @@ __device__ __forceinline__ void filt_pair_any(int r, const double* __restrict__ 
 template <int W, int BS, int MODE>
 __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) RH_WPE_IN void lin_inside_diag(McBatch B, const LinModel* __restrict__ L, int d, double lam_d, int pin)
 {
+    constexpr bool LA = MODE == 1 || MODE == 3;                 // accumulates the look-ahead sums of diagonal d+1
+    constexpr int GS = MODE == 3 ? 63 : 64;                     // columns per group (MODE 3: one column of overlap, see below)
     constexpr int WR = MODE == 2 ? 1 : W;                       // wavefronts per group
-    constexpr int NQ = MODE == 1 ? 4 : 2;                       // per-wavefront partial sums
+    constexpr int NQ = LA ? 4 : 2;                              // per-wavefront partial sums
     constexpr int NSEG = 2 * ((kMaxSingle / 2 + W) / W);       // rows g = 0..15 and LAST-g, dealt round-robin to the wavefronts
     __shared__ double part[MODE == 2 ? 1 : NQ][WR][64];
     __shared__ double gbuf[MODE == 2 ? 1 : W][MODE == 2 ? 1 : NSEG][MODE == 2 ? 1 : 96];
@@ -164,9 +166,9 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) RH_WPE_IN void lin_inside_
     block_map(pin, &sq, &slot);
     if (sq >= B.ns) return;
     const int n = B.n[sq];
-    if (d > n - 1) return;
+    if (d > (MODE == 3 ? n : n - 1)) return;
     const int ncell = n - 1 - d > 0 ? n - 1 - d : 0;
-    const int ngroup = (ncell + 63) >> 6;
+    const int ngroup = (ncell + GS - 1) / GS;
     if (slot > ngroup) return;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // w is wave-uniform: scalar loads/addressing
     const int ld = B.ld;
@@ -179,23 +181,31 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) RH_WPE_IN void lin_inside_
     if (slot == ngroup) {
         // F5i[jj] = F5i[jj-1]*ext_unpaired + sum_{k<=jj-2} F5i[k]*FCA[k+1,jj-1]*ext_paired   (ipp:3692-3717)
         // all wavefronts: the column of FCA is an anti-diagonal of the diagonal-major table (one line per term)
-        const int jj = d + 1;
+        // MODE 3: F5i[d] and F5i[d+1] (rows <= d-1 of FCA: final before this launch); otherwise F5i[d+1]
         const double* __restrict__ fca = tab + L_FCA * ts;
-        double acc = 0.0;
-        for (int k = threadIdx.x; k <= jj - 2; k += 64 * WR) acc = fma(f5i[k], fca[(jj - 2 - k) * ld + (k + 1)], acc);
-        acc = wsum(acc);
-        if (lane == 0) part[0][w][0] = acc;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double t = 0.0;
+#pragma unroll 1
+        for (int jj = MODE == 3 ? d : d + 1; jj <= d + 1; jj++) {
+            if (jj < 1 || jj > n) continue;
+            double acc = 0.0;
+            for (int k = threadIdx.x; k <= jj - 2; k += 64 * WR) acc = fma(f5i[k], fca[(jj - 2 - k) * ld + (k + 1)], acc);
+            acc = wsum(acc);
+            if (lane == 0) part[0][w][0] = acc;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                double t = 0.0;
 #pragma unroll
-            for (int k = 0; k < WR; k++) t += part[0][k][0];
-            f5i[jj] = f5i[jj - 1] * L->w_eu + t * L->w_ep2;
+                for (int k = 0; k < WR; k++) t += part[0][k][0];
+                f5i[jj] = f5i[jj - 1] * L->w_eu + t * L->w_ep2;
+            }
+            __syncthreads();   // F5i[jj] is an operand of F5i[jj+1]
         }
         return;
     }
 
-    const int i = 1 + slot * 64 + lane, j = i + d;
+    // MODE 3: a group's 64 lanes hold 64 cells of diagonal d but only 63 of d+1 (lane l of d+1 needs lanes l and l+1 of d),
+    // so groups advance by 63 columns and the last column of a group's diagonal d is computed again, bit for bit, as the
+    // first of the next group's
+    const int i = 1 + slot * GS + lane, j = i + d;
     const bool valid = i <= ncell;
     int s_im1 = 4, s_i = 4, s_ip1 = 4, s_j = 4, s_jp1 = 4, s_jp2 = 4;
     if (valid) { s_im1 = s[i - 1]; s_i = s[i]; s_ip1 = s[i + 1]; s_j = s[j]; s_jp1 = s[j + 1]; s_jp2 = s[j + 2]; }
@@ -207,6 +217,34 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) RH_WPE_IN void lin_inside_
     const int idd = 25 * (5 * s_jp1 + s_jp2) + 5 * s_i + s_im1;     // (j+1,i-1) as enclosed pair
     double e_tjb = 0, e_tja = 0, e_tst = 0, e_bp = 0, e_tjbd = 0, e_tjad = 0, e_n01 = 0, e_n10 = 0, e_n11 = 0;
     double o_x01 = 0, o_x10 = 0, o_x11 = 0, o_fc = 0, o_fca = 0, o_fm1 = 0, o_fm = 0;
+    // MODE 3: the same for cell (i, j+1) of diagonal d+1, which wavefront 0 finishes after diagonal d
+    const int d1 = d + 1;
+    const bool valid1 = LA && i <= n - 1 - d1 && (MODE != 3 || lane < 63);
+    double n_tjb = 0, n_tja = 0, n_tst = 0, n_bp = 0, n_tjbd = 0, n_tjad = 0, n_n01 = 0, n_n10 = 0, n_n11 = 0;
+    double n_x01 = 0, n_x10 = 0, n_x11 = 0, n_fc = 0, n_fca = 0, n_a1 = 0, n_bd = 0, n_far = 0;
+    bool pairable1 = false;
+    if constexpr (MODE == 3) {
+        if (w == 0 && valid1) {
+            const int s_jp3 = s[j + 3];
+            pairable1 = pairs(s_i, s_jp2);
+            const int ix = 25 * (5 * s_i + s_ip1) + 5 * s_jp2 + s_jp1, id = 25 * (5 * s_jp2 + s_jp3) + 5 * s_i + s_im1;
+            n_tjb = L->TJB[ix]; n_tja = L->TJA[ix]; n_tst = L->TST[ix]; n_bp = L->E_bp[s_i * 5 + s_jp2];
+            n_tjbd = L->TJB[id]; n_tjad = L->TJA[id];
+            n_n01 = L->E_b01[s_jp1]; n_n10 = L->E_b10[s_ip1]; n_n11 = L->E_11[s_ip1 * 5 + s_jp1];
+            if (d1 >= 3) {
+                const double* __restrict__ fcx = tab + L_FCX * ts;
+                n_x01 = fcx[(d1 - 3) * ld + i + 1];
+                n_x10 = fcx[(d1 - 3) * ld + i + 2];
+                if (d1 >= 4) n_x11 = fcx[(d1 - 4) * ld + i + 2];
+            }
+            if (d1 >= 2) {
+                n_fc = tab[L_FC * ts + (d1 - 2) * ld + i + 1];
+                n_fca = tab[L_FCA * ts + (d1 - 2) * ld + i + 1];
+                n_a1 = tab[L_FM1 * ts + ld + i];            // FM1[1][i]   (term m = 1 of FM2[i,d+1]; its partner FM[d][i+1] is computed below)
+                n_bd = tab[L_FM * ts + ld + i + d];         // FM[1][i+d]  (term m = d; its partner FM1[d][i] is computed below)
+            }
+        }
+    }
     if (w == 0 && valid) {
         e_tjb = L->TJB[idx]; e_tja = L->TJA[idx]; e_tst = L->TST[idx]; e_bp = L->E_bp[s_i * 5 + s_jp1];
         e_tjbd = L->TJB[idd]; e_tjad = L->TJA[idd];
@@ -231,6 +269,12 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) RH_WPE_IN void lin_inside_
         const int I = i / BS, J = j / BS;
         if (J - I >= 4) { kA = (I + 2) * BS; kB = (J - 1) * BS; }
     }
+    int kB1 = 0;                                  // the same for cell (i, j+1) of diagonal d+1 (kA1 = kA where far blocks exist)
+    if (LA && BS > 0) {
+        const int I = i / BS, J1 = (j + 1) / BS;
+        if (J1 - I >= 4) kB1 = (J1 - 1) * BS;
+    }
+    const int kA1 = kB1 > 0 ? (i / (BS > 0 ? BS : 1) + 2) * BS : 1 << 30;
     double acc2 = 0.0, accc = 0.0;
     if constexpr (MODE == 2) {
         // the look-ahead sums of the previous launch + the two terms that touch row d-1:  m = 1: FM1[1][i]*FM[d-1][i+1],
@@ -249,20 +293,12 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) RH_WPE_IN void lin_inside_
         }
     } else {
     // ---- FM2[i,d] = sum_{m=1}^{d-1} FM1[m][i] * FM[d-m][i+m]          (ipp:3384-3411)
-    double acc2n = 0.0, acccn = 0.0;              // MODE 1: the same sums of diagonal d+1 without the terms that touch row d
-    const int d1 = d + 1;
-    const bool valid1 = MODE == 1 && i <= n - 1 - d1;
-    int kB1 = 0;                                  // kA is the same for (i, j+1)
-    if (MODE == 1 && BS > 0) {
-        const int I = i / BS, J1 = (j + 1) / BS;
-        if (J1 - I >= 4) kB1 = (J1 - 1) * BS;
-    }
-    const int kA1 = kB1 > 0 ? (i / (BS > 0 ? BS : 1) + 2) * BS : 1 << 30;
+    double acc2n = 0.0, acccn = 0.0;              // look-ahead: the same sums of diagonal d+1 without the terms that touch row d
     {
         const int ic = valid ? i : (ncell > 0 ? ncell : 1);   // invalid lanes read the last valid cell's operands
         const double* __restrict__ fm1c = tab + L_FM1 * ts + ic;
         const double* __restrict__ fmc = tab + L_FM * ts + ic;
-        constexpr int UF = MODE == 1 ? 6 : 8;  // 2*UF (3*UF) row segments (512 B each) in flight per wavefront
+        constexpr int UF = LA ? 6 : 8;  // 2*UF (3*UF) row segments (512 B each) in flight per wavefront
         // uniform m-ranges that cover every lane's near set: [1, d-1], or its two ends when far blocks exist
         const bool split = BS > 0 && d - 1 > 4 * BS;
         const int lo0 = 1, hi0 = split ? 2 * BS : d - 1;
@@ -283,14 +319,14 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) RH_WPE_IN void lin_inside_
 #else
                     b[u] = fmc[(d - mc) * ld + mc];
 #endif
-                    if (MODE == 1) bn[u] = fmc[(d1 - mc) * ld + mc];   // FM[d+1-m][i+m]: row d-(m-1), final for m >= 2
+                    if (LA) bn[u] = fmc[(d1 - mc) * ld + mc];   // FM[d+1-m][i+m]: row d-(m-1), final for m >= 2
                 }
 #pragma unroll
                 for (int u = 0; u < UF; u++) {
                     const int mm = m + u * W, k = i + mm;
                     const bool ok = valid && mm <= hi && (k < kA || k >= kB);
                     acc2 = fma(ok ? a[u] : 0.0, b[u], acc2);
-                    if (MODE == 1) {
+                    if (LA) {
                         const bool ok1 = valid1 && mm <= hi && mm >= 2 && (k < kA1 || k >= kB1);
                         acc2n = fma(ok1 ? a[u] : 0.0, bn[u], acc2n);
                     }
@@ -308,10 +344,10 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) RH_WPE_IN void lin_inside_
 #ifdef RH_EXP_NOFILT
     if (d < 0) {
 #else
-    if (MODE == 1 ? d >= 1 : d >= 2) {
+    if (LA ? d >= 1 : d >= 2) {
 #endif
         const int tmax = d - 2 < kMaxSingle ? d - 2 : kMaxSingle;
-        const int i0 = 1 + slot * 64;
+        const int i0 = 1 + slot * GS;
         const double* __restrict__ fcx = tab + L_FCX * ts;
         // pass 1: stage every segment this wavefront filters.  Straight-line code: all row loads are issued back to
         // back (clamped addresses, no branches -- a branch per load makes the compiler wait for each load in turn), then
@@ -319,15 +355,15 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) RH_WPE_IN void lin_inside_
         double r0[NSEG], r1[NSEG];
         const int col0 = i0 + 1;                                  // lane k of a segment = column col0+k of the row
         const int c0 = col0 + lane < ld ? col0 + lane : ld - 1, c1 = col0 + 64 + (lane & 31) < ld ? col0 + 64 + (lane & 31) : ld - 1;
-        constexpr int HALF = MODE == 1 ? (kMaxSingle + 1) / 2 : kMaxSingle / 2;   // rows g and LAST-g share a wavefront
-        constexpr int LAST = MODE == 1 ? kMaxSingle + 1 : kMaxSingle;
-        const int rmax = MODE == 1 ? (d - 1 < LAST ? d - 1 : LAST) : tmax;        // last staged row index that exists
+        constexpr int HALF = LA ? (kMaxSingle + 1) / 2 : kMaxSingle / 2;   // rows g and LAST-g share a wavefront
+        constexpr int LAST = LA ? kMaxSingle + 1 : kMaxSingle;
+        const int rmax = LA ? (d - 1 < LAST ? d - 1 : LAST) : tmax;        // last staged row index that exists
 #pragma unroll
         for (int q = 0; q < NSEG; q++) {
             const int g = w + (q >> 1) * W;
             const int t = (q & 1) ? LAST - g : g;
             const bool on = g <= HALF && !((q & 1) && t == g) && t <= rmax;   // wave-uniform
-            const int srow = MODE == 1 ? d - 1 - t : d - 2 - t;
+            const int srow = LA ? d - 1 - t : d - 2 - t;
             const double* __restrict__ row = fcx + (on ? srow : 0) * ld;
             r0[q] = row[c0];
             r1[q] = row[c1];
@@ -346,7 +382,7 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) RH_WPE_IN void lin_inside_
             const int t = (q & 1) ? LAST - g : g;
             const bool on = g <= HALF && !((q & 1) && t == g) && t <= rmax;
             if (!on) continue;
-            if constexpr (MODE == 1) {
+            if constexpr (LA) {
                 double sa, sb;
                 filt_pair_any(t, L->shape_w + (t > 0 ? (t - 1) * t / 2 : 0), L->shape_w + (t <= kMaxSingle ? t * (t + 1) / 2 : 0), &gbuf[w][q][lane], sa, sb);
                 accc += sa;
@@ -357,7 +393,8 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) RH_WPE_IN void lin_inside_
         }
         if (!pairable) accc = 0.0;
     }
-    if constexpr (MODE == 1) { part[2][w][lane] = acc2n; part[3][w][lane] = acccn; }
+    if constexpr (LA) { part[2][w][lane] = acc2n; part[3][w][lane] = acccn; }
+    if constexpr (MODE == 3) { if (w == 0 && valid1 && BS > 0 && kB1 > 0) n_far = tab[L_FM2F * ts + d1 * ld + i]; }
     }
 
     if constexpr (MODE != 2) {
@@ -374,7 +411,7 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) RH_WPE_IN void lin_inside_
             }
         }
     }
-    if (w != 0 || !valid) return;
+    if (w != 0 || (MODE != 3 && !valid)) return;
     double fm2 = acc2, g = accc;
     if constexpr (MODE != 2) {
         fm2 = 0.0; g = 0.0;
@@ -394,11 +431,47 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) RH_WPE_IN void lin_inside_
         fm1v = o_fca * L->w_mp2 + o_fm1 * L->w_mu;
         fmv = fm2 + o_fm * L->w_mu + fm1v;
     }
-    tab[L_FC * ts + at] = fc;
-    tab[L_FCX * ts + at] = fc * e_bp * e_tjbd;
-    tab[L_FCA * ts + at] = fc * e_bp * e_tjad;
-    tab[L_FM1 * ts + at] = fm1v;
-    tab[L_FM * ts + at] = fmv;
+    if (MODE != 3 || valid) {
+        tab[L_FC * ts + at] = fc;
+        tab[L_FCX * ts + at] = fc * e_bp * e_tjbd;
+        tab[L_FCA * ts + at] = fc * e_bp * e_tjad;
+        tab[L_FM1 * ts + at] = fm1v;
+        tab[L_FM * ts + at] = fmv;
+    }
+    if constexpr (MODE == 3) {
+        // ---- diagonal d+1, cell (i, j+1): look-ahead sums + the two FM2 terms that touch row d, whose row-d factors are in
+        // this wavefront's registers (lane l: column i, lane l+1: column i+1)
+        const double fm_right = __shfl_down(valid ? fmv : 0.0, 1, 64);     // FM [d][i+1]
+        const double fm1_right = __shfl_down(valid ? fm1v : 0.0, 1, 64);   // FM1[d][i+1]
+        if (!valid1) return;
+        double fm2n = 0.0, gn = 0.0;
+#pragma unroll
+        for (int k = 0; k < W; k++) { fm2n += part[2][k][lane]; gn += part[3][k][lane]; }
+        if (d1 >= 2) {
+            const int k1 = i + 1, k2 = i + d;
+            if (k1 < kA1 || k1 >= kB1) fm2n = fma(n_a1, fm_right, fm2n);                 // m = 1
+            if (d1 >= 3 && (k2 < kA1 || k2 >= kB1)) fm2n = fma(fm1v, n_bd, fm2n);          // m = d
+        }
+        fm2n += n_far;
+        double fcn = 0.0;
+        if (pairable1) {
+            const double sp = L->w01 * n_n01 * n_x01 + L->w10 * n_n10 * n_x10 + L->w11 * n_n11 * n_x11;
+            const double hp = d1 >= 3 ? lam_d * L->lam * L->E_hairpin[d1 < 30 ? d1 : 30] : 0.0;
+            const double st = n_fc * L->lam2 * n_tst;
+            fcn = n_tjb * (gn + sp + hp) + st + fm2n * n_tja * L->e_mpmb;
+        }
+        double fm1n = 0.0, fmn = 0.0;
+        if (d1 >= 2) {
+            fm1n = n_fca * L->w_mp2 + fm1_right * L->w_mu;
+            fmn = fm2n + fmv * L->w_mu + fm1n;
+        }
+        const size_t at1 = d1 * ld + i;
+        tab[L_FC * ts + at1] = fcn;
+        tab[L_FCX * ts + at1] = fcn * n_bp * n_tjbd;
+        tab[L_FCA * ts + at1] = fcn * n_bp * n_tjad;
+        tab[L_FM1 * ts + at1] = fm1n;
+        tab[L_FM * ts + at1] = fmn;
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -618,5 +691,6 @@ RH_INST(8, 32) RH_INST(16, 32)
 #undef RH_INST
 template __global__ void lin_inside_diag<4, 16, 1>(McBatch, const LinModel*, int, double, int);   // look-ahead pair
 template __global__ void lin_inside_diag<4, 16, 2>(McBatch, const LinModel*, int, double, int);
+template __global__ void lin_inside_diag<4, 16, 3>(McBatch, const LinModel*, int, double, int);   // both diagonals in one launch
 
 }  // namespace rh

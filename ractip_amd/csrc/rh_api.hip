@@ -243,7 +243,8 @@ struct rh_ctx {
     int dx_w = 4;                  // wavefronts per 64-cell group of the linear duplex kernel
     int last_dx_path = 0;
     bool far_mfma = true;          // block products on v_mfma_f64_16x16x4_f64 (BS = 16); RH_FAR_MFMA=0: LDS/FMA kernel
-    bool lookahead = true;         // inside sweep in look-ahead pairs (lin_inside_diag MODE 1/2); RH_LOOKAHEAD=0: one full launch per diagonal
+    int lookahead = 2;             // inside sweep: 2 = two diagonals per launch (lin_inside_diag MODE 3), 1 = look-ahead pairs of launches
+                                   // (MODE 1/2), 0 = one full launch per diagonal; RH_LOOKAHEAD
     bool far_pk = true;            // ... on packed operand tiles (lin_pack_tiles + lin_far_*_pk); RH_FAR_PK=0: gather per product
     bool exp_nofar = false;        // RH_EXP_NOFAR=1: timing experiment only (block products skipped, results wrong)
     bool use_graphs = true;        // RH_NO_GRAPH=1 launches every kernel from the host instead
@@ -759,6 +760,21 @@ int launch_mc_lin(rh_ctx* c, int pin, int phase)
     const int last_block = BS > 0 ? (B.nmax - 1) / BS : 0;
     if (phase == 0) {
     hipLaunchKernelGGL(lin_init, dim3((B.ns + 63) / 64), dim3(64), 0, c->s_mc, B, bad);
+    if constexpr (W == 4 && BS == 16) {
+        if (c->lookahead == 2) {   // two diagonals per launch (lin_inside_diag MODE 3); the last launch may hold only F5i[nmax]
+            for (int d = 0; d <= B.nmax; d += 2) {
+                const int groups = (std::max(B.nmax - 1 - d, 0) + 62) / 63 + 1;
+                KLAUNCH(c, 0, (lin_inside_diag<4, 16, 3>), pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(64 * W), c->s_mc, B, c->d_lin, d,
+                        std::exp(-c->h_lin.s * d), pin);
+                c->n_launch[0]++;
+                if ((d + 2) % BS == 0) {
+                    const int D = (d + 2) / BS + 1;
+                    if (D >= 4 && D <= last_block) { c->n_launch[0] += far_inside_step(c, B, c->s_mc, D, last_block); c->n_far[0]++; }
+                }
+            }
+            return RH_OK;
+        }
+    }
     for (int d = 0; d <= B.nmax - 1; d++) {
         const int groups = (std::max(B.nmax - 1 - d, 0) + 63) / 64 + 1;
         if constexpr (W == 4 && BS == 16) {
@@ -1184,7 +1200,7 @@ rh_ctx* rh_create(int device, int model, const char* param_file)
     if (const char* e = std::getenv("RH_FAR_MFMA")) c->far_mfma = std::atoi(e) != 0;
     if (const char* e = std::getenv("RH_EXP_NOFAR")) c->exp_nofar = std::atoi(e) != 0;
     if (const char* e = std::getenv("RH_FAR_PK")) c->far_pk = std::atoi(e) != 0;
-    if (const char* e = std::getenv("RH_LOOKAHEAD")) c->lookahead = std::atoi(e) != 0;
+    if (const char* e = std::getenv("RH_LOOKAHEAD")) c->lookahead = std::atoi(e);
     if (const char* e = std::getenv("RH_DX_W")) c->dx_w = std::atoi(e);
     bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&c->s_mc, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&c->s_dx, hipStreamNonBlocking) == hipSuccess &&
