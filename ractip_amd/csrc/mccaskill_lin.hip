@@ -104,12 +104,14 @@ enum LinTable { L_FC = 0, L_FCX, L_FCA, L_FM1, L_FM, L_FCO, L_FCOX, L_FM2O, L_FM
 static_assert((int)L_COUNT <= (int)T_COUNT, "linear tables reuse the log-space table buffer");
 
 // F5i~[0] = 1, F5o~[n] = 1
-__global__ void lin_init(McBatch B, int* __restrict__ bad)
+__global__ void lin_init(McBatch B, const LinModel* __restrict__ L, int* __restrict__ bad)
 {
     const int sq = blockIdx.x * blockDim.x + threadIdx.x;
     if (sq >= B.ns) return;
     B.f5i[(size_t)sq * B.ld] = 1.0;
     B.f5o[(size_t)sq * B.ld + B.n[sq]] = 1.0;
+    // F5o~[n-1] = F5o~[n] * ext_unpaired (no pair fits): lin_outside_pair needs it before its first launch
+    if (B.n[sq] >= 2) B.f5o[(size_t)sq * B.ld + B.n[sq] - 1] = L->w_eu;
     bad[sq] = 0;
 }
 
@@ -217,35 +219,9 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) RH_WPE_IN void lin_inside_
     const int idd = 25 * (5 * s_jp1 + s_jp2) + 5 * s_i + s_im1;     // (j+1,i-1) as enclosed pair
     double e_tjb = 0, e_tja = 0, e_tst = 0, e_bp = 0, e_tjbd = 0, e_tjad = 0, e_n01 = 0, e_n10 = 0, e_n11 = 0;
     double o_x01 = 0, o_x10 = 0, o_x11 = 0, o_fc = 0, o_fca = 0, o_fm1 = 0, o_fm = 0;
-    // MODE 3: the same for cell (i, j+1) of diagonal d+1, which wavefront 0 finishes after diagonal d
     const int d1 = d + 1;
-    const bool valid1 = LA && i <= n - 1 - d1 && (MODE != 3 || lane < 63);
-    double n_tjb = 0, n_tja = 0, n_tst = 0, n_bp = 0, n_tjbd = 0, n_tjad = 0, n_n01 = 0, n_n10 = 0, n_n11 = 0;
-    double n_x01 = 0, n_x10 = 0, n_x11 = 0, n_fc = 0, n_fca = 0, n_a1 = 0, n_bd = 0, n_far = 0;
-    bool pairable1 = false;
-    if constexpr (MODE == 3) {
-        if (w == 0 && valid1) {
-            const int s_jp3 = s[j + 3];
-            pairable1 = pairs(s_i, s_jp2);
-            const int ix = 25 * (5 * s_i + s_ip1) + 5 * s_jp2 + s_jp1, id = 25 * (5 * s_jp2 + s_jp3) + 5 * s_i + s_im1;
-            n_tjb = L->TJB[ix]; n_tja = L->TJA[ix]; n_tst = L->TST[ix]; n_bp = L->E_bp[s_i * 5 + s_jp2];
-            n_tjbd = L->TJB[id]; n_tjad = L->TJA[id];
-            n_n01 = L->E_b01[s_jp1]; n_n10 = L->E_b10[s_ip1]; n_n11 = L->E_11[s_ip1 * 5 + s_jp1];
-            if (d1 >= 3) {
-                const double* __restrict__ fcx = tab + L_FCX * ts;
-                n_x01 = fcx[(d1 - 3) * ld + i + 1];
-                n_x10 = fcx[(d1 - 3) * ld + i + 2];
-                if (d1 >= 4) n_x11 = fcx[(d1 - 4) * ld + i + 2];
-            }
-            if (d1 >= 2) {
-                n_fc = tab[L_FC * ts + (d1 - 2) * ld + i + 1];
-                n_fca = tab[L_FCA * ts + (d1 - 2) * ld + i + 1];
-                n_a1 = tab[L_FM1 * ts + ld + i];            // FM1[1][i]   (term m = 1 of FM2[i,d+1]; its partner FM[d][i+1] is computed below)
-                n_bd = tab[L_FM * ts + ld + i + d];         // FM[1][i+d]  (term m = d; its partner FM1[d][i] is computed below)
-            }
-        }
-    }
-    if (w == 0 && valid) {
+    const bool valid1 = LA && i <= n - 1 - d1 && (MODE != 3 || lane < 63);   // cell (i, j+1) of diagonal d+1
+    if (MODE != 3 && w == 0 && valid) {   // (MODE 3 loads them after the term loops: two operand sets, see its epilogue)
         e_tjb = L->TJB[idx]; e_tja = L->TJA[idx]; e_tst = L->TST[idx]; e_bp = L->E_bp[s_i * 5 + s_jp1];
         e_tjbd = L->TJB[idd]; e_tjad = L->TJA[idd];
         e_n01 = L->E_b01[s_j]; e_n10 = L->E_b10[s_ip1]; e_n11 = L->E_11[s_ip1 * 5 + s_j];
@@ -394,7 +370,6 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) RH_WPE_IN void lin_inside_
         if (!pairable) accc = 0.0;
     }
     if constexpr (LA) { part[2][w][lane] = acc2n; part[3][w][lane] = acccn; }
-    if constexpr (MODE == 3) { if (w == 0 && valid1 && BS > 0 && kB1 > 0) n_far = tab[L_FM2F * ts + d1 * ld + i]; }
     }
 
     if constexpr (MODE != 2) {
@@ -411,42 +386,87 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) RH_WPE_IN void lin_inside_
             }
         }
     }
-    if (w != 0 || (MODE != 3 && !valid)) return;
-    double fm2 = acc2, g = accc;
-    if constexpr (MODE != 2) {
-        fm2 = 0.0; g = 0.0;
-#pragma unroll
-        for (int k = 0; k < W; k++) { fm2 += part[0][k][lane]; g += part[1][k][lane]; }
-    }
-
-    double fc = 0.0;
-    if (pairable) {
-        const double sp = L->w01 * e_n01 * o_x01 + L->w10 * e_n10 * o_x10 + L->w11 * e_n11 * o_x11;
-        const double hp = d >= 3 ? lam_d * L->E_hairpin[d < 30 ? d : 30] : 0.0;   // ScoreHairpin (ipp:2123-2152)
-        const double st = o_fc * L->lam2 * e_tst;                                  // stacking pair (ipp:3595)
-        fc = e_tjb * (g + sp + hp) + st + fm2 * e_tja * L->e_mpmb;                 // ipp:3573-3622
-    }
-    double fm1v = 0.0, fmv = 0.0;
-    if (d >= 2) {                                                                  // ipp:3641-3688
-        fm1v = o_fca * L->w_mp2 + o_fm1 * L->w_mu;
-        fmv = fm2 + o_fm * L->w_mu + fm1v;
-    }
-    if (MODE != 3 || valid) {
-        tab[L_FC * ts + at] = fc;
-        tab[L_FCX * ts + at] = fc * e_bp * e_tjbd;
-        tab[L_FCA * ts + at] = fc * e_bp * e_tjad;
-        tab[L_FM1 * ts + at] = fm1v;
-        tab[L_FM * ts + at] = fmv;
-    }
     if constexpr (MODE == 3) {
-        // ---- diagonal d+1, cell (i, j+1): look-ahead sums + the two FM2 terms that touch row d, whose row-d factors are in
-        // this wavefront's registers (lane l: column i, lane l+1: column i+1)
-        const double fm_right = __shfl_down(valid ? fmv : 0.0, 1, 64);     // FM [d][i+1]
-        const double fm1_right = __shfl_down(valid ? fm1v : 0.0, 1, 64);   // FM1[d][i+1]
-        if (!valid1) return;
+        // wavefront 0 finishes diagonal d and hands FM / FM1 of its row to wavefront 1 through LDS; wavefront 1 meanwhile loads
+        // the epilogue operands of diagonal d+1 (cell (i, j+1)), whose two FM2 terms that touch row d need lane l and l+1 of
+        // it.  (Two wavefronts: each holds one operand set -- in one wavefront the two sets cost ~50 VGPRs and a wavefront of
+        // occupancy; operands are loaded after the term loops for the same reason.)
+        if (w > 1) return;
+        __shared__ double hand[2][64];
+        double n_tjb = 0, n_tja = 0, n_tst = 0, n_bp = 0, n_tjbd = 0, n_tjad = 0, n_n01 = 0, n_n10 = 0, n_n11 = 0;
+        double n_x01 = 0, n_x10 = 0, n_x11 = 0, n_fc = 0, n_fca = 0, n_a1 = 0, n_bd = 0, n_far = 0;
         double fm2n = 0.0, gn = 0.0;
+        bool pairable1 = false;
+        if (w == 0) {
+            if (valid) {
+                e_tjb = L->TJB[idx]; e_tja = L->TJA[idx]; e_tst = L->TST[idx]; e_bp = L->E_bp[s_i * 5 + s_jp1];
+                e_tjbd = L->TJB[idd]; e_tjad = L->TJA[idd];
+                e_n01 = L->E_b01[s_j]; e_n10 = L->E_b10[s_ip1]; e_n11 = L->E_11[s_ip1 * 5 + s_j];
+                if (d >= 3) {
+                    const double* __restrict__ fcx = tab + L_FCX * ts;
+                    o_x01 = fcx[(d - 3) * ld + i + 1];
+                    o_x10 = fcx[(d - 3) * ld + i + 2];
+                    if (d >= 4) o_x11 = fcx[(d - 4) * ld + i + 2];
+                }
+                if (d >= 2) {
+                    o_fc = tab[L_FC * ts + (d - 2) * ld + i + 1];
+                    o_fca = tab[L_FCA * ts + (d - 2) * ld + i + 1];
+                    o_fm1 = tab[L_FM1 * ts + (d - 1) * ld + i + 1];
+                    o_fm = tab[L_FM * ts + (d - 1) * ld + i];
+                }
+            }
+            double fm2 = 0.0, g = 0.0;
 #pragma unroll
-        for (int k = 0; k < W; k++) { fm2n += part[2][k][lane]; gn += part[3][k][lane]; }
+            for (int k = 0; k < W; k++) { fm2 += part[0][k][lane]; g += part[1][k][lane]; }
+            double fc = 0.0;
+            if (pairable) {
+                const double sp = L->w01 * e_n01 * o_x01 + L->w10 * e_n10 * o_x10 + L->w11 * e_n11 * o_x11;
+                const double hp = d >= 3 ? lam_d * L->E_hairpin[d < 30 ? d : 30] : 0.0;   // ScoreHairpin (ipp:2123-2152)
+                const double st = o_fc * L->lam2 * e_tst;                                  // stacking pair (ipp:3595)
+                fc = e_tjb * (g + sp + hp) + st + fm2 * e_tja * L->e_mpmb;                 // ipp:3573-3622
+            }
+            double fm1v = 0.0, fmv = 0.0;
+            if (valid && d >= 2) {                                                         // ipp:3641-3688
+                fm1v = o_fca * L->w_mp2 + o_fm1 * L->w_mu;
+                fmv = fm2 + o_fm * L->w_mu + fm1v;
+            }
+            if (valid) {
+                tab[L_FC * ts + at] = fc;
+                tab[L_FCX * ts + at] = fc * e_bp * e_tjbd;
+                tab[L_FCA * ts + at] = fc * e_bp * e_tjad;
+                tab[L_FM1 * ts + at] = fm1v;
+                tab[L_FM * ts + at] = fmv;
+            }
+            hand[0][lane] = fmv; hand[1][lane] = fm1v;
+        } else {
+            if (valid1) {
+                const int s_jp3 = s[j + 3];
+                pairable1 = pairs(s_i, s_jp2);
+                const int ix = 25 * (5 * s_i + s_ip1) + 5 * s_jp2 + s_jp1, id = 25 * (5 * s_jp2 + s_jp3) + 5 * s_i + s_im1;
+                n_tjb = L->TJB[ix]; n_tja = L->TJA[ix]; n_tst = L->TST[ix]; n_bp = L->E_bp[s_i * 5 + s_jp2];
+                n_tjbd = L->TJB[id]; n_tjad = L->TJA[id];
+                n_n01 = L->E_b01[s_jp1]; n_n10 = L->E_b10[s_ip1]; n_n11 = L->E_11[s_ip1 * 5 + s_jp1];
+                if (d1 >= 3) {
+                    const double* __restrict__ fcx = tab + L_FCX * ts;
+                    n_x01 = fcx[(d1 - 3) * ld + i + 1];
+                    n_x10 = fcx[(d1 - 3) * ld + i + 2];
+                    if (d1 >= 4) n_x11 = fcx[(d1 - 4) * ld + i + 2];
+                }
+                if (d1 >= 2) {
+                    n_fc = tab[L_FC * ts + (d1 - 2) * ld + i + 1];
+                    n_fca = tab[L_FCA * ts + (d1 - 2) * ld + i + 1];
+                    n_a1 = tab[L_FM1 * ts + ld + i];            // FM1[1][i]   (term m = 1 of FM2[i,d+1]; its partner is FM[d][i+1])
+                    n_bd = tab[L_FM * ts + ld + i + d];         // FM[1][i+d]  (term m = d; its partner is FM1[d][i])
+                }
+                if (BS > 0 && kB1 > 0) n_far = tab[L_FM2F * ts + d1 * ld + i];
+            }
+#pragma unroll
+            for (int k = 0; k < W; k++) { fm2n += part[2][k][lane]; gn += part[3][k][lane]; }
+        }
+        __syncthreads();   // wavefronts 0 and 1 (the others have left)
+        if (w == 0 || !valid1) return;
+        const double fmv = hand[0][lane], fm1v = hand[1][lane];                    // FM[d][i],   FM1[d][i]
+        const double fm_right = hand[0][lane + 1], fm1_right = hand[1][lane + 1];  // FM[d][i+1], FM1[d][i+1]   (lane <= 62)
         if (d1 >= 2) {
             const int k1 = i + 1, k2 = i + d;
             if (k1 < kA1 || k1 >= kB1) fm2n = fma(n_a1, fm_right, fm2n);                 // m = 1
@@ -471,6 +491,32 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) RH_WPE_IN void lin_inside_
         tab[L_FCA * ts + at1] = fcn * n_bp * n_tjad;
         tab[L_FM1 * ts + at1] = fm1n;
         tab[L_FM * ts + at1] = fmn;
+    } else {
+    if (w != 0 || !valid) return;
+    double fm2 = acc2, g = accc;
+    if constexpr (MODE != 2) {
+        fm2 = 0.0; g = 0.0;
+#pragma unroll
+        for (int k = 0; k < W; k++) { fm2 += part[0][k][lane]; g += part[1][k][lane]; }
+    }
+
+    double fc = 0.0;
+    if (pairable) {
+        const double sp = L->w01 * e_n01 * o_x01 + L->w10 * e_n10 * o_x10 + L->w11 * e_n11 * o_x11;
+        const double hp = d >= 3 ? lam_d * L->E_hairpin[d < 30 ? d : 30] : 0.0;   // ScoreHairpin (ipp:2123-2152)
+        const double st = o_fc * L->lam2 * e_tst;                                  // stacking pair (ipp:3595)
+        fc = e_tjb * (g + sp + hp) + st + fm2 * e_tja * L->e_mpmb;                 // ipp:3573-3622
+    }
+    double fm1v = 0.0, fmv = 0.0;
+    if (d >= 2) {                                                                  // ipp:3641-3688
+        fm1v = o_fca * L->w_mp2 + o_fm1 * L->w_mu;
+        fmv = fm2 + o_fm * L->w_mu + fm1v;
+    }
+    tab[L_FC * ts + at] = fc;
+    tab[L_FCX * ts + at] = fc * e_bp * e_tjbd;
+    tab[L_FCA * ts + at] = fc * e_bp * e_tjad;
+    tab[L_FM1 * ts + at] = fm1v;
+    tab[L_FM * ts + at] = fmv;
     }
 }
 
@@ -669,6 +715,340 @@ __global__ __launch_bounds__(64 * W) RH_WPE_OUT void lin_outside_diag(McBatch B,
     B.bp[(size_t)sq * B.tri_stride + tri_off(n, i) + (j + 1)] = p;
 }
 
+// ---------------------------------------------------------------------------------
+// outside, diagonals d and d-1 in one launch (the counterpart of lin_inside_diag MODE 3).  Cell (i, j-1) of diagonal d-1
+// reads row d only through the two e = 1 terms of its multibranch sums and two epilogue operands, at columns i and i-1:
+// everything else is final before the launch and is the data diagonal d reads (FM1 row e serves both near sums, the FM2o /
+// FM rows are the same cache lines one column on, the filter of length t+1 runs over the staged row of the filter of
+// length t).  All wavefronts accumulate both diagonals' sums; wavefront 0 finishes d, then d-1 with lane l-1's row-d values
+// by shuffle.  Lane 0 has no left neighbour: groups advance by 63 columns and lane 0 finishes only diagonal d (except in
+// group 0, whose column 0 does not exist); the overlapping column of diagonal d is computed twice, bit for bit.
+// Last group: F5o~[k], k = khi (= d) .. d-1: diagonal d-1 needs F5o[>= d+1], which the PREVIOUS launch has to leave behind
+// (lin_init before the first one).
+template <int R>
+__device__ __forceinline__ void filt_pair_rev(const double* __restrict__ wA, const double* __restrict__ wB, const double* seg, double& sa, double& sb)
+{   // x_k = seg[R-k];  sa = sum_{k<R} wA[k]*x_k (filter t = R-1 of diagonal d), sb = sum_{k<=R} wB[k]*x_k (filter t = R of d-1; none for R = 31)
+    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+#pragma unroll
+    for (int k = 0; k <= R; k += 2) {
+        const double x0 = seg[R - k];
+        if (k < R) a0 = fma(wA[k], x0, a0);
+        if (R <= kMaxSingle) b0 = fma(wB[k], x0, b0);
+        if (k + 1 <= R) {
+            const double x1 = seg[R - k - 1];
+            if (k + 1 < R) a1 = fma(wA[k + 1], x1, a1);
+            if (R <= kMaxSingle) b1 = fma(wB[k + 1], x1, b1);
+        }
+    }
+    sa = a0 + a1;
+    sb = b0 + b1;
+}
+__device__ __forceinline__ void filt_pair_rev_any(int r, const double* __restrict__ wA, const double* __restrict__ wB, const double* seg, double& sa, double& sb)
+{
+    switch (r) {
+#define X(T) case T: filt_pair_rev<T>(wA, wB, seg, sa, sb); return;
+        RH_T_CASES(X) X(31)
+#undef X
+    }
+    sa = 0.0; sb = 0.0;
+}
+
+template <int W, int BS>
+__global__ __launch_bounds__(64 * W) RH_WPE_OUT void lin_outside_pair(McBatch B, const LinModel* __restrict__ L, int d, int khi, int pin, int* __restrict__ bad)
+{
+    constexpr int NSEG = 2 * ((kMaxSingle / 2 + W) / W);
+    __shared__ double part[6][W][64];
+    __shared__ double gbuf[W][NSEG][96];
+    int sq, slot;
+    block_map(pin, &sq, &slot);
+    if (sq >= B.ns) return;
+    const int n = B.n[sq];
+    const int d1 = d - 1;
+    const int ncell = n - 1 - d > 0 ? n - 1 - d : 0;            // cells of diagonal d; diagonal d-1 has one more (if it exists)
+    const int ncell1 = d1 >= 0 && n - 1 - d1 > 0 ? n - 1 - d1 : 0;
+    if (n - 1 - d1 < 0) return;                                // d-1 > n-1: neither cells nor an F5o entry
+    const int ncol = ncell > ncell1 ? ncell : ncell1;            // columns 1..ncol hold a cell of either diagonal
+    const int ngroup = ncol > 0 ? (ncol > 1 ? (ncol - 1 + 62) / 63 : 1) : 0;   // group g: columns 1+63g .. 64+63g
+    if (slot > ngroup) return;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int ld = B.ld;
+    const size_t ts = B.tab_stride;
+    const uint8_t* __restrict__ s = B.seq + (size_t)sq * B.lds;
+    double* __restrict__ tab = B.tab + (size_t)sq * B.seq_stride;
+    const double* __restrict__ f5i = B.f5i + sq * ld;
+    double* __restrict__ f5o = B.f5o + sq * ld;
+
+    if (slot == ngroup) {
+        // F5o[k] = F5o[k+1]*ext_unpaired + sum_{jj>=k+2} F5o[jj]*FCA[k+1,jj-1]*ext_paired   (ipp:3751-3780, pulled)
+#pragma unroll 1
+        for (int k = khi; k >= d1 && k >= 1; k--) {
+            if (k > n - 1) continue;
+            const double* __restrict__ fca = tab + L_FCA * ts + (k + 1);
+            double acc = 0.0;
+            for (int jj = k + 2 + threadIdx.x; jj <= n; jj += 64 * W) acc = fma(f5o[jj], fca[(jj - 2 - k) * ld], acc);
+            acc = wsum(acc);
+            if (lane == 0) part[0][w][0] = acc;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                double t = 0.0;
+#pragma unroll
+                for (int q = 0; q < W; q++) t += part[0][q][0];
+                f5o[k] = f5o[k + 1] * L->w_eu + t * L->w_ep2;
+            }
+            __syncthreads();   // F5o[k] is an operand of F5o[k-1]
+        }
+        return;
+    }
+
+    const int i0 = 1 + slot * 63;
+    const int i = i0 + lane, j = i + d, j1 = j - 1;
+    const bool valid = i <= ncell;                                       // cell (i, j)   of diagonal d
+    const bool valid1 = i <= ncell1 && (lane > 0 || slot == 0);          // cell (i, j-1) of diagonal d-1
+    const bool any = valid || valid1;
+    int s_im1 = 4, s_i = 4, s_ip1 = 4, s_jm1 = 4, s_j = 4, s_jp1 = 4, s_jp2 = 4;
+    if (any) {
+        s_im1 = s[i - 1]; s_i = s[i]; s_ip1 = s[i + 1]; s_j = s[j]; s_jp1 = s[j + 1];
+        if (valid) s_jp2 = s[j + 2];
+        if (j - 1 >= 0) s_jm1 = s[j - 1];
+    }
+    const bool pairable = valid && pairs(s_i, s_jp1);
+    const bool pairable1 = valid1 && pairs(s_i, s_j);
+    const bool guard_m = d >= 2, guard_m1 = d1 >= 2;
+
+    double accm = 0.0, acc1 = 0.0, accc = 0.0;      // diagonal d
+    double accmn = 0.0, acc1n = 0.0, acccn = 0.0;   // diagonal d-1 without its e = 1 terms
+    // per-lane term limits (block structure as in lin_outside_diag)
+    int mineA = valid ? i - 1 : 0, mineA1 = valid1 ? i - 1 : 0;
+    if (BS > 0) { const int lim = i - (i / (BS > 0 ? BS : 1) - 1) * BS; mineA = mineA < lim ? mineA : lim; mineA1 = mineA1 < lim ? mineA1 : lim; }
+    int mineB = valid ? n - 1 - j : 0, mineB1 = valid1 ? n - 1 - j1 : 0;
+    if (BS > 0) {
+        const int lim = (j / (BS > 0 ? BS : 1) + 2) * BS - 1 - j, lim1 = (j1 / (BS > 0 ? BS : 1) + 2) * BS - 1 - j1;
+        mineB = mineB < lim ? mineB : lim; mineB1 = mineB1 < lim1 ? mineB1 : lim1;
+    }
+    if (!guard_m) { mineA = 0; mineB = 0; }
+    if (!guard_m1) { mineA1 = 0; mineB1 = 0; }
+    if (guard_m1) {   // guard_m implies guard_m1
+        constexpr int UO = 4;
+        // FMo[i,d] += FM2o[d+e][i-e] * FM1[e][i-e], e = 1..i-1            (ipp:4046-4064, pulled)
+        // with blocks: only i' = i-e in blocks I-1, I are streamed; blocks <= I-2 come from FMOF
+        {
+            const int i_last = ncell1 < i0 + 63 ? ncell1 : i0 + 63;
+            const int emax = BS > 0 ? (i_last - 1 < 2 * BS ? i_last - 1 : 2 * BS) : i_last - 1;
+            const double* __restrict__ x = tab + L_FM2O * ts + i;
+            const double* __restrict__ y = tab + L_FM1 * ts + i;
+            for (int e = 1 + w; e <= emax; e += UO * W) {
+                double xv[UO], xn[UO], yv[UO];
+#pragma unroll
+                for (int u = 0; u < UO; u++) {
+                    const int ee = e + u * W;
+                    const bool ok = ee <= mineA, ok1 = ee <= mineA1 && ee >= 2;
+                    xv[u] = ok ? x[(d + ee) * ld - ee] : 0.0;
+                    xn[u] = ok1 ? x[(d1 + ee) * ld - ee] : 0.0;
+                    yv[u] = (ok || ok1) ? y[ee * ld - ee] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < UO; u++) { accm = fma(xv[u], yv[u], accm); accmn = fma(xn[u], yv[u], accmn); }
+            }
+            if (BS > 0 && w == 0) {
+                if (valid && guard_m) accm += tab[L_FMOF * ts + d * ld + i];
+                if (valid1) accmn += tab[L_FMOF * ts + d1 * ld + i];
+            }
+        }
+        // FM1o[i,d] += FM2o[d+e][i] * FM[e][i+d], e = 1..n-1-j; blocks >= J+2 come from FM1OF
+        {
+            const int emax_all = n - 1 - (i0 + d1);
+            const int emax = BS > 0 ? (emax_all < 2 * BS ? emax_all : 2 * BS) : emax_all;
+            const double* __restrict__ x = tab + L_FM2O * ts + i;
+            const double* __restrict__ y = tab + L_FM * ts + j;
+            for (int e = 1 + w; e <= emax; e += UO * W) {
+                double xv[UO], xn[UO], yv[UO], yn[UO];
+#pragma unroll
+                for (int u = 0; u < UO; u++) {
+                    const int ee = e + u * W;
+                    const bool ok = ee <= mineB, ok1 = ee <= mineB1 && ee >= 2;
+                    xv[u] = ok ? x[(d + ee) * ld] : 0.0;
+                    yv[u] = ok ? y[ee * ld] : 0.0;
+                    xn[u] = ok1 ? x[(d1 + ee) * ld] : 0.0;
+                    yn[u] = ok1 ? y[ee * ld - 1] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < UO; u++) { acc1 = fma(xv[u], yv[u], acc1); acc1n = fma(xn[u], yn[u], acc1n); }
+            }
+            if (BS > 0 && w == 0) {
+                if (valid && guard_m) acc1 += tab[L_FM1OF * ts + d * ld + i];
+                if (valid1) acc1n += tab[L_FM1OF * ts + d1 * ld + i];
+            }
+        }
+    }
+    {   // enclosing single-branch loops: sum_t sum_l1 w(l1,t-l1) * FCoX[d+2+t][i-1-l1]       (ipp:4004-4024, pulled)
+        // staged row r = 0..31 is table row d+1+r: filter t = r-1 of diagonal d over columns [i-r, i-1], filter t = r of
+        // diagonal d-1 over [i-1-r, i-1]; a tap is valid when its column lies in [1, n-1-row] of the source row: the
+        // segment is zero-filled outside that range while it is staged, so the taps themselves need no mask
+        const int room1 = n - 3 - d;  // source row d+1+r <= n-2
+        if (room1 >= 0) {
+            constexpr int LAST = kMaxSingle + 1, HALF = (kMaxSingle + 1) / 2;
+            const int rmax = room1 < LAST ? room1 : LAST;
+            const double* __restrict__ fcox = tab + L_FCOX * ts;
+#pragma unroll
+            for (int q = 0; q < NSEG; q++) {
+                const int g = w + (q >> 1) * W;
+                const int r = (q & 1) ? LAST - g : g;
+                const bool on = g <= HALF && r <= rmax;   // wave-uniform (LAST is odd: g never meets LAST-g)
+                if (on) {
+                    const int col0 = i0 - 1 - r;                  // segment column of lane k: col0+k; window of cell i: [i-1-r, i-1]
+                    const double* __restrict__ row = fcox + (d + 1 + r) * ld;
+                    const int cmax = n - 1 - (d + 1 + r);         // last interior column of that row
+                    const int c = col0 + lane;
+                    gbuf[w][q][lane] = (c >= 1 && c <= cmax) ? row[c] : 0.0;
+                    const int c2 = col0 + 64 + lane;
+                    if (lane < 32) gbuf[w][q][64 + lane] = (c2 >= 1 && c2 <= cmax) ? row[c2] : 0.0;
+                }
+            }
+#pragma unroll 1
+            for (int q = 0; q < NSEG; q++) {
+                const int g = w + (q >> 1) * W;
+                const int r = (q & 1) ? LAST - g : g;
+                if (!(g <= HALF && r <= rmax)) continue;
+                double sa, sb;
+                filt_pair_rev_any(r, L->shape_w + (r > 0 ? (r - 1) * r / 2 : 0), L->shape_w + (r <= kMaxSingle ? r * (r + 1) / 2 : 0), &gbuf[w][q][lane], sa, sb);
+                accc += sa;
+                acccn += sb;
+            }
+        }
+    }
+    part[0][w][lane] = accm;  part[1][w][lane] = acc1;  part[2][w][lane] = accc;
+    part[3][w][lane] = accmn; part[4][w][lane] = acc1n; part[5][w][lane] = acccn;
+    __syncthreads();
+    if (w > 1) return;
+    // wavefront 0 finishes diagonal d and hands its row-d values to wavefront 1 through LDS; wavefront 1 meanwhile loads the
+    // epilogue operands of diagonal d-1.  (Two wavefronts: each holds one operand set -- in one wavefront the two sets cost
+    // ~90 VGPRs and half the occupancy; operands are loaded after the term loops for the same reason.)
+    __shared__ double hand[3][64];
+    const size_t at = d * ld + i;
+    const double o_f5i = any ? f5i[i - 1] : 0.0, o_z = any ? f5i[n] : 1.0;
+    double n_tjb = 0, n_tja = 0, n_tst = 0, n_bp = 0, n_tjbd = 0, n_tjad = 0, n_n01 = 0, n_n10 = 0, n_n11 = 0;
+    double n_f5o = 0, n_fm1o_up = 0, n_fco_up = 0, n_x01 = 0, n_x10 = 0, n_x11 = 0, n_fc = 0, n_y1 = 0, n_y2 = 0;
+    double smn = 0.0, s1n = 0.0, gn = 0.0;
+    if (w == 0) {
+        double e_tjb = 0, e_tja = 0, e_tst = 0, e_bp = 0, e_tjbd = 0, e_tjad = 0, e_n01 = 0, e_n10 = 0, e_n11 = 0;
+        double o_fmo = 0, o_fm1o = 0, o_f5o = 0, o_fm1o_up = 0, o_fco_up = 0, o_x01 = 0, o_x10 = 0, o_x11 = 0, o_fc = 0;
+        if (valid) {
+            const bool up_ok = i - 1 >= 1 && j + 1 <= n - 1;  // the cell (i-1, j+1) is interior
+            const int idx = 25 * (5 * s_i + s_ip1) + 5 * s_jp1 + s_j;
+            const int idd = 25 * (5 * s_jp1 + s_jp2) + 5 * s_i + s_im1;
+            e_tjb = L->TJB[idx]; e_tja = L->TJA[idx]; e_bp = L->E_bp[s_i * 5 + s_jp1];
+            e_tjbd = L->TJB[idd]; e_tjad = L->TJA[idd];
+            e_tst = L->TST[25 * (5 * s_im1 + s_i) + 5 * s_jp2 + s_jp1];
+            e_n01 = L->E_b01[s_jp2]; e_n10 = L->E_b10[s_im1]; e_n11 = L->E_11[s_im1 * 5 + s_jp2];
+            if (guard_m) {
+                if (j + 1 <= n - 1) o_fmo = tab[L_FMO * ts + (d + 1) * ld + i];            // ipp:3806
+                if (i - 1 >= 1) o_fm1o = tab[L_FM1O * ts + (d + 1) * ld + i - 1];            // ipp:3833
+            }
+            o_f5o = f5o[j + 1];
+            o_fc = tab[L_FC * ts + at];
+            const double* __restrict__ fcox = tab + L_FCOX * ts;
+            if (up_ok) {
+                o_fm1o_up = tab[L_FM1O * ts + (d + 2) * ld + i - 1];                         // ipp:3828
+                o_fco_up = tab[L_FCO * ts + (d + 2) * ld + i - 1];
+            }
+            if (i - 1 >= 1 && j + 2 <= n - 1) o_x01 = fcox[(d + 3) * ld + i - 1];
+            if (i - 2 >= 1 && j + 1 <= n - 1) o_x10 = fcox[(d + 3) * ld + i - 2];
+            if (i - 2 >= 1 && j + 2 <= n - 1) o_x11 = fcox[(d + 4) * ld + i - 2];
+        }
+        double sm = 0.0, s1 = 0.0, g = 0.0;
+#pragma unroll
+        for (int k = 0; k < W; k++) { sm += part[0][k][lane]; s1 += part[1][k][lane]; g += part[2][k][lane]; }
+        double fmo = 0.0, fm1o = 0.0, fm2o = 0.0;
+        if (valid) {
+            if (guard_m) {
+                fmo = sm + o_fmo * L->w_mu;                   // ipp:3806
+                fm1o = s1 + fmo + o_fm1o * L->w_mu;           // ipp:3809, 3833
+            }
+            double fco = 0.0;
+            if (pairable) {
+                const double ext = o_f5o * o_f5i * L->w_ep2;  // exterior loop, ipp:3768-3776
+                const double multi = o_fm1o_up * L->w_mp2;    // branch of a multiloop, ipp:3828
+                const double sp = L->w01 * e_n01 * o_x01 + L->w10 * e_n10 * o_x10 + L->w11 * e_n11 * o_x11;
+                const double st = o_fco_up * L->lam2 * e_tst; // stacked on (i-1,j+1)
+                fco = e_bp * (e_tjad * (ext + multi) + e_tjbd * (g + sp)) + st;
+            }
+            fm2o = fmo + fco * e_tja * L->e_mpmb;                                                // ipp:3803, 4027
+            tab[L_FCO * ts + at] = fco;
+            tab[L_FCOX * ts + at] = fco * e_tjb;
+            tab[L_FMO * ts + at] = fmo;
+            tab[L_FM1O * ts + at] = fm1o;
+            tab[L_FM2O * ts + at] = fm2o;
+            // posterior of pair (i, j+1) = FCo * FCi / Z, clipped to [0,1]                 (ipp:4689-4827)
+            double p = fco * o_fc / o_z;
+            if (!(p == p) || p > 1e300) { atomicOr(&bad[sq], 1); p = 0.0; }
+            p = p > 1.0 ? 1.0 : (p < 0.0 ? 0.0 : p);
+            B.bp[(size_t)sq * B.tri_stride + tri_off(n, i) + (j + 1)] = p;
+        }
+        hand[0][lane] = fm2o; hand[1][lane] = fm1o; hand[2][lane] = fmo;
+    } else {
+        if (valid1) {   // operands of (i, j1 = j-1) on diagonal d1 = d-1; its row-d operands arrive through `hand`
+            const bool up_ok = i - 1 >= 1 && j1 + 1 <= n - 1;
+            const int idx = 25 * (5 * s_i + s_ip1) + 5 * s_j + s_jm1;
+            const int idd = 25 * (5 * s_j + s_jp1) + 5 * s_i + s_im1;
+            n_tjb = L->TJB[idx]; n_tja = L->TJA[idx]; n_bp = L->E_bp[s_i * 5 + s_j];
+            n_tjbd = L->TJB[idd]; n_tjad = L->TJA[idd];
+            n_tst = L->TST[25 * (5 * s_im1 + s_i) + 5 * s_jp1 + s_j];
+            n_n01 = L->E_b01[s_jp1]; n_n10 = L->E_b10[s_im1]; n_n11 = L->E_11[s_im1 * 5 + s_jp1];
+            n_f5o = f5o[j1 + 1];
+            n_fc = tab[L_FC * ts + d1 * ld + i];
+            const double* __restrict__ fcox = tab + L_FCOX * ts;
+            if (up_ok) {
+                n_fm1o_up = tab[L_FM1O * ts + (d1 + 2) * ld + i - 1];
+                n_fco_up = tab[L_FCO * ts + (d1 + 2) * ld + i - 1];
+            }
+            if (i - 1 >= 1 && j1 + 2 <= n - 1) n_x01 = fcox[(d1 + 3) * ld + i - 1];
+            if (i - 2 >= 1 && j1 + 1 <= n - 1) n_x10 = fcox[(d1 + 3) * ld + i - 2];
+            if (i - 2 >= 1 && j1 + 2 <= n - 1) n_x11 = fcox[(d1 + 4) * ld + i - 2];
+            if (guard_m1) {
+                if (i - 1 >= 1) n_y1 = tab[L_FM1 * ts + ld + i - 1];     // FM1[1][i-1]: partner of FM2o[d][i-1] (e = 1 of the FMo sum)
+                n_y2 = tab[L_FM * ts + ld + j1];                          // FM [1][j-1]: partner of FM2o[d][i]   (e = 1 of the FM1o sum)
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < W; k++) { smn += part[3][k][lane]; s1n += part[4][k][lane]; gn += part[5][k][lane]; }
+    }
+    __syncthreads();   // wavefronts 0 and 1 (the others have left)
+    if (w == 0 || !valid1) return;
+    {   // ---- diagonal d-1: row-d operands of column i (lane l) and i-1 (lane l-1)
+        const double fm2o = hand[0][lane], fmo = hand[2][lane];
+        const double fm2o_left = lane > 0 ? hand[0][lane - 1] : 0.0;   // FM2o[d][i-1]
+        const double fm1o_left = lane > 0 ? hand[1][lane - 1] : 0.0;   // FM1o[d][i-1]
+        double fmon = 0.0, fm1on = 0.0;
+        if (guard_m1) {
+            if (1 <= mineA1) smn = fma(fm2o_left, n_y1, smn);                      // e = 1: FM2o[d][i-1] * FM1[1][i-1]
+            if (1 <= mineB1) s1n = fma(fm2o, n_y2, s1n);                           // e = 1: FM2o[d][i]   * FM [1][j-1]
+            const double up_fmo = j1 + 1 <= n - 1 ? fmo : 0.0;                     // FMO [d][i]
+            const double up_fm1o = i - 1 >= 1 ? fm1o_left : 0.0;                   // FM1O[d][i-1]
+            fmon = smn + up_fmo * L->w_mu;
+            fm1on = s1n + fmon + up_fm1o * L->w_mu;
+        }
+        double fcon = 0.0;
+        if (pairable1) {
+            const double ext = n_f5o * o_f5i * L->w_ep2;
+            const double multi = n_fm1o_up * L->w_mp2;
+            const double sp = L->w01 * n_n01 * n_x01 + L->w10 * n_n10 * n_x10 + L->w11 * n_n11 * n_x11;
+            const double st = n_fco_up * L->lam2 * n_tst;
+            fcon = n_bp * (n_tjad * (ext + multi) + n_tjbd * (gn + sp)) + st;
+        }
+        const double fm2on = fmon + fcon * n_tja * L->e_mpmb;
+        const size_t at1 = d1 * ld + i;
+        tab[L_FCO * ts + at1] = fcon;
+        tab[L_FCOX * ts + at1] = fcon * n_tjb;
+        tab[L_FMO * ts + at1] = fmon;
+        tab[L_FM1O * ts + at1] = fm1on;
+        tab[L_FM2O * ts + at1] = fm2on;
+        double p = fcon * n_fc / o_z;
+        if (!(p == p) || p > 1e300) { atomicOr(&bad[sq], 1); p = 0.0; }
+        p = p > 1.0 ? 1.0 : (p < 0.0 ? 0.0 : p);
+        B.bp[(size_t)sq * B.tri_stride + tri_off(n, i) + (j1 + 1)] = p;
+    }
+}
+
 // logZ = log F5i~[n] + s*n; flags a sequence whose scaled values left the double range
 __global__ void lin_finish(McBatch B, const LinModel* __restrict__ L, double* __restrict__ logz, int* __restrict__ bad)
 {
@@ -692,5 +1072,7 @@ RH_INST(8, 32) RH_INST(16, 32)
 template __global__ void lin_inside_diag<4, 16, 1>(McBatch, const LinModel*, int, double, int);   // look-ahead pair
 template __global__ void lin_inside_diag<4, 16, 2>(McBatch, const LinModel*, int, double, int);
 template __global__ void lin_inside_diag<4, 16, 3>(McBatch, const LinModel*, int, double, int);   // both diagonals in one launch
+template __global__ void lin_outside_pair<8, 16>(McBatch, const LinModel*, int, int, int, int*);
+template __global__ void lin_outside_pair<4, 16>(McBatch, const LinModel*, int, int, int, int*);
 
 }  // namespace rh

@@ -31,9 +31,10 @@ __global__ void mc_unpaired(McBatch B);
 __global__ void dx_sweep_diag(DxBatch B, const ScoreModel* __restrict__ M, int t);
 __global__ void dx_logz(DxBatch B, const ScoreModel* __restrict__ M);
 __global__ void dx_posterior(DxBatch B);
-__global__ void lin_init(McBatch B, int* __restrict__ bad);
+__global__ void lin_init(McBatch B, const LinModel* __restrict__ L, int* __restrict__ bad);
 template <int W, int BS, int MODE> __global__ void lin_inside_diag(McBatch B, const LinModel* __restrict__ L, int d, double lam_d, int pin);
 template <int W, int BS> __global__ void lin_outside_diag(McBatch B, const LinModel* __restrict__ L, int d, int pin, int* __restrict__ bad);
+template <int W, int BS> __global__ void lin_outside_pair(McBatch B, const LinModel* __restrict__ L, int d, int khi, int pin, int* __restrict__ bad);
 template <int BS> __global__ void lin_far_inside(McBatch B, int D);
 template <int BS> __global__ void lin_far_outside(McBatch B, int D);
 __global__ void lin_far_inside_mfma(McBatch B, int D);
@@ -250,7 +251,7 @@ struct rh_ctx {
     bool use_graphs = true;        // RH_NO_GRAPH=1 launches every kernel from the host instead
     GraphSlot g_in, g_out, g_dx;
     int mode = RH_MODE_AUTO;       // which McCaskill path rh_batch_compute takes
-    int lin_w = 8;                 // wavefronts per 64-cell group of the linear outside kernel
+    int lin_w = 4;                 // wavefronts per 64-cell group of the linear outside kernel (Vienna-BL kernels: 8)
     int lin_w_in = 4;              // ... of the inside kernel (fewer, longer wavefronts: less per-wavefront scalar overhead)
     int lin_bs = 16;               // block size of the far/near split of the O(n^3) terms (0 = off)
     int last_path = 0;             // 1 = linear, 2 = log-space, 3 = linear then log-space fallback
@@ -759,7 +760,7 @@ int launch_mc_lin(rh_ctx* c, int pin, int phase)
     int* bad = (int*)c->d_bad;
     const int last_block = BS > 0 ? (B.nmax - 1) / BS : 0;
     if (phase == 0) {
-    hipLaunchKernelGGL(lin_init, dim3((B.ns + 63) / 64), dim3(64), 0, c->s_mc, B, bad);
+    hipLaunchKernelGGL(lin_init, dim3((B.ns + 63) / 64), dim3(64), 0, c->s_mc, B, c->d_lin, bad);
     if constexpr (W == 4 && BS == 16) {
         if (c->lookahead == 2) {   // two diagonals per launch (lin_inside_diag MODE 3); the last launch may hold only F5i[nmax]
             for (int d = 0; d <= B.nmax; d += 2) {
@@ -816,6 +817,26 @@ int launch_mc_lin(rh_ctx* c, int pin, int phase)
             }
             c->n_far[1]++;
         }
+    if constexpr (BS == 16 && (W == 8 || W == 4)) {
+        if (c->lookahead == 2 && c->far_mfma) {   // two diagonals per launch (lin_outside_pair)
+            // pairs are (odd, even) whatever the batch: a sequence's results do not depend on its neighbours' lengths
+            for (int d = (B.nmax - 2) | 1; d >= 0; d -= 2) {
+                for (int r = d; r >= d - 1 && r >= 0; r--)   // block products whose tiles start on either diagonal of the pair
+                    if ((r + 1) % BS == 0) {
+                        const int D = (r + 1) / BS - 1;
+                        if (D >= 0 && D <= last_block) { c->n_launch[1] += far_outside_step(c, B, c->s_mc, D, last_block); c->n_far[1]++; }
+                    }
+                const int ncol = B.nmax - 1 - d + 1;          // columns of the longer diagonal d-1 (d = 0: diagonal 0 alone, one less)
+                const int groups = std::max(1, (ncol - 1 + 62) / 63) + 1;
+                KLAUNCH(c, 2, (lin_outside_pair<W, BS>), pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(64 * W), c->s_mc, B, c->d_lin, d,
+                        d, pin, bad);
+                c->n_launch[1]++;
+            }
+            hipLaunchKernelGGL(lin_finish, dim3((B.ns + 63) / 64), dim3(64), 0, c->s_mc, B, c->d_lin, (double*)c->d_mclogz, bad);
+            hipLaunchKernelGGL(mc_unpaired, dim3((B.nmax + 3) / 4, B.ns), dim3(256), 0, c->s_mc, B);
+            return RH_OK;
+        }
+    }
     for (int d = B.nmax - 2; d >= 0; d--) {
         if (BS > 0 && (d + 1) % BS == 0) {
             const int D = (d + 1) / BS - 1;
@@ -1523,17 +1544,22 @@ int rh_batch_kernels(rh_ctx* c, const char* fine[3], const char* far[3], int n_f
     if (!c) return RH_ERR_ARG;
     if (!c->computed) return fail(c, RH_ERR_ARG, "no computed batch");
     static thread_local std::string names[6];
-    const std::string w = std::to_string(c->lin_w == 16 ? 16 : 8), w_in = std::to_string(c->lin_w_in == 16 ? 16 : (c->lin_w_in == 4 && c->lin_bs != 0 && c->lin_bs != 32 ? 4 : 8)), bs = std::to_string(c->lin_bs == 0 || c->lin_bs == 32 ? c->lin_bs : 16);
+    const bool vienna0 = c->model == RH_MODEL_VIENNA_BL;
+    const std::string w = std::to_string(c->lin_w == 16 ? 16 : (!vienna0 && c->lin_w == 4 && c->lin_bs != 0 && c->lin_bs != 32 ? 4 : 8)), w_in = std::to_string(c->lin_w_in == 16 ? 16 : (c->lin_w_in == 4 && c->lin_bs != 0 && c->lin_bs != 32 ? 4 : 8)), bs = std::to_string(c->lin_bs == 0 || c->lin_bs == 32 ? c->lin_bs : 16);
     const bool vienna = c->model == RH_MODEL_VIENNA_BL, lin = c->last_path == 1;
+    const bool pairs = !vienna && lin && c->lookahead == 2 && c->far_mfma && c->lin_bs == 16;   // two diagonals per launch
     const std::string pre = vienna ? "vlin_" : "lin_";
     const std::string targs = vienna ? bs + ", false" : bs;
-    names[0] = !c->has_mc ? "" : lin ? pre + "inside_diag<" + (vienna ? w : w_in) + ", " + targs + ">" : vienna ? "mcv_inside_diag" : "mc_inside_diag";
-    names[1] = !c->has_mc ? "" : lin ? pre + "outside_diag<" + w + ", " + targs + ">" : vienna ? "mcv_outside_diag" : "mc_outside_diag";
+    names[0] = !c->has_mc ? "" : lin ? pre + "inside_diag<" + (vienna ? "8" : w_in) + ", " + targs + (vienna ? "" : (pairs && c->lin_w_in == 4) ? ", 3" : (c->lookahead == 1 && c->lin_w_in == 4 && c->lin_bs == 16) ? ", 1" : ", 0") + ">"
+                                     : vienna ? "mcv_inside_diag" : "mc_inside_diag";
+    names[1] = !c->has_mc ? "" : lin ? ((pairs && (c->lin_w == 4 || c->lin_w == 8)) ? "lin_outside_pair<" + w + ", " + targs + ">" : pre + "outside_diag<" + (vienna ? "8" : w) + ", " + targs + ">")
+                                     : vienna ? "mcv_outside_diag" : "mc_outside_diag";
     names[2] = !c->has_dx ? "" : vienna ? (c->hybrid == RH_HYBRID_COFOLD ? (c->last_dx_path == 1 ? "vlin_inside_diag<8, 16, true> + vlin_outside_diag<8, 16, true> (s1+s2)"
                                                                                          : "mcv_inside_diag + mcv_outside_diag (s1+s2)") : "dxv_sweep_diag") : c->last_dx_path == 1 ? "dxl_sweep<" + std::to_string(c->dx_w == 2 || c->dx_w == 8 ? c->dx_w : 4) + ">" : "dx_sweep_diag";
     const bool mfma = c->far_mfma && c->lin_bs != 0 && c->lin_bs != 32;
-    names[3] = (c->has_mc && lin && c->n_far[0]) ? (mfma ? "lin_far_inside_mfma" : "lin_far_inside<" + bs + ">") : "";
-    names[4] = (c->has_mc && lin && c->n_far[1]) ? (mfma ? "lin_far_outside_mfma" : "lin_far_outside<" + bs + ">") : "";
+    const std::string fsuf = c->far_pk ? "_pk" : "_mfma";
+    names[3] = (c->has_mc && lin && c->n_far[0]) ? (mfma ? "lin_far_inside" + fsuf : "lin_far_inside<" + bs + ">") : "";
+    names[4] = (c->has_mc && lin && c->n_far[1]) ? (mfma ? "lin_far_outside" + fsuf : "lin_far_outside<" + bs + ">") : "";
     names[5] = "";
     for (int k = 0; k < 3; k++) {
         if (fine) fine[k] = names[k].c_str();
