@@ -55,6 +55,36 @@ __device__ __forceinline__ double win_sum_any(int t, const double* seg)
     }
     return 0.0;
 }
+// all windows of wavefront WV of a W-wavefront group (see dxl_sweep): window q has length t = 2+WV+q*W on source row
+// sdA -/+ (2+t); diagonal A takes it with weight lam^(t+2) (3 <= t), diagonal B takes it plus one more column with lam^(t+3)
+template <int W, int WV>
+__device__ __forceinline__ void win_pass(const double* seg0, const double* __restrict__ lam_pow, bool outside, int sdA, int smax, double& accA, double& accB)
+{
+    if constexpr (WV < W) {
+        constexpr int NSEG = (27 + W - 1) / W;
+#pragma unroll
+        for (int q = 0; q < NSEG; q++) {
+            constexpr int t0 = 2 + WV;
+            const int t = t0 + q * W;        // compile-time after unrolling
+            if (t > 28) continue;
+            const int row = outside ? sdA + 2 + t : sdA - 2 - t;
+            if (row >= 2 && row <= smax) {
+                const double* seg = seg0 + q * 96;
+                double s0 = 0.0, s1 = 0.0;
+                lds_vptr vs = (lds_vptr)seg;
+#pragma unroll
+                for (int k = 0; k <= t; k += 2) {
+                    s0 += vs[k];
+                    if (k + 1 <= t) s1 += vs[k + 1];
+                }
+                const double wa = s0 + s1;
+                const double wb = wa + (outside ? vs[t + 1] : vs[-1]);
+                if (t >= 3) accA = fma(lam_pow[t + 2], wa, accA);
+                if (t <= 27) accB = fma(lam_pow[t + 3], wb, accB);
+            }
+        }
+    }
+}
 }  // namespace
 
 // ---------------------------------------------------------------------------------
@@ -156,18 +186,16 @@ __global__ __launch_bounds__(64 * W) RH_WPE_DX void dxl_sweep(DxLinBatch B, cons
             if (lane < 32) buf[w][q][64 + lane] = r[64 + lane];
         }
     }
-    // pass 2: the window sums; rolled: ONE copy of the window switch (unrolled, the NSEG copies made the kernel larger
-    // than the instruction cache two CUs share)
-#pragma unroll 1
-    for (int q = 0; q < NSEG; q++) {
-        const int t = 2 + w + q * W;
-        const int row = outside ? sdA + 2 + t : sdA - 2 - t;
-        if (t <= 28 && row >= 2 && row <= smax) {
-            const double* seg = &buf[w][q][lane + (outside ? 0 : 1)];     // A's window = seg[0..t]
-            const double wa = win_sum_any(t, seg);
-            const double wb = wa + *(lds_vptr)(seg + (outside ? t + 1 : -1));
-            if (t >= 3) accA = fma(L->lam_pow[t + 2], wa, accA);
-            if (t <= 27) accB = fma(L->lam_pow[t + 3], wb, accB);
+    // pass 2: the window sums.  One specialisation per wavefront index: its window lengths t = 2+w, 2+w+W, ... are then
+    // compile-time constants (straight-line taps, immediate offsets, no per-window dispatch on the scalar unit), and the code
+    // stays one copy of every window length (unrolled over q inside ONE body it was NSEG copies of the whole switch, larger than
+    // the instruction cache two CUs share)
+    {
+        const double* seg0 = &buf[w][0][lane + (outside ? 0 : 1)];       // A's window of segment q = seg0[q*96 .. q*96+t]
+        switch (w) {
+#define X(V) case V: win_pass<W, V>(seg0, L->lam_pow, outside, sdA, smax, accA, accB); break;
+            X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+#undef X
         }
     }
     part[0][w][lane] = accA;

@@ -274,7 +274,11 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) RH_WPE_IN void lin_inside_
         const int ic = valid ? i : (ncell > 0 ? ncell : 1);   // invalid lanes read the last valid cell's operands
         const double* __restrict__ fm1c = tab + L_FM1 * ts + ic;
         const double* __restrict__ fmc = tab + L_FM * ts + ic;
-        constexpr int UF = LA ? 6 : 8;  // 2*UF (3*UF) row segments (512 B each) in flight per wavefront
+#ifdef RH_EXP_UF
+        constexpr int UF = RH_EXP_UF;
+#else
+        constexpr int UF = 8;
+#endif  // 2*UF (3*UF) row segments (512 B each) in flight per wavefront
         // uniform m-ranges that cover every lane's near set: [1, d-1], or its two ends when far blocks exist
         const bool split = BS > 0 && d - 1 > 4 * BS;
         const int lo0 = 1, hi0 = split ? 2 * BS : d - 1;
@@ -828,7 +832,11 @@ __global__ __launch_bounds__(64 * W) RH_WPE_OUT void lin_outside_pair(McBatch B,
     if (!guard_m) { mineA = 0; mineB = 0; }
     if (!guard_m1) { mineA1 = 0; mineB1 = 0; }
     if (guard_m1) {   // guard_m implies guard_m1
+#ifdef RH_EXP_UO
+        constexpr int UO = RH_EXP_UO;
+#else
         constexpr int UO = 4;
+#endif
         // FMo[i,d] += FM2o[d+e][i-e] * FM1[e][i-e], e = 1..i-1            (ipp:4046-4064, pulled)
         // with blocks: only i' = i-e in blocks I-1, I are streamed; blocks <= I-2 come from FMOF
         {
