@@ -154,6 +154,36 @@ __device__ __forceinline__ void filt_pair_any(int r, const double* __restrict__ 
     sa = 0.0; sb = 0.0;
 }
 
+// every staged row of wavefront WV of a W-wavefront group in the look-ahead kernels: rows r = g and 31-g, g = WV, WV+W, ...
+// (<= 15), are compile-time constants here -- straight-line taps, immediate weight offsets, no per-row dispatch
+template <int W, int WV, bool REV>
+__device__ __forceinline__ void filt_pass_pair(const double* __restrict__ shape_w, const double* seg0, int rmax, double& accA, double& accB)
+{
+    if constexpr (WV < W) {
+        constexpr int NSEG = 2 * ((kMaxSingle / 2 + W) / W), LAST = kMaxSingle + 1, HALF = (kMaxSingle + 1) / 2;
+#pragma unroll
+        for (int q = 0; q < NSEG; q++) {
+            const int g = WV + (q >> 1) * W;
+            const int r = (q & 1) ? LAST - g : g;       // compile-time after unrolling
+            if (g > HALF) continue;
+            if (r <= rmax) {
+                const double* __restrict__ wA = shape_w + (r > 0 ? (r - 1) * r / 2 : 0);
+                const double* __restrict__ wB = shape_w + (r <= kMaxSingle ? r * (r + 1) / 2 : 0);
+                const double* seg = seg0 + q * 96;
+                double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+#pragma unroll
+                for (int k = 0; k <= r; k++) {
+                    const double x = REV ? seg[r - k] : seg[k];
+                    if (k < r) { if (k & 1) a1 = fma(wA[k], x, a1); else a0 = fma(wA[k], x, a0); }
+                    if (r <= kMaxSingle) { if (k & 1) b1 = fma(wB[k], x, b1); else b0 = fma(wB[k], x, b0); }
+                }
+                accA += a0 + a1;
+                accB += b0 + b1;
+            }
+        }
+    }
+}
+
 template <int W, int BS, int MODE>
 __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) RH_WPE_IN void lin_inside_diag(McBatch B, const LinModel* __restrict__ L, int d, double lam_d, int pin)
 {
@@ -356,19 +386,19 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) RH_WPE_IN void lin_inside_
         // pass 2: the filters
         // rolled: ONE copy of the filter switch (unrolled, the NSEG copies made the kernel larger than the
         // instruction cache two CUs share)
+        if constexpr (LA) {
+            switch (w) {
+#define X(V) case V: filt_pass_pair<W, V, false>(L->shape_w, &gbuf[w][0][lane], rmax, accc, acccn); break;
+                X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
+#undef X
+            }
+        } else {
 #pragma unroll 1
-        for (int q = 0; q < NSEG; q++) {
-            const int g = w + (q >> 1) * W;
-            const int t = (q & 1) ? LAST - g : g;
-            const bool on = g <= HALF && !((q & 1) && t == g) && t <= rmax;
-            if (!on) continue;
-            if constexpr (LA) {
-                double sa, sb;
-                filt_pair_any(t, L->shape_w + (t > 0 ? (t - 1) * t / 2 : 0), L->shape_w + (t <= kMaxSingle ? t * (t + 1) / 2 : 0), &gbuf[w][q][lane], sa, sb);
-                accc += sa;
-                acccn += sb;
-            } else {
-                accc += filt_fwd_any(t, L->shape_w + t * (t + 1) / 2, &gbuf[w][q][lane]);
+            for (int q = 0; q < NSEG; q++) {
+                const int g = w + (q >> 1) * W;
+                const int t = (q & 1) ? LAST - g : g;
+                const bool on = g <= HALF && !((q & 1) && t == g) && t <= rmax;
+                if (on) accc += filt_fwd_any(t, L->shape_w + t * (t + 1) / 2, &gbuf[w][q][lane]);
             }
         }
         if (!pairable) accc = 0.0;
@@ -912,15 +942,10 @@ __global__ __launch_bounds__(64 * W) RH_WPE_OUT void lin_outside_pair(McBatch B,
                     if (lane < 32) gbuf[w][q][64 + lane] = (c2 >= 1 && c2 <= cmax) ? row[c2] : 0.0;
                 }
             }
-#pragma unroll 1
-            for (int q = 0; q < NSEG; q++) {
-                const int g = w + (q >> 1) * W;
-                const int r = (q & 1) ? LAST - g : g;
-                if (!(g <= HALF && r <= rmax)) continue;
-                double sa, sb;
-                filt_pair_rev_any(r, L->shape_w + (r > 0 ? (r - 1) * r / 2 : 0), L->shape_w + (r <= kMaxSingle ? r * (r + 1) / 2 : 0), &gbuf[w][q][lane], sa, sb);
-                accc += sa;
-                acccn += sb;
+            switch (w) {
+#define X(V) case V: filt_pass_pair<W, V, true>(L->shape_w, &gbuf[w][0][lane], rmax, accc, acccn); break;
+                X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+#undef X
             }
         }
     }
