@@ -223,62 +223,91 @@ __global__ __launch_bounds__(64 * W) RH_WPE_DX void dxl_sweep(DxLinBatch B, cons
     }
 }
 
-// Z~ = sum IN~[a,b] * close~(a,b); one workgroup per pair                        (DuplexEngine.ipp:1066-1073)
-__global__ __launch_bounds__(1024) void dxl_logz(DxLinBatch B, const DxLinModel* __restrict__ L, double* __restrict__ zbar,
-                                                 double* __restrict__ logz, int* __restrict__ bad)
+// Z~ = sum IN~[a,b] * close~(a,b)                                                (DuplexEngine.ipp:1066-1073)
+// two stages, both in a fixed summation order (results do not depend on scheduling): kLzRows anti-diagonals per
+// workgroup, read along the rows of the table (coalesced), then one thread per pair adds the chunks in order.
+// zpart: [NP][nchunk] partial sums, cpart: pairable-cell counts
+constexpr int kLzRows = 16;
+__global__ __launch_bounds__(256) void dxl_logz_part(DxLinBatch B, const DxLinModel* __restrict__ L, double* __restrict__ zpart, int* __restrict__ cpart, int nchunk)
 {
-    __shared__ double sm[16];
-    __shared__ int sc[16];
-    const int pr = blockIdx.x;
+    __shared__ double sm[4];
+    __shared__ int sc[4];
+    const int pr = blockIdx.y, chunk = blockIdx.x;
     const int L1 = B.n[2 * pr], L2 = B.n[2 * pr + 1];
     const uint8_t* __restrict__ s1 = B.seq + (size_t)(2 * pr) * B.lds;
     const uint8_t* __restrict__ s2 = B.seq + (size_t)(2 * pr + 1) * B.lds;
     const double* __restrict__ in = B.tab + (size_t)pr * B.pair_stride + DL_IN * B.tab_stride + kDxPad;
     double acc = 0.0;
     int npair = 0;
-    const int total = L1 * L2;
-    for (int c = threadIdx.x; c < total; c += blockDim.x) {
-        const int i = c / L2 + 1, j = c % L2 + 1;
-        const int a = i, b = L2 + 1 - j;
-        const int x = s1[i], y = s2[j];
-        if (!pairs(x, y)) continue;
-        npair++;
-        const double v = in[(size_t)(a + b) * B.lda + a];
+    for (int sd = 2 + chunk * kLzRows; sd < 2 + (chunk + 1) * kLzRows && sd <= L1 + L2; sd++) {
         // close~ = (lam*e^eu)^(L1+L2-sd) * lam^2 * dangles * helix_closing
-        const double cl = pow(L->lam_eu, (double)(L1 + L2 - a - b)) * L->lam_pow[2] * L->E_dl[x * 25 + y * 5 + s1[i + 1]] *
-                          L->E_dr[x * 25 + y * 5 + s2[j - 1]] * L->E_hc[x * 5 + y];
-        acc = fma(v, cl, acc);
+        const double rowf = pow(L->lam_eu, (double)(L1 + L2 - sd)) * L->lam_pow[2];
+        const int alo = sd - L2 > 1 ? sd - L2 : 1, ahi = sd - 1 < L1 ? sd - 1 : L1;
+        for (int a = alo + threadIdx.x; a <= ahi; a += 256) {
+            const int i = a, j = L2 + 1 - (sd - a);
+            const int x = s1[i], y = s2[j];
+            if (!pairs(x, y)) continue;
+            npair++;
+            const double cl = rowf * L->E_dl[x * 25 + y * 5 + s1[i + 1]] * L->E_dr[x * 25 + y * 5 + s2[j - 1]] * L->E_hc[x * 5 + y];
+            acc = fma(in[(size_t)sd * B.lda + a], cl, acc);
+        }
     }
     for (int o = 32; o > 0; o >>= 1) { acc += __shfl_xor(acc, o, 64); npair += __shfl_xor(npair, o, 64); }
     if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6] = acc; sc[threadIdx.x >> 6] = npair; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double z = 0.0;
-        int any = 0;
-        for (int k = 0; k < 16; k++) { z += sm[k]; any += sc[k]; }
-        zbar[pr] = z;
-        // no complementary pair at all: the reference leaves logZ at its -2e20 sentinel and hp at zero
-        if (!any) { logz[pr] = RH_NEG_INF; bad[pr] = 0; return; }
-        bad[pr] = (z > 1e-200 && z < 1e200) ? 0 : 1;
-        logz[pr] = log(z) + L->s * (double)(L1 + L2 + 2);
+        zpart[(size_t)pr * nchunk + chunk] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+        cpart[(size_t)pr * nchunk + chunk] = sc[0] + sc[1] + sc[2] + sc[3];
     }
+}
+__global__ void dxl_logz_final(DxLinBatch B, const DxLinModel* __restrict__ L, const double* __restrict__ zpart, const int* __restrict__ cpart, int nchunk,
+                               double* __restrict__ zbar, double* __restrict__ logz, int* __restrict__ bad)
+{
+    const int pr = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pr >= B.np) return;
+    const int L1 = B.n[2 * pr], L2 = B.n[2 * pr + 1];
+    double z = 0.0;
+    int any = 0;
+    for (int k = 0; k < nchunk; k++) { z += zpart[(size_t)pr * nchunk + k]; any += cpart[(size_t)pr * nchunk + k]; }
+    zbar[pr] = z;
+    // no complementary pair at all: the reference leaves logZ at its -2e20 sentinel and hp at zero
+    if (!any) { logz[pr] = RH_NEG_INF; bad[pr] = 0; return; }
+    bad[pr] = (z > 1e-200 && z < 1e200) ? 0 : 1;
+    logz[pr] = log(z) + L->s * (double)(L1 + L2 + 2);
 }
 
 // hp[i][j] = IN~ * OUT~ / Z~                                                      (DuplexEngine.ipp:1146-1169)
+// 32x32 tiles of (anti-diagonal sd, column a): read along the table rows, transposed through LDS, written along the rows
+// of hp (for a fixed i = a the 32 anti-diagonals of a tile are 32 consecutive j)
 __global__ __launch_bounds__(256) void dxl_posterior(DxLinBatch B, const double* __restrict__ zbar, int* __restrict__ bad)
 {
-    const int pr = blockIdx.y;
+    __shared__ double tile[32][33];
+    const int pr = blockIdx.z;
     const int L1 = B.n[2 * pr], L2 = B.n[2 * pr + 1];
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= L1 * L2) return;
-    const int i = c / L2 + 1, j = c % L2 + 1;
-    const int a = i, b = L2 + 1 - j;
+    const int a0 = 1 + blockIdx.x * 32, s0 = 2 + blockIdx.y * 32;
+    if (a0 > L1 || s0 > L1 + L2) return;
     const double* __restrict__ tab = B.tab + (size_t)pr * B.pair_stride + kDxPad;
-    const size_t at = (size_t)(a + b) * B.lda + a;
     const double z = zbar[pr];
-    double p = z > 0.0 ? tab[DL_IN * B.tab_stride + at] * tab[DL_OUT * B.tab_stride + at] / z : 0.0;
-    if (!(p == p) || p > 1e300) { atomicOr(&bad[pr], 1); p = 0.0; }
-    B.hp[(size_t)pr * B.hp_stride + (size_t)i * B.ldd + j] = p;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    bool flag = false;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int sd = s0 + ty + 8 * k, a = a0 + tx, b = sd - a;
+        double p = 0.0;
+        if (a <= L1 && b >= 1 && b <= L2 && z > 0.0) {
+            const size_t at = (size_t)sd * B.lda + a;
+            p = tab[DL_IN * B.tab_stride + at] * tab[DL_OUT * B.tab_stride + at] / z;
+            if (!(p == p) || p > 1e300) { flag = true; p = 0.0; }
+        }
+        tile[ty + 8 * k][tx] = p;
+    }
+    if (flag) atomicOr(&bad[pr], 1);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int a = a0 + ty + 8 * k, sd = s0 + tx, b = sd - a;
+        if (a <= L1 && b >= 1 && b <= L2) B.hp[(size_t)pr * B.hp_stride + (size_t)a * B.ldd + (L2 + 1 - b)] = tile[tx][ty + 8 * k];
+    }
 }
 
 template __global__ void dxl_sweep<2>(DxLinBatch, const DxLinModel*, int, int);

@@ -44,7 +44,9 @@ __global__ void lin_far_inside_pk(McBatch B, int D);
 __global__ void lin_far_outside_pk(McBatch B, int D);
 __global__ void lin_finish(McBatch B, const LinModel* __restrict__ L, double* __restrict__ logz, int* __restrict__ bad);
 template <int W> __global__ void dxl_sweep(DxLinBatch B, const DxLinModel* __restrict__ L, int step, int groups);
-__global__ void dxl_logz(DxLinBatch B, const DxLinModel* __restrict__ L, double* __restrict__ zbar, double* __restrict__ logz, int* __restrict__ bad);
+__global__ void dxl_logz_part(DxLinBatch B, const DxLinModel* __restrict__ L, double* __restrict__ zpart, int* __restrict__ cpart, int nchunk);
+__global__ void dxl_logz_final(DxLinBatch B, const DxLinModel* __restrict__ L, const double* __restrict__ zpart, const int* __restrict__ cpart, int nchunk,
+                               double* __restrict__ zbar, double* __restrict__ logz, int* __restrict__ bad);
 __global__ void dxl_posterior(DxLinBatch B, const double* __restrict__ zbar, int* __restrict__ bad);
 __global__ void dxv_sweep_diag(DxBatch B, const ViennaDx* __restrict__ V, int t);
 __global__ void dxv_logz(DxBatch B, const ViennaDx* __restrict__ V);
@@ -282,6 +284,8 @@ struct rh_ctx {
     void* d_cnt = nullptr;   size_t cap_cnt = 0;
     void* d_dxbad = nullptr; size_t cap_dxbad = 0;
     void* d_zbar = nullptr;  size_t cap_zbar = 0;
+    void* d_zpart = nullptr; size_t cap_zpart = 0;   // per-chunk partial sums of Z~ (+ pairable-cell counts behind them)
+    int lz_chunks = 0;
     void* d_cand = nullptr;  size_t cap_cand = 0;
     void* d_gaps = nullptr;  size_t cap_gaps = 0;
     void* d_allow = nullptr; size_t cap_allow = 0;   // structure-constraint masks [ns][ld*ld] bytes (Vienna-BL, optional)
@@ -518,6 +522,8 @@ int stage(rh_ctx* c, int ns, const char* const* seqs, const int* lens, bool with
         }
         if ((rc = ensure(c, &c->d_dxbad, &c->cap_dxbad, sizeof(int) * D.np, false))) return rc;
         if ((rc = ensure(c, &c->d_zbar, &c->cap_zbar, sizeof(double) * D.np, false))) return rc;
+        c->lz_chunks = (n1max + n2max - 1 + 15) / 16;   // kLzRows anti-diagonals per chunk
+        if ((rc = ensure(c, &c->d_zpart, &c->cap_zpart, (sizeof(double) + sizeof(int)) * (size_t)D.np * c->lz_chunks, false))) return rc;
         if ((rc = ensure(c, &c->d_logz, &c->cap_logz, sizeof(double) * D.np, false))) return rc;
         const size_t hp_bytes = sizeof(double) * D.tab_stride * D.np;
         if ((rc = ensure(c, &c->d_hp, &c->cap_hp, hp_bytes, false))) return rc;
@@ -942,10 +948,12 @@ int launch_dx_lin(rh_ctx* c)
         KLAUNCH(c, 4, dxl_sweep<W>, dim3(groups, X.np, 2), dim3(64 * W), c->s_dx, X, c->d_dxlin, t, groups);
         c->n_launch[2]++;
     }
-    hipLaunchKernelGGL(dxl_logz, dim3(X.np), dim3(1024), 0, c->s_dx, X, c->d_dxlin, (double*)c->d_zbar, (double*)c->d_logz,
-                       (int*)c->d_dxbad);
-    const int cells = X.n1max * X.n2max;
-    hipLaunchKernelGGL(dxl_posterior, dim3((cells + 255) / 256, X.np), dim3(256), 0, c->s_dx, X, (const double*)c->d_zbar,
+    double* zpart = (double*)c->d_zpart;
+    int* cpart = (int*)(zpart + (size_t)X.np * c->lz_chunks);
+    hipLaunchKernelGGL(dxl_logz_part, dim3(c->lz_chunks, X.np), dim3(256), 0, c->s_dx, X, c->d_dxlin, zpart, cpart, c->lz_chunks);
+    hipLaunchKernelGGL(dxl_logz_final, dim3((X.np + 63) / 64), dim3(64), 0, c->s_dx, X, c->d_dxlin, (const double*)zpart, (const int*)cpart,
+                       c->lz_chunks, (double*)c->d_zbar, (double*)c->d_logz, (int*)c->d_dxbad);
+    hipLaunchKernelGGL(dxl_posterior, dim3((X.n1max + 31) / 32, (smax - 1 + 31) / 32, X.np), dim3(256), 0, c->s_dx, X, (const double*)c->d_zbar,
                        (int*)c->d_dxbad);
     return RH_OK;
 }
@@ -979,7 +987,7 @@ size_t shape_key(const rh_ctx* c, int which)
     } else {
         const DxLinBatch& X = c->dxl;
         for (size_t v : {(size_t)X.np, (size_t)X.n1max, (size_t)X.n2max, (size_t)X.lda, (size_t)X.ldd, (size_t)X.tab, (size_t)X.hp,
-                         (size_t)X.seq, (size_t)X.n, (size_t)c->d_zbar, (size_t)c->d_logz, (size_t)c->d_dxbad, (size_t)c->dx_w})
+                         (size_t)X.seq, (size_t)X.n, (size_t)c->d_zbar, (size_t)c->d_logz, (size_t)c->d_dxbad, (size_t)c->dx_w, (size_t)c->d_zpart})
             h = mix(h, v);
     }
     return h;
@@ -1255,7 +1263,7 @@ void rh_destroy(rh_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    void* bufs[] = {c->d_seq, c->d_n, c->d_mctab, c->d_f5, c->d_bp, c->d_up, c->d_dxtab, c->d_hp, c->d_logz, c->d_scal, c->d_mclogz, c->d_bad, c->d_cnt, c->d_cand, c->d_dxbad, c->d_zbar, c->d_gaps, c->d_coseq, c->d_con, c->d_cotab, c->d_pk, c->d_copk, c->d_rowp, c->d_cof5, c->d_cobp, c->d_cobad, c->d_allow, c->d_coallow, c->d_vlin, c->d_hplen, c->d_model, c->d_lin, c->d_dxlin, c->d_vienna};
+    void* bufs[] = {c->d_seq, c->d_n, c->d_mctab, c->d_f5, c->d_bp, c->d_up, c->d_dxtab, c->d_hp, c->d_logz, c->d_scal, c->d_mclogz, c->d_bad, c->d_cnt, c->d_cand, c->d_dxbad, c->d_zbar, c->d_zpart, c->d_gaps, c->d_coseq, c->d_con, c->d_cotab, c->d_pk, c->d_copk, c->d_rowp, c->d_cof5, c->d_cobp, c->d_cobad, c->d_allow, c->d_coallow, c->d_vlin, c->d_hplen, c->d_model, c->d_lin, c->d_dxlin, c->d_vienna};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (GraphSlot* g : {&c->g_in, &c->g_out, &c->g_dx}) if (g->exec) (void)hipGraphExecDestroy(g->exec);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
