@@ -524,3 +524,45 @@ def test_errors_are_reported_not_swallowed(ctx):
         ctx.unpaired("ACGU", max_w=5)      # the CONTRAfold path has width-1 accessibility only
     with pytest.raises(ractip_amd.RhError):
         ctx.batch_upload([("ACGU", "")])
+
+
+def test_sweep_organisations_agree(hotlib, oracle, monkeypatch):
+    """The fused two-diagonal sweeps (default), the look-ahead pair of launches, the one-diagonal-per-launch kernels and the
+    block products with / without packed operand tiles are the same arithmetic up to summation order: every variant against
+    the CPU oracle at 1e-6 and against the default at 1e-10, on lengths around the 63/64-column group edges and the
+    16-letter blocks."""
+    import ractip_amd
+    rng = np.random.RandomState(5)
+    seqs = [rnd(rng, n) for n in (62, 63, 64, 65, 127, 128, 129, 190, 331)]
+    pairs = [(seqs[0], seqs[3]), (seqs[4], seqs[1]), (seqs[7], seqs[8])]
+
+    def run(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        c = ractip_amd.Context(device=0)
+        try:
+            out = [c.bpp(s) for s in seqs]
+            c.batch_upload(pairs)
+            c.batch_compute()
+            res = [c.batch_results(p) for p in range(len(pairs))]
+        finally:
+            c.close()
+            for k in env:
+                monkeypatch.delenv(k)
+        return out, res
+
+    base, base_pairs = run({})
+    for (bp, z), s in zip(base, seqs):
+        o = oracle.inference(s)
+        assert abs(z - o["logZ"]) < 1e-9
+        assert_prob_close(bp, o["post"], rel=REL, what="default n=%d" % len(s))
+    for env in ({"RH_LOOKAHEAD": "1"}, {"RH_LOOKAHEAD": "0"}, {"RH_FAR_PK": "0"}, {"RH_LOOKAHEAD": "0", "RH_LIN_W": "8"}, {"RH_LIN_W": "8"},
+                {"RH_DX_W": "8"}):
+        got, got_pairs = run(env)
+        for (bp, z), (bp0, z0), s in zip(got, base, seqs):
+            assert abs(z - z0) < 1e-10, (env, len(s))
+            assert_prob_close(bp, bp0, rel=1e-10, what="%r n=%d" % (env, len(s)))
+        for r, r0 in zip(got_pairs, base_pairs):
+            assert_prob_close(r["hp"], r0["hp"], rel=1e-10, what="%r hp" % (env,))
+            assert_prob_close(r["bp1"], r0["bp1"], rel=1e-10, what="%r bp1" % (env,))
+            assert np.allclose(r["logZ"], r0["logZ"], rtol=0, atol=1e-10)
