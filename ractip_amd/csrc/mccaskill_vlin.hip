@@ -76,6 +76,48 @@ __device__ __forceinline__ double vfilt_rev_m(int t, const double* __restrict__ 
     for (int l1 = 0; l1 <= t; l1++) s0 += (l1 >= lo && l1 <= hi) ? wt[l1] * seg[t - l1] : 0.0;
     return s0;
 }
+// look-ahead pair (see vlin_inside_diag MODE 1): staged row r carries filter t = r-1 of diagonal d (taps l < r, weights wA)
+// and filter t = r of diagonal d+1 (taps l <= r, weights wB); generic filters exist for t >= 4 only
+template <int R>
+__device__ __forceinline__ void vfilt_pair(const double* __restrict__ wA, const double* __restrict__ wB, const double* seg, double& sa, double& sb)
+{
+    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+#pragma unroll
+    for (int l = 0; l <= R; l++) {
+        const double x = seg[l];
+        if (R - 1 >= 4 && l < R) { if (l & 1) a1 = fma(wA[l], x, a1); else a0 = fma(wA[l], x, a0); }
+        if (R <= kMaxSingle) { if (l & 1) b1 = fma(wB[l], x, b1); else b0 = fma(wB[l], x, b0); }
+    }
+    sa = a0 + a1;
+    sb = b0 + b1;
+}
+__device__ __forceinline__ void vfilt_pair_any(int r, const double* __restrict__ wA, const double* __restrict__ wB, const double* seg, double& sa, double& sb)
+{
+    switch (r) {
+#define X(T) case T: vfilt_pair<T>(wA, wB, seg, sa, sb); return;
+        X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24)
+        X(25) X(26) X(27) X(28) X(29) X(30) X(31)
+#undef X
+    }
+    sa = 0.0; sb = 0.0;
+}
+// the same with per-lane gap limits of both cells (rolled; only the groups next to the missing gap)
+__device__ __forceinline__ void vfilt_pair_m(int r, const double* __restrict__ wA, const double* __restrict__ wB, const double* seg,
+                                             int l1maxA, int l2maxA, int l1maxB, int l2maxB, double& sa, double& sb)
+{
+    const int tA = r - 1;
+    const int loA = tA - l2maxA > 0 ? tA - l2maxA : 0, hiA = tA < l1maxA ? tA : l1maxA;
+    const int loB = r - l2maxB > 0 ? r - l2maxB : 0, hiB = r < l1maxB ? r : l1maxB;
+    const bool onA = tA >= 4, onB = r <= kMaxSingle;
+    double a = 0.0, b = 0.0;
+#pragma unroll 1
+    for (int l = 0; l <= r; l++) {
+        const double x = seg[l];
+        a += (onA && l >= loA && l <= hiA) ? wA[l] * x : 0.0;
+        b += (onB && l >= loB && l <= hiB) ? wB[l] * x : 0.0;
+    }
+    sa = a; sb = b;
+}
 // generic loops need l1, l2 >= 1 and t >= 4 (1x1, 1x2, 2x1 are tabulated; 2x2 has weight 0 in shape_w)
 #define RH_VT_CASES(X) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) \
     X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30)
@@ -116,6 +158,9 @@ __device__ __forceinline__ double small_w(const VLinModel* L, int l1, int l2, in
 
 }  // namespace
 
+#ifndef RH_VLA_WPE
+#define RH_VLA_WPE 4   // wavefronts/SIMD the look-ahead (MODE 1) kernel is compiled for
+#endif
 #define GAPOK(g) (!CUT || gap_ok_vl(cut, (g)))
 // table slots: 3, 4, 7, 10, 11, 12 are the ones mccaskill_far.hip addresses (LinTableFar)
 enum VLinTable { VL_FC = 0, VL_FCX, VL_FCA, VL_FM1, VL_FM, VL_FCO, VL_FCOX, VL_FM2O, VL_FMSO, VL_FM1O,
@@ -141,11 +186,18 @@ __global__ void vlin_init(McBatch B, int* __restrict__ bad)
 
 // ---------------------------------------------------------------------------------
 // inside, diagonal d.  hp_d = lam^d * hairpin length weight of a loop of d unpaired letters.
-template <int W, int BS, bool CUT>
-__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(6, 8))) void vlin_inside_diag(McBatch B, const VLinModel* __restrict__ L, int d, double hp_d, int pin)
+// MODE 0: one full launch per diagonal.  MODE 1 / 2 = look-ahead pair (as lin_inside_diag MODE 1 / 2 of mccaskill_lin.hip):
+// the MODE 1 launch of an even diagonal d also accumulates, from the operands it holds, the sums of diagonal d+1 that do not
+// touch row d (FM2 without m = 1 and m = d; the filter of length t+1 over the staged row of the filter of length t; the bulge
+// taps) and leaves them in B.rowp; the MODE 2 launch of d+1 (one wavefront per group) adds the two fresh FM2 terms and runs
+// the epilogue.  F5 / XP / XS groups run in both launches unchanged.
+template <int W, int BS, bool CUT, int MODE>
+__global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) __attribute__((amdgpu_waves_per_eu(MODE == 1 ? RH_VLA_WPE : 6, 8))) void vlin_inside_diag(McBatch B, const VLinModel* __restrict__ L, int d, double hp_d, int pin)
 {
-    __shared__ double part[3][W][64];
-    __shared__ double gbuf[W][2 * ((kMaxSingle / 2 + W) / W)][96];
+    constexpr int WR = MODE == 2 ? 1 : W;
+    __shared__ double part[MODE == 1 ? 6 : 3][WR][64];
+    __shared__ double gbuf[MODE == 2 ? 1 : W][MODE == 2 ? 1 : 2 * ((kMaxSingle / 2 + W) / W)][MODE == 2 ? 1 : 96];
+    double* __restrict__ rowp = B.rowp + (size_t)(pin ? blockIdx.x : blockIdx.y) * 3 * B.ld;   // look-ahead sums of the next diagonal
     int sq, slot;
     block_map_vl(pin, &sq, &slot);
     if (sq >= B.ns) return;
@@ -170,15 +222,15 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(6, 8))) 
         const int b = cut + d + 1, a = cut - d;
         if (is_xp ? b > n : a < 1) return;
         double acc = 0.0;
-        if (is_xp) for (int k = cut + threadIdx.x; k <= b - 2; k += 64 * W) acc = fma(xv[k], fca[(b - k - 2) * ld + (k + 1)], acc);
-        else for (int l = a + 4 + threadIdx.x; l <= cut; l += 64 * W) acc = fma(fca[(l - 1 - a) * ld + a], xv[l + 1], acc);
+        if (is_xp) for (int k = cut + threadIdx.x; k <= b - 2; k += 64 * WR) acc = fma(xv[k], fca[(b - k - 2) * ld + (k + 1)], acc);
+        else for (int l = a + 4 + threadIdx.x; l <= cut; l += 64 * WR) acc = fma(fca[(l - 1 - a) * ld + a], xv[l + 1], acc);
         acc = wsum_vl(acc);
         if (lane == 0) part[0][w][0] = acc;
         __syncthreads();
         if (threadIdx.x == 0) {
             double t = 0.0;
 #pragma unroll
-            for (int k = 0; k < W; k++) t += part[0][k][0];
+            for (int k = 0; k < WR; k++) t += part[0][k][0];
             if (is_xp) xv[b] = xv[b - 1] * L->lam + t * L->lam2;
             else xv[a] = xv[a + 1] * L->lam + t * L->lam2;
         }
@@ -189,14 +241,14 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(6, 8))) 
         const int jj = d + 1;
         const double* __restrict__ fca = tab + VL_FCA * ts;
         double acc = 0.0;
-        for (int k = threadIdx.x; k <= jj - 2; k += 64 * W) acc = fma(f5i[k], fca[(jj - 2 - k) * ld + (k + 1)], acc);
+        for (int k = threadIdx.x; k <= jj - 2; k += 64 * WR) acc = fma(f5i[k], fca[(jj - 2 - k) * ld + (k + 1)], acc);
         acc = wsum_vl(acc);
         if (lane == 0) part[0][w][0] = acc;
         __syncthreads();
         if (threadIdx.x == 0) {
             double t = 0.0;
 #pragma unroll
-            for (int k = 0; k < W; k++) t += part[0][k][0];
+            for (int k = 0; k < WR; k++) t += part[0][k][0];
             f5i[jj] = f5i[jj - 1] * L->lam + t * L->lam2;
         }
         return;
@@ -211,7 +263,12 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(6, 8))) 
     // two-molecule form: the missing gap inside the pair limits both sides of an enclosed loop to their own strand
     const bool nick_in = CUT && valid && i <= cut && cut <= j;
     const int l1max = nick_in ? cut - i - 1 : 99, l2max = nick_in ? j - cut - 1 : 99;
-    const bool masked = CUT && __any(l1max < kMaxSingle || l2max < kMaxSingle);   // the same for all W wavefronts of the group
+    // MODE 1: cell (i, j+1) of diagonal d+1
+    const int d1 = d + 1;
+    const bool valid1 = MODE == 1 && i <= n - 1 - d1;
+    const bool nick_in1 = CUT && valid1 && i <= cut && cut <= j + 1;
+    const int l1max1 = nick_in1 ? cut - i - 1 : 99, l2max1 = nick_in1 ? j - cut : 99;
+    const bool masked = CUT && __any(l1max < kMaxSingle || l2max < kMaxSingle || l1max1 < kMaxSingle || l2max1 < kMaxSingle);   // the same for all W wavefronts of the group
 
     // epilogue operands (wave 0 only), issued ahead of the term loops
     const size_t at = d * ld + i;
@@ -220,7 +277,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(6, 8))) 
     const int idd = 25 * (5 * s_jp1 + (GAPOK(j + 1) ? s_jp2 : 0)) + 5 * s_i + (GAPOK(i - 1) ? s_im1 : 0);
     const int idx_raw = 25 * (5 * s_jp1 + s_jp2) + 5 * s_i + s_im1;
     // ---- FM2[i,d] = sum_{m=1}^{d-1} FM1[m][i] * FM[d-m][i+m]: near terms here, far blocks from FM2F
-    double acc2 = 0.0;
+    double acc2 = 0.0, acc2n = 0.0;
     {
         const double* __restrict__ fm1 = tab + VL_FM1 * ts + i;
         const double* __restrict__ fm = tab + VL_FM * ts + i;
@@ -229,7 +286,24 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(6, 8))) 
             const int I = i / BS, J = j / BS;
             if (J - I >= 4) { kA = (I + 2) * BS; kB = (J - 1) * BS; }
         }
-        constexpr int UF = 8;
+        int kA1 = 1 << 30, kB1 = 0;   // near set of (i, j+1)
+        if (MODE == 1 && BS > 0) {
+            const int I = i / BS, J1 = (j + 1) / BS;
+            if (J1 - I >= 4) { kA1 = (I + 2) * BS; kB1 = (J1 - 1) * BS; }
+        }
+        if constexpr (MODE == 2) {
+            // the look-ahead sum of the previous launch + the two terms that touch row d-1
+            if (valid) {
+                acc2 = rowp[i];
+                if (d >= 2) {
+                    const int k1 = i + 1, k2 = i + d - 1;
+                    if (k1 < kA || k1 >= kB) acc2 = fma(fm1[ld], fm[(d - 1) * ld + 1], acc2);                       // m = 1
+                    if (d >= 3 && (k2 < kA || k2 >= kB)) acc2 = fma(fm1[(d - 1) * ld], fm[ld + d - 1], acc2);        // m = d-1
+                }
+                if (BS > 0 && kB > 0) acc2 += tab[VL_FM2F * ts + d * ld + i];
+            }
+        } else {
+        constexpr int UF = MODE == 1 ? 6 : 8;
         const bool split = BS > 0 && d - 1 > 4 * BS;
         const int lo0 = 1, hi0 = split ? 2 * BS : d - 1;
         const int lo1 = split ? d - 2 * BS : 1, hi1 = split ? d - 1 : 0;
@@ -237,23 +311,85 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(6, 8))) 
         for (int part_i = 0; part_i < 2; part_i++) {
             const int lo = part_i ? lo1 : lo0, hi = part_i ? hi1 : hi0;
             for (int m = lo + w; m <= hi; m += UF * W) {
-                double a[UF], b[UF];
+                double a[UF], b[UF], bn[UF];
 #pragma unroll
                 for (int u = 0; u < UF; u++) {
                     const int mm = m + u * W, k = i + mm;
                     const bool ok = valid && mm <= hi && (k < kA || k >= kB);
-                    a[u] = ok ? fm1[mm * ld] : 0.0;
+                    const bool ok1 = MODE == 1 && valid1 && mm <= hi && mm >= 2 && (k < kA1 || k >= kB1);
+                    a[u] = (ok || ok1) ? fm1[mm * ld] : 0.0;
                     b[u] = ok ? fm[(d - mm) * ld + mm] : 0.0;
+                    bn[u] = ok1 ? fm[(d1 - mm) * ld + mm] : 0.0;
                 }
 #pragma unroll
-                for (int u = 0; u < UF; u++) acc2 = fma(a[u], b[u], acc2);
+                for (int u = 0; u < UF; u++) { acc2 = fma(b[u] != 0.0 ? a[u] : 0.0, b[u], acc2); if (MODE == 1) acc2n = fma(a[u], bn[u], acc2n); }
             }
         }
         if (BS > 0 && valid && kB > 0) acc2 += (w == 0) ? tab[VL_FM2F * ts + d * ld + i] : 0.0;
+        }
     }
 
     // ---- generic interior loops (LDS-staged filters over FCX) and long bulges (two taps per length over FCB)
-    double accc = 0.0, accb = 0.0;
+    double accc = 0.0, accb = 0.0, acccn = 0.0, accbn = 0.0;
+    if constexpr (MODE == 2) {
+        if (valid) { accc = rowp[ld + i]; accb = rowp[2 * ld + i]; }
+        if (!pairable) { accc = 0.0; accb = 0.0; }
+    } else if constexpr (MODE == 1) {
+        // staged row r = 2..31 is table row d-1-r: filter / bulge length t = r-1 of diagonal d and t = r of diagonal d+1
+        if (d >= 3) {
+            constexpr int LAST = kMaxSingle + 1, HALF = (kMaxSingle + 1) / 2;
+            const int rmax = d - 1 < LAST ? d - 1 : LAST;
+            const int i0 = 1 + slot * 64;
+            const double* __restrict__ fcx = tab + VL_FCX * ts;
+            const double* __restrict__ fcb = tab + VL_FCB * ts;
+            constexpr int NSEG = 2 * ((kMaxSingle / 2 + W) / W);
+            int rseg[NSEG];
+            double bA[NSEG], bB[NSEG];
+#pragma unroll
+            for (int q = 0; q < NSEG; q++) {
+                const int g = w + (q >> 1) * W;
+                const int r = (q & 1) ? LAST - g : g;
+                const bool on = g <= HALF && r <= rmax && r >= 2;   // wave-uniform
+                rseg[q] = on ? r : -1;
+                bA[q] = bB[q] = 0.0;
+                if (on) {
+                    const int col0 = i0 + 1;
+                    if (r >= 4) {
+                        const double* __restrict__ row = fcx + (d - 1 - r) * ld + col0;
+                        gbuf[w][q][lane] = col0 + lane < ld ? row[lane] : 0.0;
+                        if (lane < 32) gbuf[w][q][64 + lane] = col0 + 64 + lane < ld ? row[64 + lane] : 0.0;
+                    }
+                    // bulges of length t on the 3' side (l1 = 0: column i+1) and on the 5' side (l1 = t: column i+1+t)
+                    const double* __restrict__ brow = fcb + (d - 1 - r) * ld + i + 1;
+                    const int tA = r - 1;
+                    const bool a0 = valid && tA >= 2 && l1max >= 0 && tA <= l2max, a1 = valid && tA >= 2 && tA <= l1max && l2max >= 0;
+                    const bool b0 = valid1 && r <= kMaxSingle && l1max1 >= 0 && r <= l2max1, b1 = valid1 && r <= kMaxSingle && r <= l1max1 && l2max1 >= 0;
+                    const double x0 = (a0 || b0) ? brow[0] : 0.0;
+                    bA[q] = (a0 ? x0 : 0.0) + (a1 ? brow[tA] : 0.0);
+                    bB[q] = (b0 ? x0 : 0.0) + (b1 ? brow[r] : 0.0);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NSEG; q++)
+                if (rseg[q] >= 0) {
+                    const int r = rseg[q];
+                    if (r >= 4) {
+                        const double* __restrict__ wA = L->shape_w + (r - 1) * r / 2;
+                        const double* __restrict__ wB = L->shape_w + (r <= kMaxSingle ? r * (r + 1) / 2 : 0);
+                        double sa, sb;
+                        if (masked) vfilt_pair_m(r, wA, wB, &gbuf[w][q][lane], l1max, l2max, l1max1, l2max1, sa, sb);
+                        else vfilt_pair_any(r, wA, wB, &gbuf[w][q][lane], sa, sb);
+                        accc += sa;
+                        acccn += sb;
+                    }
+                    if (r - 1 >= 2) accb = fma(L->WB[r - 1], bA[q], accb);
+                    if (r <= kMaxSingle) accbn = fma(L->WB[r], bB[q], accbn);
+                }
+            if (!pairable) { accc = 0.0; accb = 0.0; }
+        } else if (d >= 1) {
+            // d = 1, 2: diagonal d has no generic loop yet (t <= 0); diagonal d+1 has lengths t <= d-1 <= 1: none either
+        }
+    } else
     if (d >= 2) {
         const int tmax = d - 2 < kMaxSingle ? d - 2 : kMaxSingle;
         const int i0 = 1 + slot * 64;
@@ -294,10 +430,21 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(6, 8))) 
         if (!pairable) { accc = 0.0; accb = 0.0; }
     }
 
-    part[0][w][lane] = acc2;
-    part[1][w][lane] = accc;
-    part[2][w][lane] = accb;
-    __syncthreads();
+    if constexpr (MODE != 2) {
+        part[0][w][lane] = acc2;
+        part[1][w][lane] = accc;
+        part[2][w][lane] = accb;
+        if constexpr (MODE == 1) { part[3][w][lane] = acc2n; part[4][w][lane] = acccn; part[5][w][lane] = accbn; }
+        __syncthreads();
+        if constexpr (MODE == 1) {
+            if (w == 1 && i < ld) {   // the look-ahead sums of diagonal d+1
+                double p2 = 0.0, pc = 0.0, pb = 0.0;
+#pragma unroll
+                for (int k = 0; k < W; k++) { p2 += part[3][k][lane]; pc += part[4][k][lane]; pb += part[5][k][lane]; }
+                rowp[i] = p2; rowp[ld + i] = pc; rowp[2 * ld + i] = pb;
+            }
+        }
+    }
     if (w != 0 || !valid) return;
     double e_txo = 0, e_tmc = 0, e_tmh = 0, e_txi = 0, e_tsa = 0, e_tau = 1, e_tet = 1, nick = 0.0;
     double o_fca = 0, o_fm1 = 0, o_fms = 0, sm7 = 0.0;
@@ -336,9 +483,12 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(6, 8))) 
         }
     }
 
-    double fm2 = 0.0, g = 0.0, gb = 0.0;
+    double fm2 = acc2, g = accc, gb = accb;
+    if constexpr (MODE != 2) {
+        fm2 = 0.0; g = 0.0; gb = 0.0;
 #pragma unroll
-    for (int k = 0; k < W; k++) { fm2 += part[0][k][lane]; g += part[1][k][lane]; gb += part[2][k][lane]; }
+        for (int k = 0; k < W; k++) { fm2 += part[0][k][lane]; g += part[1][k][lane]; gb += part[2][k][lane]; }
+    }
 
     double fc = 0.0;
     if (pairable) {
@@ -845,10 +995,14 @@ __global__ __launch_bounds__(256) void vlin_acc_final(McBatch B, const VLinModel
     *up = acc > 1.0 ? 1.0 : acc;
 }
 
-#define RH_VINST(BS, CUT)                                                                                \
-    template __global__ void vlin_inside_diag<8, BS, CUT>(McBatch, const VLinModel*, int, double, int);  \
+#define RH_VINST(BS, CUT)                                                                                   \
+    template __global__ void vlin_inside_diag<8, BS, CUT, 0>(McBatch, const VLinModel*, int, double, int);  \
     template __global__ void vlin_outside_diag<8, BS, CUT>(McBatch, const VLinModel*, int, int, int*);
 RH_VINST(16, false) RH_VINST(0, false) RH_VINST(16, true) RH_VINST(0, true)
 #undef RH_VINST
+template __global__ void vlin_inside_diag<8, 16, false, 1>(McBatch, const VLinModel*, int, double, int);   // look-ahead pairs
+template __global__ void vlin_inside_diag<8, 16, false, 2>(McBatch, const VLinModel*, int, double, int);
+template __global__ void vlin_inside_diag<8, 16, true, 1>(McBatch, const VLinModel*, int, double, int);
+template __global__ void vlin_inside_diag<8, 16, true, 2>(McBatch, const VLinModel*, int, double, int);
 
 }  // namespace rh

@@ -64,7 +64,7 @@ __global__ void mcv_acc_gaps(McBatch B, const ViennaDx* __restrict__ V, double* 
 __global__ void mcv_acc_final(McBatch B, const ViennaDx* __restrict__ V, const double* __restrict__ gaps, int max_w);
 __global__ void mcv_finish(McBatch B, double* __restrict__ logz);
 __global__ void vlin_init(McBatch B, int* __restrict__ bad);
-template <int W, int BS, bool CUT> __global__ void vlin_inside_diag(McBatch B, const VLinModel* __restrict__ L, int d, double hp_d, int pin);
+template <int W, int BS, bool CUT, int MODE> __global__ void vlin_inside_diag(McBatch B, const VLinModel* __restrict__ L, int d, double hp_d, int pin);
 template <int W, int BS, bool CUT> __global__ void vlin_outside_diag(McBatch B, const VLinModel* __restrict__ L, int d, int pin, int* __restrict__ bad);
 __global__ void vlin_finish(McBatch B, const VLinModel* __restrict__ L, double* __restrict__ logz, int* __restrict__ bad);
 __global__ void mcv_extract_hp(McBatch B, double* __restrict__ hp, size_t hp_stride, int ldd, double* __restrict__ logz, double lin_s, int* __restrict__ bad);
@@ -269,6 +269,7 @@ struct rh_ctx {
     void* d_seq = nullptr;   size_t cap_seq = 0;
     void* d_n = nullptr;     size_t cap_n = 0;
     void* d_mctab = nullptr; size_t cap_mctab = 0;
+    void* d_corowp = nullptr; size_t cap_corowp = 0;
     void* d_rowp = nullptr; size_t cap_rowp = 0;    // look-ahead partial sums of the next inside diagonal
     void* d_pk = nullptr; size_t cap_pk = 0;        // operand tiles of the block products (single-molecule batch)
     void* d_copk = nullptr; size_t cap_copk = 0;    // ... of the s1+s2 batch
@@ -462,7 +463,7 @@ int stage(rh_ctx* c, int ns, const char* const* seqs, const int* lens, bool with
         B.pk_stride = (size_t)B.nb * (B.nb + 1) / 2 * 256;
         if ((rc = ensure(c, &c->d_pk, &c->cap_pk, sizeof(double) * B.pk_stride * kPkCopies * ns, false))) return rc;
         B.pk = (double*)c->d_pk;
-        if ((rc = ensure(c, &c->d_rowp, &c->cap_rowp, sizeof(double) * 2 * B.ld * ns, false))) return rc;
+        if ((rc = ensure(c, &c->d_rowp, &c->cap_rowp, sizeof(double) * 3 * B.ld * ns, false))) return rc;
         B.rowp = (double*)c->d_rowp;
         if ((rc = ensure(c, &c->d_f5, &c->cap_f5, sizeof(double) * 2 * B.ld * ns, false))) return rc;
         if ((rc = ensure(c, &c->d_up, &c->cap_up, sizeof(double) * B.ld * c->max_w * ns, false))) return rc;
@@ -556,6 +557,8 @@ int stage(rh_ctx* c, int ns, const char* const* seqs, const int* lens, bool with
             C.pk_stride = (size_t)C.nb * (C.nb + 1) / 2 * 256;
             if ((rc = ensure(c, &c->d_copk, &c->cap_copk, sizeof(double) * C.pk_stride * kPkCopies * np, false))) return rc;
             C.pk = (double*)c->d_copk;
+            if ((rc = ensure(c, &c->d_corowp, &c->cap_corowp, sizeof(double) * 3 * C.ld * np, false))) return rc;
+            C.rowp = (double*)c->d_corowp;
             if ((rc = ensure(c, &c->d_cof5, &c->cap_cof5, sizeof(double) * 6 * C.ld * np, false))) return rc;
             if ((rc = ensure(c, &c->d_cobp, &c->cap_cobp, sizeof(double) * C.tri_stride * np, false))) return rc;
             if ((rc = ensure(c, &c->d_cobad, &c->cap_cobad, sizeof(int) * np, false))) return rc;
@@ -691,8 +694,24 @@ int launch_mc_vlin(rh_ctx* c, int pin, int phase, bool co)
         for (int d = 0; d <= B.nmax - 1; d++) {
             const int groups = (std::max(B.nmax - 1 - d, 0) + 63) / 64 + extra;
             const double hp_d = c->h_hplen[d];
-            if (co) KLAUNCH(c, 0, (vlin_inside_diag<W, BS, true>), pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(64 * W), st, B, c->d_vlin, d, hp_d, pin);
-            else KLAUNCH(c, 0, (vlin_inside_diag<W, BS, false>), pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(64 * W), st, B, c->d_vlin, d, hp_d, pin);
+            const dim3 grid = pin ? dim3(B.ns, groups) : dim3(groups, B.ns);
+            bool done = false;
+            if constexpr (BS == 16) {
+                if (c->lookahead) {   // look-ahead pairs: even diagonal = full launch that also accumulates d+1's sums, odd = one wavefront per group
+                    done = true;
+                    if ((d & 1) == 0) {
+                        if (co) KLAUNCH(c, 0, (vlin_inside_diag<W, 16, true, 1>), grid, dim3(64 * W), st, B, c->d_vlin, d, hp_d, pin);
+                        else KLAUNCH(c, 0, (vlin_inside_diag<W, 16, false, 1>), grid, dim3(64 * W), st, B, c->d_vlin, d, hp_d, pin);
+                    } else {
+                        if (co) KLAUNCH(c, 0, (vlin_inside_diag<W, 16, true, 2>), grid, dim3(64), st, B, c->d_vlin, d, hp_d, pin);
+                        else KLAUNCH(c, 0, (vlin_inside_diag<W, 16, false, 2>), grid, dim3(64), st, B, c->d_vlin, d, hp_d, pin);
+                    }
+                }
+            }
+            if (!done) {
+                if (co) KLAUNCH(c, 0, (vlin_inside_diag<W, BS, true, 0>), grid, dim3(64 * W), st, B, c->d_vlin, d, hp_d, pin);
+                else KLAUNCH(c, 0, (vlin_inside_diag<W, BS, false, 0>), grid, dim3(64 * W), st, B, c->d_vlin, d, hp_d, pin);
+            }
             (*nl)++;
             if (BS > 0 && (d + 1) % BS == 0) {
                 const int D = (d + 1) / BS + 1;
@@ -975,7 +994,7 @@ size_t shape_key(const rh_ctx* c, int which)
         for (size_t v : {(size_t)B.ns, (size_t)B.nmax, (size_t)B.ld, (size_t)B.lds, (size_t)B.tab, (size_t)B.seq, (size_t)B.n, (size_t)B.f5i,
                          (size_t)B.bp, (size_t)c->d_cobad, (size_t)c->lin_bs, (size_t)B.tri_stride, (size_t)c->dx.hp, (size_t)c->dx.logz,
                          (size_t)c->dx.ldd, (size_t)c->dx.tab_stride, (size_t)c->dx.n1max, (size_t)c->dx.n2max, (size_t)B.allow, (size_t)B.pk,
-                         (size_t)c->far_pk})
+                         (size_t)c->far_pk, (size_t)B.rowp, (size_t)c->lookahead})
             h = mix(h, v);
     } else if (which <= 1) {
         const McBatch& B = c->mc;
@@ -1263,7 +1282,7 @@ void rh_destroy(rh_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    void* bufs[] = {c->d_seq, c->d_n, c->d_mctab, c->d_f5, c->d_bp, c->d_up, c->d_dxtab, c->d_hp, c->d_logz, c->d_scal, c->d_mclogz, c->d_bad, c->d_cnt, c->d_cand, c->d_dxbad, c->d_zbar, c->d_zpart, c->d_gaps, c->d_coseq, c->d_con, c->d_cotab, c->d_pk, c->d_copk, c->d_rowp, c->d_cof5, c->d_cobp, c->d_cobad, c->d_allow, c->d_coallow, c->d_vlin, c->d_hplen, c->d_model, c->d_lin, c->d_dxlin, c->d_vienna};
+    void* bufs[] = {c->d_seq, c->d_n, c->d_mctab, c->d_f5, c->d_bp, c->d_up, c->d_dxtab, c->d_hp, c->d_logz, c->d_scal, c->d_mclogz, c->d_bad, c->d_cnt, c->d_cand, c->d_dxbad, c->d_zbar, c->d_zpart, c->d_gaps, c->d_coseq, c->d_con, c->d_cotab, c->d_pk, c->d_copk, c->d_rowp, c->d_corowp, c->d_cof5, c->d_cobp, c->d_cobad, c->d_allow, c->d_coallow, c->d_vlin, c->d_hplen, c->d_model, c->d_lin, c->d_dxlin, c->d_vienna};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (GraphSlot* g : {&c->g_in, &c->g_out, &c->g_dx}) if (g->exec) (void)hipGraphExecDestroy(g->exec);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
