@@ -118,6 +118,46 @@ __device__ __forceinline__ void vfilt_pair_m(int r, const double* __restrict__ w
     }
     sa = a; sb = b;
 }
+// reversed forms for the outside sweep: x_k = seg[r-k]
+template <int R>
+__device__ __forceinline__ void vfilt_pair_rev(const double* __restrict__ wA, const double* __restrict__ wB, const double* seg, double& sa, double& sb)
+{
+    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+#pragma unroll
+    for (int l = 0; l <= R; l++) {
+        const double x = seg[R - l];
+        if (R - 1 >= 4 && l < R) { if (l & 1) a1 = fma(wA[l], x, a1); else a0 = fma(wA[l], x, a0); }
+        if (R <= kMaxSingle) { if (l & 1) b1 = fma(wB[l], x, b1); else b0 = fma(wB[l], x, b0); }
+    }
+    sa = a0 + a1;
+    sb = b0 + b1;
+}
+__device__ __forceinline__ void vfilt_pair_rev_any(int r, const double* __restrict__ wA, const double* __restrict__ wB, const double* seg, double& sa, double& sb)
+{
+    switch (r) {
+#define X(T) case T: vfilt_pair_rev<T>(wA, wB, seg, sa, sb); return;
+        X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24)
+        X(25) X(26) X(27) X(28) X(29) X(30) X(31)
+#undef X
+    }
+    sa = 0.0; sb = 0.0;
+}
+__device__ __forceinline__ void vfilt_pair_rev_m(int r, const double* __restrict__ wA, const double* __restrict__ wB, const double* seg,
+                                                 int l1maxA, int l2maxA, int l1maxB, int l2maxB, double& sa, double& sb)
+{
+    const int tA = r - 1;
+    const int loA = tA - l2maxA > 0 ? tA - l2maxA : 0, hiA = tA < l1maxA ? tA : l1maxA;
+    const int loB = r - l2maxB > 0 ? r - l2maxB : 0, hiB = r < l1maxB ? r : l1maxB;
+    const bool onA = tA >= 4, onB = r <= kMaxSingle;
+    double a = 0.0, b = 0.0;
+#pragma unroll 1
+    for (int l = 0; l <= r; l++) {
+        const double x = seg[r - l];
+        a += (onA && l >= loA && l <= hiA) ? wA[l] * x : 0.0;
+        b += (onB && l >= loB && l <= hiB) ? wB[l] * x : 0.0;
+    }
+    sa = a; sb = b;
+}
 // generic loops need l1, l2 >= 1 and t >= 4 (1x1, 1x2, 2x1 are tabulated; 2x2 has weight 0 in shape_w)
 #define RH_VT_CASES(X) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) \
     X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30)
@@ -513,18 +553,26 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) __attribute__((amdgpu_wave
 
 // ---------------------------------------------------------------------------------
 // outside (pull form) + posterior, diagonal d; last group: F5o~[d+1]
-template <int W, int BS, bool CUT>
-__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(6, 8))) void vlin_outside_diag(McBatch B, const VLinModel* __restrict__ L, int d, int pin, int* __restrict__ bad)
+// MODE 0: one full launch per diagonal.  MODE 1 / 2 = look-ahead pair (see vlin_inside_diag): the MODE 1 launch of an odd
+// diagonal d also accumulates the sums of diagonal d-1 that do not touch row d (FMo / FM1o without their e = 1 terms, the
+// filter of length t+1 over the staged row of the filter of length t, the bulge taps) into B.rowp; the MODE 2 launch of d-1
+// (one wavefront per group) adds the two e = 1 terms and runs the epilogue.  Pairs are (odd, even) whatever the batch.
+template <int W, int BS, bool CUT, int MODE>
+__global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) __attribute__((amdgpu_waves_per_eu(MODE == 1 ? RH_VLA_WPE : 6, 8))) void vlin_outside_diag(McBatch B, const VLinModel* __restrict__ L, int d, int pin, int* __restrict__ bad)
 {
-    __shared__ double part[4][W][64];
-    __shared__ double gbuf[W][2 * ((kMaxSingle / 2 + W) / W)][96];
+    constexpr int WR = MODE == 2 ? 1 : W;
+    __shared__ double part[MODE == 1 ? 8 : 4][WR][64];
+    __shared__ double gbuf[MODE == 2 ? 1 : W][MODE == 2 ? 1 : 2 * ((kMaxSingle / 2 + W) / W)][MODE == 2 ? 1 : 96];
     int sq, slot;
     block_map_vl(pin, &sq, &slot);
     if (sq >= B.ns) return;
+    double* __restrict__ rowp = B.rowp + (size_t)sq * 4 * B.ld;   // look-ahead sums of the next diagonal
     const int n = B.n[sq];
-    const int ncell = n - 1 - d;
-    if (ncell < 1) return;
-    const int ngroup = (ncell + 63) >> 6;
+    const int ncell = n - 1 - d > 0 ? n - 1 - d : 0;
+    const int d1 = d - 1;
+    const int ncell1 = MODE == 1 && d1 >= 0 ? n - 1 - d1 : 0;     // diagonal d-1 has one more cell
+    if (ncell < 1 && ncell1 < 1) return;
+    const int ngroup = ((ncell > ncell1 ? ncell : ncell1) + 63) >> 6;
     const int cut = CUT ? B.cut[sq] : 0;   // CUT = false: one molecule per sequence, every gap test folds away
     if (slot > ngroup + (CUT ? 2 : 0)) return;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -547,21 +595,21 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(6, 8))) 
         if (is_xp) {
             const double* __restrict__ xs = B.xs + (size_t)sq * ld;
             const double* __restrict__ xpo = B.xpo + (size_t)sq * ld;
-            for (int i = 1 + threadIdx.x; i <= cut; i += 64 * W) {
+            for (int i = 1 + threadIdx.x; i <= cut; i += 64 * WR) {
                 if (b + 1 - i < 4 || !L->ptype[s[i] * 5 + s[b + 1]]) continue;
                 const int ix = 25 * (5 * s[i] + (GAPOK(i) ? s[i + 1] : 0)) + 5 * s[b + 1] + (GAPOK(b) ? s[b] : 0);
                 acc = fma(fco[(b - i) * ld + i] * L->TNC[ix], xs[i + 1], acc);
             }
-            for (int bb = b + 2 + threadIdx.x; bb <= n; bb += 64 * W) acc2 = fma(xpo[bb], fca[(bb - b - 2) * ld + b + 1], acc2);
+            for (int bb = b + 2 + threadIdx.x; bb <= n; bb += 64 * WR) acc2 = fma(xpo[bb], fca[(bb - b - 2) * ld + b + 1], acc2);
         } else {
             const double* __restrict__ xp = B.xp + (size_t)sq * ld;
             const double* __restrict__ xso = B.xso + (size_t)sq * ld;
-            for (int j = cut + threadIdx.x; j <= n - 1; j += 64 * W) {
+            for (int j = cut + threadIdx.x; j <= n - 1; j += 64 * WR) {
                 if (j + 1 - (a - 1) < 4 || !L->ptype[s[a - 1] * 5 + s[j + 1]]) continue;
                 const int ix = 25 * (5 * s[a - 1] + (GAPOK(a - 1) ? s[a] : 0)) + 5 * s[j + 1] + (GAPOK(j) ? s[j] : 0);
                 acc = fma(fco[(j - a + 1) * ld + a - 1] * L->TNC[ix], xp[j], acc);
             }
-            for (int aa = 1 + threadIdx.x; aa <= a - 2; aa += 64 * W) acc2 = fma(xso[aa], fca[(a - 2 - aa) * ld + aa], acc2);
+            for (int aa = 1 + threadIdx.x; aa <= a - 2; aa += 64 * WR) acc2 = fma(xso[aa], fca[(a - 2 - aa) * ld + aa], acc2);
         }
         acc = wsum_vl(acc); acc2 = wsum_vl(acc2);
         if (lane == 0) { part[0][w][0] = acc; part[1][w][0] = acc2; }
@@ -569,7 +617,7 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(6, 8))) 
         if (threadIdx.x == 0) {
             double t = 0.0, t2 = 0.0;
 #pragma unroll
-            for (int q = 0; q < W; q++) { t += part[0][q][0]; t2 += part[1][q][0]; }
+            for (int q = 0; q < WR; q++) { t += part[0][q][0]; t2 += part[1][q][0]; }
             if (is_xp) { double* xpo = B.xpo + (size_t)sq * ld; xpo[b] = t + xpo[b + 1] * L->lam + t2 * L->lam2; }
             else { double* xso = B.xso + (size_t)sq * ld; xso[a] = t + xso[a - 1] * L->lam + t2 * L->lam2; }
         }
@@ -577,16 +625,17 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(6, 8))) 
     }
     if (slot == ngroup) {
         const int k = d + 1;
+        if (k > n - 1) return;   // (MODE 1 on a diagonal beyond this sequence's first)
         const double* __restrict__ fca = tab + VL_FCA * ts + (k + 1);
         double acc = 0.0;
-        for (int jj = k + 2 + threadIdx.x; jj <= n; jj += 64 * W) acc = fma(f5o[jj], fca[(jj - 2 - k) * ld], acc);
+        for (int jj = k + 2 + threadIdx.x; jj <= n; jj += 64 * WR) acc = fma(f5o[jj], fca[(jj - 2 - k) * ld], acc);
         acc = wsum_vl(acc);
         if (lane == 0) part[0][w][0] = acc;
         __syncthreads();
         if (threadIdx.x == 0) {
             double t = 0.0;
 #pragma unroll
-            for (int q = 0; q < W; q++) t += part[0][q][0];
+            for (int q = 0; q < WR; q++) t += part[0][q][0];
             f5o[k] = f5o[k + 1] * L->lam + t * L->lam2;
         }
         return;
@@ -603,7 +652,13 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(6, 8))) 
     // two-molecule form: the sides of an ENCLOSING loop (letters io..i and j+1..jo+1) may not cross the missing gap
     const int l1max = (CUT && valid && cut <= i - 1) ? i - 2 - cut : 99;
     const int l2max = (CUT && valid && cut >= j + 1) ? cut - j - 2 : 99;
-    const bool masked = CUT && __any(l1max < kMaxSingle || l2max < kMaxSingle);
+    // MODE 1: cell (i, j-1) of diagonal d-1
+    const bool valid1 = MODE == 1 && i <= ncell1;
+    const int j1 = j - 1;
+    const int l1max1 = (CUT && valid1 && cut <= i - 1) ? i - 2 - cut : 99;
+    const int l2max1 = (CUT && valid1 && cut >= j1 + 1) ? cut - j1 - 2 : 99;
+    const bool guard_m1 = MODE == 1 && d1 >= 2;
+    const bool masked = CUT && __any(l1max < kMaxSingle || l2max < kMaxSingle || l1max1 < kMaxSingle || l2max1 < kMaxSingle);
 
     const size_t at = d * ld + i;
     const bool up_ok = i - 1 >= 1 && j + 1 <= n - 1;
@@ -611,51 +666,136 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(6, 8))) 
     const int idd = 25 * (5 * s_jp1 + (GAPOK(j + 1) ? s_jp2 : 0)) + 5 * s_i + (GAPOK(i - 1) ? s_im1 : 0);
     const int idx_raw = 25 * (5 * s_jp1 + s_jp2) + 5 * s_i + s_im1;
     double accm = 0.0, acc1 = 0.0, accc = 0.0, accb = 0.0;
-    if (guard_m) {
-        constexpr int UO = 6;
+    double accmn = 0.0, acc1n = 0.0, acccn = 0.0, accbn = 0.0;   // MODE 1: diagonal d-1 without its e = 1 terms
+    if constexpr (MODE == 2) {
+        // the look-ahead sums of the previous launch + the e = 1 terms (row d+1) + the block products
+        if (valid) {
+            accm = rowp[i]; acc1 = rowp[B.ld + i]; accc = rowp[2 * B.ld + i]; accb = rowp[3 * B.ld + i];
+            if (guard_m) {
+                int mineA = i - 1, mineB = n - 1 - j;
+                if (BS > 0) {
+                    const int limA = i - (i / (BS > 0 ? BS : 1) - 1) * BS, limB = (j / (BS > 0 ? BS : 1) + 2) * BS - 1 - j;
+                    mineA = mineA < limA ? mineA : limA; mineB = mineB < limB ? mineB : limB;
+                }
+                if (1 <= mineA) accm = fma(tab[VL_FM2O * ts + (d + 1) * ld + i - 1], tab[VL_FM1 * ts + ld + i - 1], accm);
+                if (1 <= mineB) acc1 = fma(tab[VL_FM2O * ts + (d + 1) * ld + i], tab[VL_FM * ts + ld + j], acc1);
+                if (BS > 0) { accm += tab[VL_FMOF * ts + d * ld + i]; acc1 += tab[VL_FM1OF * ts + d * ld + i]; }
+            } else { accm = 0.0; acc1 = 0.0; }
+        }
+        if (!pairable) { accc = 0.0; accb = 0.0; }
+    } else {
+    if (guard_m || guard_m1) {
+        constexpr int UO = MODE == 1 ? 4 : 6;
         {   // FMo[i,d] += FM2o[d+e][i-e] * FM1[e][i-e]; blocks <= I-2 come from FMOF
-            const int i_last = ncell < i0 + 63 ? ncell : i0 + 63;
+            const int ncl = MODE == 1 ? ncell1 : ncell;
+            const int i_last = ncl < i0 + 63 ? ncl : i0 + 63;
             const int emax = BS > 0 ? (i_last - 1 < 2 * BS ? i_last - 1 : 2 * BS) : i_last - 1;
             const double* __restrict__ x = tab + VL_FM2O * ts + i;
             const double* __restrict__ y = tab + VL_FM1 * ts + i;
-            int mine = valid ? i - 1 : 0;
-            if (BS > 0 && valid) { const int lim = i - (i / BS - 1) * BS; mine = mine < lim ? mine : lim; }
+            int mine = valid && guard_m ? i - 1 : 0, mine1 = valid1 && guard_m1 ? i - 1 : 0;
+            if (BS > 0) { const int lim = i - (i / (BS > 0 ? BS : 1) - 1) * BS; mine = mine < lim ? mine : lim; mine1 = mine1 < lim ? mine1 : lim; }
             for (int e = 1 + w; e <= emax; e += UO * W) {
-                double xv[UO], yv[UO];
+                double xv[UO], xn[UO], yv[UO];
 #pragma unroll
                 for (int u = 0; u < UO; u++) {
                     const int ee = e + u * W;
-                    const bool ok = ee <= mine;
+                    const bool ok = ee <= mine, ok1 = MODE == 1 && ee <= mine1 && ee >= 2;
                     xv[u] = ok ? x[(d + ee) * ld - ee] : 0.0;
-                    yv[u] = ok ? y[ee * ld - ee] : 0.0;
+                    xn[u] = ok1 ? x[(d1 + ee) * ld - ee] : 0.0;
+                    yv[u] = (ok || ok1) ? y[ee * ld - ee] : 0.0;
                 }
 #pragma unroll
-                for (int u = 0; u < UO; u++) accm = fma(xv[u], yv[u], accm);
+                for (int u = 0; u < UO; u++) { accm = fma(xv[u], yv[u], accm); if (MODE == 1) accmn = fma(xn[u], yv[u], accmn); }
             }
-            if (BS > 0 && valid && w == 0) accm += tab[VL_FMOF * ts + d * ld + i];
+            if (BS > 0 && valid && guard_m && w == 0) accm += tab[VL_FMOF * ts + d * ld + i];
         }
         {   // FM1o[i,d] += FM2o[d+e][i] * FM[e][i+d]; blocks >= J+2 come from FM1OF
-            const int emax_all = n - 1 - (i0 + d);
+            const int emax_all = n - 1 - (i0 + (MODE == 1 ? d1 : d));
             const int emax = BS > 0 ? (emax_all < 2 * BS ? emax_all : 2 * BS) : emax_all;
             const double* __restrict__ x = tab + VL_FM2O * ts + i;
             const double* __restrict__ y = tab + VL_FM * ts + j;
-            int mine = valid ? n - 1 - j : 0;
-            if (BS > 0 && valid) { const int lim = (j / BS + 2) * BS - 1 - j; mine = mine < lim ? mine : lim; }
+            int mine = valid && guard_m ? n - 1 - j : 0, mine1 = valid1 && guard_m1 ? n - 1 - j1 : 0;
+            if (BS > 0) {
+                const int lim = (j / (BS > 0 ? BS : 1) + 2) * BS - 1 - j, lim1 = (j1 / (BS > 0 ? BS : 1) + 2) * BS - 1 - j1;
+                mine = mine < lim ? mine : lim; mine1 = mine1 < lim1 ? mine1 : lim1;
+            }
             for (int e = 1 + w; e <= emax; e += UO * W) {
-                double xv[UO], yv[UO];
+                double xv[UO], yv[UO], xn[UO], yn[UO];
 #pragma unroll
                 for (int u = 0; u < UO; u++) {
                     const int ee = e + u * W;
-                    const bool ok = ee <= mine;
+                    const bool ok = ee <= mine, ok1 = MODE == 1 && ee <= mine1 && ee >= 2;
                     xv[u] = ok ? x[(d + ee) * ld] : 0.0;
                     yv[u] = ok ? y[ee * ld] : 0.0;
+                    xn[u] = ok1 ? x[(d1 + ee) * ld] : 0.0;
+                    yn[u] = ok1 ? y[ee * ld - 1] : 0.0;
                 }
 #pragma unroll
-                for (int u = 0; u < UO; u++) acc1 = fma(xv[u], yv[u], acc1);
+                for (int u = 0; u < UO; u++) { acc1 = fma(xv[u], yv[u], acc1); if (MODE == 1) acc1n = fma(xn[u], yn[u], acc1n); }
             }
-            if (BS > 0 && valid && w == 0) acc1 += tab[VL_FM1OF * ts + d * ld + i];
+            if (BS > 0 && valid && guard_m && w == 0) acc1 += tab[VL_FM1OF * ts + d * ld + i];
         }
     }
+    if constexpr (MODE == 1) {
+        // staged row r = 2..31 is table row d+1+r: filter / bulge length t = r-1 of diagonal d, t = r of diagonal d-1
+        const int room1 = n - 3 - d;
+        if (room1 >= 2) {
+            constexpr int LAST = kMaxSingle + 1, HALF = (kMaxSingle + 1) / 2;
+            const int rmax = room1 < LAST ? room1 : LAST;
+            const double* __restrict__ fcox = tab + VL_FCOX * ts;
+            const double* __restrict__ fcob = tab + VL_FCOB * ts;
+            constexpr int NSEG = 2 * ((kMaxSingle / 2 + W) / W);
+            int rseg[NSEG];
+            double bA[NSEG], bB[NSEG];
+#pragma unroll
+            for (int q = 0; q < NSEG; q++) {
+                const int g = w + (q >> 1) * W;
+                const int r = (q & 1) ? LAST - g : g;
+                const bool on = g <= HALF && r <= rmax && r >= 2;
+                rseg[q] = on ? r : -1;
+                bA[q] = bB[q] = 0.0;
+                if (on) {
+                    const int cmax = n - 1 - (d + 1 + r);         // last interior column of the source row
+                    if (r >= 4) {
+                        const int col0 = i0 - 1 - r;
+                        const double* __restrict__ row = fcox + (d + 1 + r) * ld;
+                        const int c = col0 + lane;
+                        gbuf[w][q][lane] = (c >= 1 && c <= cmax) ? row[c] : 0.0;
+                        const int c2 = col0 + 64 + lane;
+                        if (lane < 32) gbuf[w][q][64 + lane] = (c2 >= 1 && c2 <= cmax) ? row[c2] : 0.0;
+                    }
+                    // bulges: outer pair at column i-1 (3' side) or i-1-t (5' side) of the source row
+                    const double* __restrict__ row = fcob + (d + 1 + r) * ld;
+                    const int tA = r - 1, c0 = i - 1, cA = i - 1 - tA, cB = i - 1 - r;
+                    const bool in0 = c0 >= 1 && c0 <= cmax;
+                    const bool a0 = valid && tA >= 2 && in0 && l1max >= 0 && tA <= l2max;
+                    const bool a1 = valid && tA >= 2 && cA >= 1 && cA <= cmax && tA <= l1max && l2max >= 0;
+                    const bool b0 = valid1 && r <= kMaxSingle && in0 && l1max1 >= 0 && r <= l2max1;
+                    const bool b1 = valid1 && r <= kMaxSingle && cB >= 1 && cB <= cmax && r <= l1max1 && l2max1 >= 0;
+                    const double x0 = (a0 || b0) ? row[c0] : 0.0;
+                    bA[q] = (a0 ? x0 : 0.0) + (a1 ? row[cA] : 0.0);
+                    bB[q] = (b0 ? x0 : 0.0) + (b1 ? row[cB] : 0.0);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NSEG; q++)
+                if (rseg[q] >= 0) {
+                    const int r = rseg[q];
+                    if (r >= 4) {
+                        const double* __restrict__ wA = L->shape_w + (r - 1) * r / 2;
+                        const double* __restrict__ wB = L->shape_w + (r <= kMaxSingle ? r * (r + 1) / 2 : 0);
+                        double sa, sb;
+                        if (masked) vfilt_pair_rev_m(r, wA, wB, &gbuf[w][q][lane], l1max, l2max, l1max1, l2max1, sa, sb);
+                        else vfilt_pair_rev_any(r, wA, wB, &gbuf[w][q][lane], sa, sb);
+                        accc += sa;
+                        acccn += sb;
+                    }
+                    if (r - 1 >= 2) accb = fma(L->WB[r - 1], bA[q], accb);
+                    if (r <= kMaxSingle) accbn = fma(L->WB[r], bB[q], accbn);
+                }
+            if (!pairable) { accc = 0.0; accb = 0.0; }
+        }
+    } else
     {   // enclosing generic loops (staged, zero-filled outside the interior) and long bulges over FCoB
         const int room = n - 4 - d;
         if (room >= 0) {
@@ -702,11 +842,23 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(6, 8))) 
             if (!pairable) { accc = 0.0; accb = 0.0; }
         }
     }
-    part[0][w][lane] = accm;
-    part[1][w][lane] = acc1;
-    part[2][w][lane] = accc;
-    part[3][w][lane] = accb;
-    __syncthreads();
+    }
+    if constexpr (MODE != 2) {
+        part[0][w][lane] = accm;
+        part[1][w][lane] = acc1;
+        part[2][w][lane] = accc;
+        part[3][w][lane] = accb;
+        if constexpr (MODE == 1) { part[4][w][lane] = accmn; part[5][w][lane] = acc1n; part[6][w][lane] = acccn; part[7][w][lane] = accbn; }
+        __syncthreads();
+        if constexpr (MODE == 1) {
+            if (w == 1 && i < ld) {   // the look-ahead sums of diagonal d-1
+                double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+#pragma unroll
+                for (int k = 0; k < W; k++) { p0 += part[4][k][lane]; p1 += part[5][k][lane]; p2 += part[6][k][lane]; p3 += part[7][k][lane]; }
+                rowp[i] = p0; rowp[B.ld + i] = p1; rowp[2 * B.ld + i] = p2; rowp[3 * B.ld + i] = p3;
+            }
+        }
+    }
     if (w != 0 || !valid) return;
     double e_txo = 0, e_tmc = 0, e_txi = 0, e_tsa = 0, e_tau = 1;
     double o_fmso = 0, o_fm1o = 0, o_f5o = 0, o_f5i = 0, o_fm1o_up = 0, o_fc = 0, o_z = 1, sm7 = 0.0, o_x = 0.0;
@@ -740,9 +892,12 @@ __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(6, 8))) 
         }
     }
 
-    double sm = 0.0, s1 = 0.0, g = 0.0, gb = 0.0;
+    double sm = accm, s1 = acc1, g = accc, gb = accb;
+    if constexpr (MODE != 2) {
+        sm = 0.0; s1 = 0.0; g = 0.0; gb = 0.0;
 #pragma unroll
-    for (int k = 0; k < W; k++) { sm += part[0][k][lane]; s1 += part[1][k][lane]; g += part[2][k][lane]; gb += part[3][k][lane]; }
+        for (int k = 0; k < W; k++) { sm += part[0][k][lane]; s1 += part[1][k][lane]; g += part[2][k][lane]; gb += part[3][k][lane]; }
+    }
 
     double fmo = 0.0, fmso = 0.0, fm1o = 0.0;
     if (guard_m) {
@@ -997,12 +1152,16 @@ __global__ __launch_bounds__(256) void vlin_acc_final(McBatch B, const VLinModel
 
 #define RH_VINST(BS, CUT)                                                                                   \
     template __global__ void vlin_inside_diag<8, BS, CUT, 0>(McBatch, const VLinModel*, int, double, int);  \
-    template __global__ void vlin_outside_diag<8, BS, CUT>(McBatch, const VLinModel*, int, int, int*);
+    template __global__ void vlin_outside_diag<8, BS, CUT, 0>(McBatch, const VLinModel*, int, int, int*);
 RH_VINST(16, false) RH_VINST(0, false) RH_VINST(16, true) RH_VINST(0, true)
 #undef RH_VINST
 template __global__ void vlin_inside_diag<8, 16, false, 1>(McBatch, const VLinModel*, int, double, int);   // look-ahead pairs
 template __global__ void vlin_inside_diag<8, 16, false, 2>(McBatch, const VLinModel*, int, double, int);
 template __global__ void vlin_inside_diag<8, 16, true, 1>(McBatch, const VLinModel*, int, double, int);
 template __global__ void vlin_inside_diag<8, 16, true, 2>(McBatch, const VLinModel*, int, double, int);
+template __global__ void vlin_outside_diag<8, 16, false, 1>(McBatch, const VLinModel*, int, int, int*);
+template __global__ void vlin_outside_diag<8, 16, false, 2>(McBatch, const VLinModel*, int, int, int*);
+template __global__ void vlin_outside_diag<8, 16, true, 1>(McBatch, const VLinModel*, int, int, int*);
+template __global__ void vlin_outside_diag<8, 16, true, 2>(McBatch, const VLinModel*, int, int, int*);
 
 }  // namespace rh

@@ -65,7 +65,7 @@ __global__ void mcv_acc_final(McBatch B, const ViennaDx* __restrict__ V, const d
 __global__ void mcv_finish(McBatch B, double* __restrict__ logz);
 __global__ void vlin_init(McBatch B, int* __restrict__ bad);
 template <int W, int BS, bool CUT, int MODE> __global__ void vlin_inside_diag(McBatch B, const VLinModel* __restrict__ L, int d, double hp_d, int pin);
-template <int W, int BS, bool CUT> __global__ void vlin_outside_diag(McBatch B, const VLinModel* __restrict__ L, int d, int pin, int* __restrict__ bad);
+template <int W, int BS, bool CUT, int MODE> __global__ void vlin_outside_diag(McBatch B, const VLinModel* __restrict__ L, int d, int pin, int* __restrict__ bad);
 __global__ void vlin_finish(McBatch B, const VLinModel* __restrict__ L, double* __restrict__ logz, int* __restrict__ bad);
 __global__ void mcv_extract_hp(McBatch B, double* __restrict__ hp, size_t hp_stride, int ldd, double* __restrict__ logz, double lin_s, int* __restrict__ bad);
 }  // namespace rh
@@ -463,7 +463,7 @@ int stage(rh_ctx* c, int ns, const char* const* seqs, const int* lens, bool with
         B.pk_stride = (size_t)B.nb * (B.nb + 1) / 2 * 256;
         if ((rc = ensure(c, &c->d_pk, &c->cap_pk, sizeof(double) * B.pk_stride * kPkCopies * ns, false))) return rc;
         B.pk = (double*)c->d_pk;
-        if ((rc = ensure(c, &c->d_rowp, &c->cap_rowp, sizeof(double) * 3 * B.ld * ns, false))) return rc;
+        if ((rc = ensure(c, &c->d_rowp, &c->cap_rowp, sizeof(double) * 4 * B.ld * ns, false))) return rc;
         B.rowp = (double*)c->d_rowp;
         if ((rc = ensure(c, &c->d_f5, &c->cap_f5, sizeof(double) * 2 * B.ld * ns, false))) return rc;
         if ((rc = ensure(c, &c->d_up, &c->cap_up, sizeof(double) * B.ld * c->max_w * ns, false))) return rc;
@@ -557,7 +557,7 @@ int stage(rh_ctx* c, int ns, const char* const* seqs, const int* lens, bool with
             C.pk_stride = (size_t)C.nb * (C.nb + 1) / 2 * 256;
             if ((rc = ensure(c, &c->d_copk, &c->cap_copk, sizeof(double) * C.pk_stride * kPkCopies * np, false))) return rc;
             C.pk = (double*)c->d_copk;
-            if ((rc = ensure(c, &c->d_corowp, &c->cap_corowp, sizeof(double) * 3 * C.ld * np, false))) return rc;
+            if ((rc = ensure(c, &c->d_corowp, &c->cap_corowp, sizeof(double) * 4 * C.ld * np, false))) return rc;
             C.rowp = (double*)c->d_corowp;
             if ((rc = ensure(c, &c->d_cof5, &c->cap_cof5, sizeof(double) * 6 * C.ld * np, false))) return rc;
             if ((rc = ensure(c, &c->d_cobp, &c->cap_cobp, sizeof(double) * C.tri_stride * np, false))) return rc;
@@ -724,14 +724,34 @@ int launch_mc_vlin(rh_ctx* c, int pin, int phase, bool co)
         (*nl) += far_outside_begin(c, B, st, last_block);
         for (int D = last_block; D >= 0 && (D + 1) * BS - 1 > B.nmax - 2; D--) { (*nl) += far_outside_step(c, B, st, D, last_block); (*nf)++; }
     }
-    for (int d = B.nmax - 2; d >= 0; d--) {
-        if (BS > 0 && (d + 1) % BS == 0) {
+    const bool la = BS == 16 && c->lookahead;   // look-ahead pairs (odd diagonal: full launch + the sums of the next, even: one wavefront per group)
+    for (int d = la ? ((B.nmax - 2) | 1) : B.nmax - 2; d >= 0; d--) {
+        if (BS > 0 && (d + 1) % BS == 0 && d <= B.nmax - 2) {
             const int D = (d + 1) / BS - 1;
             if (D >= 0 && D <= last_block) { (*nl) += far_outside_step(c, B, st, D, last_block); (*nf)++; }
         }
-        const int groups = (B.nmax - 1 - d + 63) / 64 + extra;
-        if (co) KLAUNCH(c, 2, (vlin_outside_diag<W, BS, true>), pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(64 * W), st, B, c->d_vlin, d, pin, bad);
-        else KLAUNCH(c, 2, (vlin_outside_diag<W, BS, false>), pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(64 * W), st, B, c->d_vlin, d, pin, bad);
+        bool done = false;
+        if constexpr (BS == 16) {
+            if (la) {
+                done = true;
+                if (d & 1) {
+                    const int groups = (B.nmax - d + 63) / 64 + extra;   // cells of diagonal d-1
+                    const dim3 grid = pin ? dim3(B.ns, groups) : dim3(groups, B.ns);
+                    if (co) KLAUNCH(c, 2, (vlin_outside_diag<W, 16, true, 1>), grid, dim3(64 * W), st, B, c->d_vlin, d, pin, bad);
+                    else KLAUNCH(c, 2, (vlin_outside_diag<W, 16, false, 1>), grid, dim3(64 * W), st, B, c->d_vlin, d, pin, bad);
+                } else {
+                    const int groups = (B.nmax - 1 - d + 63) / 64 + extra;
+                    const dim3 grid = pin ? dim3(B.ns, groups) : dim3(groups, B.ns);
+                    if (co) KLAUNCH(c, 2, (vlin_outside_diag<W, 16, true, 2>), grid, dim3(64), st, B, c->d_vlin, d, pin, bad);
+                    else KLAUNCH(c, 2, (vlin_outside_diag<W, 16, false, 2>), grid, dim3(64), st, B, c->d_vlin, d, pin, bad);
+                }
+            }
+        }
+        if (!done) {
+            const int groups = (B.nmax - 1 - d + 63) / 64 + extra;
+            if (co) KLAUNCH(c, 2, (vlin_outside_diag<W, BS, true, 0>), pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(64 * W), st, B, c->d_vlin, d, pin, bad);
+            else KLAUNCH(c, 2, (vlin_outside_diag<W, BS, false, 0>), pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(64 * W), st, B, c->d_vlin, d, pin, bad);
+        }
         (*nl)++;
     }
     if (co) {
