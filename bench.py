@@ -312,6 +312,8 @@ def main():
                 hits = [v for k2, v in tj.items() if name and name.split("<")[0] in k2 and ("mfma" in name) == ("mfma" in k2)]
                 return hits[0] if hits else None
             tf, tb = per_dispatch(dom), per_dispatch(kd["block_product_kernel"])
+            if tb is not None and (kd["block_product_kernel"] or "").endswith("_pk"):
+                tb += per_dispatch("lin_pack_tiles") or 0.0   # the operand-packing launch that precedes each product
             if tf is not None and (tb is not None or not kd["of_which_block_product"]):
                 nfine = kd["launches_per_step"] - kd["of_which_block_product"]
                 traffic = (tf * nfine + (tb or 0.0) * kd["of_which_block_product"]) / kd["launches_per_step"]

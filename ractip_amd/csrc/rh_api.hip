@@ -648,31 +648,29 @@ int launch_mc_vienna(rh_ctx* c, int pin)
 //   inside : far(D) uses FM1/FM tiles of block diagonals 2..D-2; block diagonal D-2 completes with fine diagonal (D-1)*16-1
 //   outside: far(D) uses FM2o tiles of block diagonals >= D+2 (final before fine diagonal (D+1)*16-1) and FM1/FM tiles of
 //            every block diagonal (the last two are packed when the outside phase starts)
-// returns the number of launches
+// returns the number of launches it counts: 1 (the pack launch rides with its product; bench.py adds its traffic to the product's)
 static int far_inside_step(rh_ctx* c, const McBatch& B, hipStream_t st, int D, int last_block)
 {
     if (c->exp_nofar) return 0;
     if (!c->far_pk) { KLAUNCH(c, 1, lin_far_inside_mfma, dim3(last_block - D + 1, B.ns), dim3(256), st, B, D); return 1; }
     KLAUNCH(c, 1, lin_pack_tiles, dim3(B.nb - (D - 2), B.ns, 2), dim3(256), st, B, D - 2, 0);
     KLAUNCH(c, 1, lin_far_inside_pk, dim3(last_block - D + 1, B.ns), dim3(256), st, B, D);
-    return 2;
+    return 1;
 }
 static int far_outside_begin(rh_ctx* c, const McBatch& B, hipStream_t st, int last_block)
 {
     if (c->exp_nofar || !c->far_pk) return 0;
-    int nl = 0;
-    for (int Dblk = std::max(2, last_block - 1); Dblk <= last_block; Dblk++, nl++)
+    for (int Dblk = std::max(2, last_block - 1); Dblk <= last_block; Dblk++)
         KLAUNCH(c, 3, lin_pack_tiles, dim3(B.nb - Dblk, B.ns, 2), dim3(256), st, B, Dblk, 0);
-    return nl;
+    return 0;
 }
 static int far_outside_step(rh_ctx* c, const McBatch& B, hipStream_t st, int D, int last_block)
 {
     if (c->exp_nofar) return 0;
     if (!c->far_pk) { KLAUNCH(c, 3, lin_far_outside_mfma, dim3(last_block - D + 1, B.ns, 2), dim3(256), st, B, D); return 1; }
-    int nl = 1;
-    if (D + 2 <= last_block) { KLAUNCH(c, 3, lin_pack_tiles, dim3(B.nb - (D + 2), B.ns, 1), dim3(256), st, B, D + 2, 1); nl++; }
+    if (D + 2 <= last_block) KLAUNCH(c, 3, lin_pack_tiles, dim3(B.nb - (D + 2), B.ns, 1), dim3(256), st, B, D + 2, 1);
     KLAUNCH(c, 3, lin_far_outside_pk, dim3(last_block - D + 1, B.ns, 2), dim3(256), st, B, D);
-    return nl;
+    return 1;
 }
 
 // ---- Vienna-BL McCaskill sweeps, scaled linear-space path (mccaskill_vlin.hip) with the block products of mccaskill_far.hip.
