@@ -223,6 +223,197 @@ __global__ __launch_bounds__(64 * W) RH_WPE_DX void dxl_sweep(DxLinBatch B, cons
     }
 }
 
+// ---------------------------------------------------------------------------------
+// Four anti-diagonals per launch.  Launch `step` covers, per direction, the diagonals X_k = A + k*dir, k = 0..3 (inside:
+// A = 2+4*step, dir = +1; outside: A = Smax-4*step, dir = -1).  Diagonal X_k reads only rows X_k - dir*2 and beyond, so
+//   * every window row of all four (rows A - dir*(2+t), t = 0..28) is final before the launch: the window of length t on that
+//     row belongs to X_0, and X_1 / X_2 / X_3 read the same row with length t+1 / t+2 / t+3 over the same columns plus one /
+//     two / three -- the wavefront that sums it adds three more taps and serves all four cells of the lane;
+//   * X_0 and X_1 read nothing of this launch; X_2 reads X_0 (stacked pair, column a-dir), X_3 reads X_1 (stacked) and X_0
+//     (the 0x1 / 1x0 loops, columns a-dir, a-2*dir).  Wavefronts 0 / 1 finish X_0 / X_1 and leave their values in LDS,
+//     wavefronts 2 / 3 have meanwhile loaded the other operands of X_2 / X_3 and finish them after one barrier.
+// A lane needs its neighbours a-dir and a-2*dir of the same group: groups advance by 62 columns, X_2 / X_3 are written by the
+// 62 lanes that have both neighbours (all 64 in the group at the open end), X_0 / X_1 by all 64 (two columns twice, bit for bit).
+struct DxCellOps { double o_st, o_01, o_10, o_02, o_11, o_20, e_up, e_dn, e_ends, e_st, e_b01, e_b10, e_11; };
+
+// coefficient part of the operands of cell (sd, a) and the loads of the rows it may take from memory (mask bit k: row sd+dir*(2+k))
+__device__ __forceinline__ DxCellOps dx_cell_ops(int lda, const DxLinModel* __restrict__ L, const double* __restrict__ rawt,
+                                                 const double* __restrict__ dect, const uint8_t* __restrict__ s1, const uint8_t* __restrict__ s2,
+                                                 bool outside, int sd, int a, int L1, int L2, int smax, int rows_mask, bool* pairable)
+{
+    DxCellOps o = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const int b = sd - a, i = a, j = L2 + 1 - b;
+    const bool incell = sd >= 2 && sd <= smax && a >= 1 && a <= L1 && b >= 1 && b <= L2;
+    *pairable = false;
+    if (!incell) return o;
+    const int x = s1[i], xm = s1[i - 1], xp = s1[i + 1], y = s2[j], ym = s2[j - 1], yp = s2[j + 1];
+    if (!pairs(x, y)) return o;
+    *pairable = true;
+    const int dir = outside ? 1 : -1;     // sources lie at rows sd + dir*(2+t), columns a + dir*(1+l1)
+    const int r2 = sd + 2 * dir, r3 = sd + 3 * dir, r4 = sd + 4 * dir;
+    if ((rows_mask & 1) && r2 >= 2 && r2 <= smax) o.o_st = rawt[(size_t)r2 * lda + a + dir];
+    if ((rows_mask & 2) && r3 >= 2 && r3 <= smax) { o.o_01 = dect[(size_t)r3 * lda + a + dir]; o.o_10 = dect[(size_t)r3 * lda + a + 2 * dir]; }
+    if ((rows_mask & 4) && r4 >= 2 && r4 <= smax) {
+        o.o_02 = dect[(size_t)r4 * lda + a + dir]; o.o_11 = dect[(size_t)r4 * lda + a + 2 * dir]; o.o_20 = dect[(size_t)r4 * lda + a + 3 * dir];
+    }
+    o.e_up = L->E_tm[((x * 5 + y) * 5 + xp) * 5 + ym];                          // terminal_mismatch[s1[i]][s2[j]][s1[i+1]][s2[j-1]]
+    o.e_dn = L->E_tm[((y * 5 + x) * 5 + yp) * 5 + xm] * L->E_bp[x * 5 + y];     // terminal_mismatch[s2[j]][s1[i]][s2[j+1]][s1[i-1]] * base_pair
+    if (!outside) {
+        o.e_ends = L->E_dr[y * 25 + x * 5 + xm] * L->E_dl[y * 25 + x * 5 + yp] * L->E_bp[y * 5 + x] * L->E_hc[y * 5 + x];
+        o.e_st = L->E_bp[x * 5 + y] * L->E_hs[((xm * 5 + yp) * 5 + x) * 5 + y];
+        o.e_b01 = L->E_b01[yp]; o.e_b10 = L->E_b10[xm]; o.e_11 = L->E_11[xm * 5 + yp];
+    } else {
+        o.e_ends = L->E_dl[x * 25 + y * 5 + xp] * L->E_dr[x * 25 + y * 5 + ym] * L->E_hc[x * 5 + y];
+        o.e_st = L->E_bp[xp * 5 + ym] * L->E_hs[((x * 5 + y) * 5 + xp) * 5 + ym];
+        o.e_b01 = L->E_b01[ym]; o.e_b10 = L->E_b10[xp]; o.e_11 = L->E_11[xp * 5 + ym];
+    }
+    return o;
+}
+// inside : inside[i][j]  = open  + stack + down * (0x1/1x0/t=2 shapes + windows)   (DuplexEngine.ipp:1029-1064)
+// outside: outside[p][q] = close + stack + up   * (...)                             (DuplexEngine.ipp:1094-1129, pulled)
+__device__ __forceinline__ void dx_cell_value(const DxLinModel* __restrict__ L, const DxCellOps& o, bool outside, double pw, double g, double* v, double* vx)
+{
+    const double l2 = L->lam_pow[2], l3 = L->lam_pow[3], l4 = L->lam_pow[4];
+    const double ends = pw * o.e_ends;
+    const double sp = l3 * (o.e_b01 * o.o_01 + o.e_b10 * o.o_10) + l4 * (o.o_02 + o.e_11 * o.o_11 + o.o_20);
+    const double own = outside ? o.e_up : o.e_dn;      // this cell's factor of every loop term
+    *v = ends + o.o_st * l2 * o.e_st + own * (sp + g);
+    *vx = *v * (outside ? o.e_dn : o.e_up);            // decorated as the other end of a later loop
+}
+
+// windows of wavefront WV: rows t = WV, WV+4, ... <= 28 (row index relative to X_0: table row A - dir*(2+t)); lengths are
+// compile-time constants.  seg0[q*96 + k]: inside column a-4-t+k (X_0's window = seg[3..3+t], X_k adds seg[3-k]); outside
+// column a+1+k (X_0's window = seg[0..t], X_k adds seg[t+k])
+template <int WV>
+__device__ __forceinline__ void win_pass4(const double* seg0, const double* __restrict__ lam_pow, bool outside, int sdA, int smax, double acc[4])
+{
+    if constexpr (WV < 4) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int t = WV + 4 * q;        // compile-time after unrolling
+            if (t > 28) continue;
+            const int row = outside ? sdA + 2 + t : sdA - 2 - t;
+            if (row >= 2 && row <= smax) {
+                lds_vptr vs = (lds_vptr)(seg0 + q * 96);
+                double s0 = 0.0, s1 = 0.0;
+                const int base = outside ? 0 : 3;
+#pragma unroll
+                for (int k = 0; k <= t; k += 2) {
+                    s0 += vs[base + k];
+                    if (k + 1 <= t) s1 += vs[base + k + 1];
+                }
+                const double w0 = s0 + s1;
+                const double w1 = w0 + (outside ? vs[t + 1] : vs[2]);
+                const double w2 = w1 + (outside ? vs[t + 2] : vs[1]);
+                const double w3 = w2 + (outside ? vs[t + 3] : vs[0]);
+                if (t >= 3) acc[0] = fma(lam_pow[t + 2], w0, acc[0]);                 // lengths 3..28 only
+                if (t + 1 >= 3 && t + 1 <= 28) acc[1] = fma(lam_pow[t + 3], w1, acc[1]);
+                if (t + 2 >= 3 && t + 2 <= 28) acc[2] = fma(lam_pow[t + 4], w2, acc[2]);
+                if (t + 3 <= 28) acc[3] = fma(lam_pow[t + 5], w3, acc[3]);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) RH_WPE_DX void dxl_sweep4(DxLinBatch B, const DxLinModel* __restrict__ L, int step, int groups)
+{
+    __shared__ double buf[4][8][96];
+    __shared__ double part[4][4][64];
+    __shared__ double hand[3][64];      // raw X_0, decorated X_0, raw X_1 of this group's columns
+    const int pr = blockIdx.y;
+    const int L1 = B.n[2 * pr], L2 = B.n[2 * pr + 1];
+    const bool outside = blockIdx.z != 0;
+    const int grp = blockIdx.x;
+    const int smax = L1 + L2;
+    const int dir = outside ? 1 : -1, fwd = -dir;               // X_k = A + k*fwd
+    const int sdA = outside ? smax - 4 * step : 2 + 4 * step;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int a0 = grp * 62;
+    if (a0 > B.n1max + 1) return;
+    const int a = a0 + lane;
+    const int lda = B.lda;
+    const size_t ts = B.tab_stride;
+    double* __restrict__ tab = B.tab + (size_t)pr * B.pair_stride;
+    const uint8_t* __restrict__ s1 = B.seq + (size_t)(2 * pr) * B.lds;
+    const uint8_t* __restrict__ s2 = B.seq + (size_t)(2 * pr + 1) * B.lds;
+    if (outside ? sdA < 2 : sdA > smax) return;                 // none of the four diagonals exists
+    // lanes that write X_2 / X_3: those with both neighbours a+dir, a+2*dir in this group, and everything at the open end
+    const bool owns23 = outside ? (lane <= 61 || a0 + 62 > B.n1max + 1) : (lane >= 2 || grp == 0);
+    bool has = false;   // does this group hold cells [max(1, sd-L2), min(L1, sd-1)] of any of the four diagonals?
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int sd = sdA + k * fwd;
+        has = has || (sd >= 2 && sd <= smax && !(a0 + 63 < (sd - L2 > 1 ? sd - L2 : 1) || a0 > (sd - 1 < L1 ? sd - 1 : L1)));
+    }
+    const int sdw = sdA + w * fwd;      // the diagonal wavefront w finishes
+    const bool mine = sdw >= 2 && sdw <= smax;
+    const size_t at = (size_t)sdw * lda + kDxPad + a;
+    if (!has) {   // only clear the columns of the rows
+        if (mine && a <= B.n1max + 1 && (w < 2 || owns23)) {
+            tab[(outside ? DL_OUT : DL_IN) * ts + at] = 0.0;
+            tab[(outside ? DL_OUTX : DL_INX) * ts + at] = 0.0;
+        }
+        return;
+    }
+
+    // ---- windows (all four wavefronts): stage the rows t = w, w+4, ... then sum
+    const double* __restrict__ src = tab + (outside ? DL_OUTX : DL_INX) * ts + kDxPad;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const int t = w + 4 * q;
+        const int row = outside ? sdA + 2 + t : sdA - 2 - t;
+        if (t <= 28 && row >= 2 && row <= smax) {   // wave-uniform
+            const int c0 = outside ? a0 + 1 : a0 - 4 - t;
+            const double* __restrict__ r = src + (size_t)row * lda + c0;
+            buf[w][q][lane] = r[lane];
+            if (lane < 32) buf[w][q][64 + lane] = r[64 + lane];
+        }
+    }
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    switch (w) {
+#define X(V) case V: win_pass4<V>(&buf[w][0][lane], L->lam_pow, outside, sdA, smax, acc); break;
+        X(0) X(1) X(2) X(3)
+#undef X
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) part[k][w][lane] = acc[k];
+
+    // ---- epilogues: wavefront w finishes X_w.  Operands from rows of earlier launches are loaded now (before the barrier);
+    // X_2 takes its stacked-pair operand, X_3 its stacked-pair and 0x1 / 1x0 operands from `hand`
+    const double* __restrict__ rawt = tab + (outside ? DL_OUT : DL_IN) * ts + kDxPad;
+    const double* __restrict__ dect = tab + (outside ? DL_OUTX : DL_INX) * ts + kDxPad;
+    bool pairable;
+    DxCellOps o = dx_cell_ops(lda, L, rawt, dect, s1, s2, outside, sdw, a, L1, L2, smax, w < 2 ? 7 : (w == 2 ? 6 : 4), &pairable);
+    __syncthreads();
+    double g = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) g += part[w][k][lane];
+    double v = 0.0, vx = 0.0;
+    if (w < 2) {
+        if (mine && pairable) dx_cell_value(L, o, outside, B.pw4[w], g, &v, &vx);
+        if (w == 0) { hand[0][lane] = v; hand[1][lane] = vx; } else hand[2][lane] = v;
+    }
+    __syncthreads();
+    if (w >= 2) {
+        if (!mine || !owns23) return;
+        if (pairable) {
+            const int l1 = lane + dir, l2 = lane + 2 * dir;                  // neighbours a+dir, a+2*dir; beyond the open end: no cell
+            const bool in1 = l1 >= 0 && l1 < 64, in2 = l2 >= 0 && l2 < 64;
+            if (w == 2) o.o_st = in1 ? hand[0][l1] : 0.0;                    // X_2 stacks on X_0
+            else {                                                           // X_3 stacks on X_1, 0x1 / 1x0 loops close on X_0
+                o.o_st = in1 ? hand[2][l1] : 0.0;
+                o.o_01 = in1 ? hand[1][l1] : 0.0;
+                o.o_10 = in2 ? hand[1][l2] : 0.0;
+            }
+            dx_cell_value(L, o, outside, B.pw4[w], g, &v, &vx);
+        }
+    } else if (!mine) return;
+    if (a <= B.n1max + 1) {  // every column of the row is rewritten: stale values of other shapes never survive
+        tab[(outside ? DL_OUT : DL_IN) * ts + at] = v;
+        tab[(outside ? DL_OUTX : DL_INX) * ts + at] = vx;
+    }
+}
+
 // Z~ = sum IN~[a,b] * close~(a,b)                                                (DuplexEngine.ipp:1066-1073)
 // two stages, both in a fixed summation order (results do not depend on scheduling): kLzRows anti-diagonals per
 // workgroup, read along the rows of the table (coalesced), then one thread per pair adds the chunks in order.

@@ -527,8 +527,9 @@ def test_errors_are_reported_not_swallowed(ctx):
 
 
 def test_sweep_organisations_agree(hotlib, oracle, monkeypatch):
-    """The fused two-diagonal sweeps (default), the look-ahead pair of launches, the one-diagonal-per-launch kernels and the
-    block products with / without packed operand tiles are the same arithmetic up to summation order: every variant against
+    """The fused two-diagonal sweeps (default), the look-ahead pair of launches, the one-diagonal-per-launch kernels, the
+    block products with / without packed operand tiles and the duplex sweep with four / two anti-diagonals per launch are
+    the same arithmetic up to summation order: every variant against
     the CPU oracle at 1e-6 and against the default at 1e-10, on lengths around the 63/64-column group edges and the
     16-letter blocks."""
     import ractip_amd
@@ -557,7 +558,7 @@ def test_sweep_organisations_agree(hotlib, oracle, monkeypatch):
         assert abs(z - o["logZ"]) < 1e-9
         assert_prob_close(bp, o["post"], rel=REL, what="default n=%d" % len(s))
     for env in ({"RH_LOOKAHEAD": "1"}, {"RH_LOOKAHEAD": "0"}, {"RH_FAR_PK": "0"}, {"RH_LOOKAHEAD": "0", "RH_LIN_W": "8"}, {"RH_LIN_W": "8"},
-                {"RH_DX_W": "8"}):
+                {"RH_DX_W": "8"}, {"RH_DX_QUAD": "0"}):
         got, got_pairs = run(env)
         for (bp, z), (bp0, z0), s in zip(got, base, seqs):
             assert abs(z - z0) < 1e-10, (env, len(s))
