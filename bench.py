@@ -193,8 +193,9 @@ def main():
         n = max(len(oxys), len(fhla))
         all_pairs = _shard.zscore_shuffles(oxys, fhla, 12, batch * world, 1)
     else:
-        # measured on MI355X: 3024 pairs/s at 128 pairs/step vs 2739 at 64 (n=500); 110 at 16 vs 58 at 4 (n=2000)
-        batch = args.batch or (128 if n <= 600 else (32 if n <= 1200 else 16))
+        # measured on MI355X (r01_n): n=500: 6218 pairs/s at 256 pairs/step, 5976 at 128, 5182 at 64, 5995 at 512;
+        # n=2000: 271 at 32, 202 at 16; Vienna-BL n=500: 1007 at 128, 960 at 64
+        batch = args.batch or (256 if n <= 600 else (64 if n <= 1200 else 32))
         if args.model == "vienna" and not args.batch:
             batch = max(1, batch // 2)
         # every rank draws from ONE stream and keeps its own slice: distinct pairs per rank (weak scaling)

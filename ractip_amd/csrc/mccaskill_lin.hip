@@ -426,7 +426,7 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) RH_WPE_IN void lin_inside_
         // it.  (Two wavefronts: each holds one operand set -- in one wavefront the two sets cost ~50 VGPRs and a wavefront of
         // occupancy; operands are loaded after the term loops for the same reason.)
         if (w > 1) return;
-        __shared__ double hand[2][64];
+        double (*hand)[64] = part[0];   // FM / FM1 of row d: over wavefront 0's own look-behind sums, which only it reads (keeps the group at 32 KB: 5 per CU)
         double n_tjb = 0, n_tja = 0, n_tst = 0, n_bp = 0, n_tjbd = 0, n_tjad = 0, n_n01 = 0, n_n10 = 0, n_n11 = 0;
         double n_x01 = 0, n_x10 = 0, n_x11 = 0, n_fc = 0, n_fca = 0, n_a1 = 0, n_bd = 0, n_far = 0;
         double fm2n = 0.0, gn = 0.0;
