@@ -45,6 +45,11 @@ __global__ void lin_far_outside_pk(McBatch B, int D);
 __global__ void lin_finish(McBatch B, const LinModel* __restrict__ L, double* __restrict__ logz, int* __restrict__ bad);
 template <int W> __global__ void dxl_sweep(DxLinBatch B, const DxLinModel* __restrict__ L, int step, int groups);
 __global__ void dxl_sweep4(DxLinBatch B, const DxLinModel* __restrict__ L, int step, int groups);
+__global__ void dxvl_sweep4(DxLinBatch B, const VLinModel* __restrict__ L, const VDxLin* __restrict__ D, int step);
+__global__ void dxvl_logz_part(DxLinBatch B, const VLinModel* __restrict__ L, const VDxLin* __restrict__ D, double* __restrict__ zpart,
+                               int* __restrict__ cpart, int nchunk);
+__global__ void dxvl_logz_final(DxLinBatch B, double s, const double* __restrict__ zpart, const int* __restrict__ cpart, int nchunk,
+                                double* __restrict__ zbar, double* __restrict__ logz, int* __restrict__ bad);
 __global__ void dxl_logz_part(DxLinBatch B, const DxLinModel* __restrict__ L, double* __restrict__ zpart, int* __restrict__ cpart, int nchunk);
 __global__ void dxl_logz_final(DxLinBatch B, const DxLinModel* __restrict__ L, const double* __restrict__ zpart, const int* __restrict__ cpart, int nchunk,
                                double* __restrict__ zbar, double* __restrict__ logz, int* __restrict__ bad);
@@ -240,6 +245,9 @@ struct rh_ctx {
     ViennaDx* d_vienna = nullptr;  // RH_MODEL_VIENNA_BL only
     VLinModel* d_vlin = nullptr;   // the same model in scaled linear space
     VLinModel* h_vlin = nullptr;
+    VLinModel* d_vdxl = nullptr;   // the same tables at the duplex scale (duplex_vlin.hip)
+    VDxLin* d_vdx = nullptr;
+    double vdx_s = 0.27;           // log Z of pf_duplex per unit of a+b: 0.23 (random ACGU) .. 0.32 (70 % GC)
     DxLinModel* d_dxlin = nullptr;
     DxLinModel h_dxlin;
     DxLinBatch dxl = {};
@@ -513,7 +521,7 @@ int stage(rh_ctx* c, int ns, const char* const* seqs, const int* lens, bool with
         X.lda = (n1max + 2 + 2 * kDxPad + 1) & ~1;
         const size_t rows = (size_t)n1max + n2max + 3;
         X.tab_stride = rows * X.lda + 128;   // slack: the staged 96-column segments may run past the last row
-        X.pair_stride = X.tab_stride * DL_COUNT;
+        X.pair_stride = X.tab_stride * (vienna ? 6 : (int)DL_COUNT);   // Vienna-BL: raw + two decorated copies per direction
         const size_t dx_bytes = sizeof(double) * std::max(D.pair_stride, X.pair_stride) * D.np;
         void* before = c->d_dxtab;
         if ((rc = ensure(c, &c->d_dxtab, &c->cap_dxtab, dx_bytes, false))) return rc;
@@ -1004,6 +1012,40 @@ int launch_dx_lin(rh_ctx* c)
                        (int*)c->d_dxbad);
     return RH_OK;
 }
+// Vienna-BL pf_duplex, scaled linear space (duplex_vlin.hip)
+int launch_dx_vlin(rh_ctx* c)
+{
+    DxLinBatch X = c->dxl;
+    const int smax = X.n1max + X.n2max;
+    const int groups4 = (X.n1max + 2 + 61) / 62;
+    const double lam = std::exp(-c->vdx_s);
+    for (int t = 0; 4 * t < smax - 1; t++) {
+        for (int k = 0; k < 4; k++) X.pw4[k] = std::pow(lam, 2.0 + 4.0 * t + k);
+        KLAUNCH(c, 4, dxvl_sweep4, dim3(groups4, X.np, 2), dim3(256), c->s_dx, X, c->d_vdxl, c->d_vdx, t);
+        c->n_launch[2]++;
+    }
+    double* zpart = (double*)c->d_zpart;
+    int* cpart = (int*)(zpart + (size_t)X.np * c->lz_chunks);
+    hipLaunchKernelGGL(dxvl_logz_part, dim3(c->lz_chunks, X.np), dim3(256), 0, c->s_dx, X, c->d_vdxl, c->d_vdx, zpart, cpart, c->lz_chunks);
+    hipLaunchKernelGGL(dxvl_logz_final, dim3((X.np + 63) / 64), dim3(64), 0, c->s_dx, X, c->vdx_s, (const double*)zpart, (const int*)cpart,
+                       c->lz_chunks, (double*)c->d_zbar, (double*)c->d_logz, (int*)c->d_dxbad);
+    hipLaunchKernelGGL(dxl_posterior, dim3((X.n1max + 31) / 32, (smax - 1 + 31) / 32, X.np), dim3(256), 0, c->s_dx, X, (const double*)c->d_zbar,
+                       (int*)c->d_dxbad);
+    return RH_OK;
+}
+int launch_dx_vlog(rh_ctx* c)
+{
+    const DxBatch& D = c->dx;
+    const int steps = (D.n1max + D.n2max) / 2;
+    const int waves = 2 * std::min(D.n1max, D.n2max);
+    for (int t = 0; t < steps; t++) {
+        KLAUNCH(c, 4, dxv_sweep_diag, dim3((waves + 3) / 4, D.np, 2), dim3(256), c->s_dx, D, c->d_vienna, t);
+        c->n_launch[2]++;
+    }
+    hipLaunchKernelGGL(dxv_logz, dim3(D.np), dim3(1024), 0, c->s_dx, D, c->d_vienna);
+    hipLaunchKernelGGL(dxv_posterior, dim3((D.n1max * D.n2max + 255) / 256, D.np), dim3(256), 0, c->s_dx, D);
+    return RH_OK;
+}
 int launch_dx_lin_any(rh_ctx* c)
 {
     switch (c->dx_w) {
@@ -1073,16 +1115,13 @@ int compute(rh_ctx* c)
             if (c->last_dx_path != 3) c->last_dx_path = 2;
         }
     } else if (c->has_dx && !skip_dx && c->model == RH_MODEL_VIENNA_BL) {
-        const DxBatch& D = c->dx;
-        const int steps = (D.n1max + D.n2max) / 2;
-        const int waves = 2 * std::min(D.n1max, D.n2max);
-        for (int t = 0; t < steps; t++) {
-            KLAUNCH(c, 4, dxv_sweep_diag, dim3((waves + 3) / 4, D.np, 2), dim3(256), c->s_dx, D, c->d_vienna, t);
-            c->n_launch[2]++;
+        if (c->mode != RH_MODE_LOG) {   // scaled linear sweeps; pairs outside the double range send the batch to the log-space kernels
+            if ((rc = run_graphed(c, c->g_dx, shape_key(c, 2), c->s_dx, &c->n_launch[2], &c->n_far[2], [&] { return launch_dx_vlin(c); }))) return rc;
+            dx_lin_launched = true;
+        } else {
+            if ((rc = launch_dx_vlog(c))) return rc;
+            c->last_dx_path = 2;
         }
-        hipLaunchKernelGGL(dxv_logz, dim3(D.np), dim3(1024), 0, c->s_dx, D, c->d_vienna);
-        hipLaunchKernelGGL(dxv_posterior, dim3((D.n1max * D.n2max + 255) / 256, D.np), dim3(256), 0, c->s_dx, D);
-        c->last_dx_path = 2;
     } else if (c->has_dx && !skip_dx) {
         if (c->mode != RH_MODE_LOG) {
             if ((rc = run_graphed(c, c->g_dx, shape_key(c, 2), c->s_dx, &c->n_launch[2], &c->n_far[2], [&] { return launch_dx_lin_any(c); }))) return rc;
@@ -1173,7 +1212,7 @@ int compute(rh_ctx* c)
             if (redo) {  // some pair left the double range: recompute the batch with the log-space kernels
                 c->n_launch[2] = 0;
                 HIP_TRY(c, hipEventRecord(c->ev[3], c->s_dx));
-                if ((rc = launch_dx_log(c))) return rc;
+                if ((rc = (c->model == RH_MODEL_VIENNA_BL ? launch_dx_vlog(c) : launch_dx_log(c)))) return rc;
                 HIP_TRY(c, hipEventRecord(c->ev[4], c->s_dx));
                 c->last_dx_path = 3;
             }
@@ -1296,6 +1335,18 @@ rh_ctx* rh_create(int device, int model, const char* param_file)
              hipMemcpy(c->d_vienna, host_vienna, sizeof(ViennaDx), hipMemcpyHostToDevice) == hipSuccess &&
              hipMalloc((void**)&c->d_vlin, sizeof(VLinModel)) == hipSuccess &&
              hipMemcpy(c->d_vlin, c->h_vlin, sizeof(VLinModel), hipMemcpyHostToDevice) == hipSuccess;
+        if (ok) {   // pf_duplex in scaled linear space: the loop tables at the duplex scale + its own end / mismatch weights
+            if (const char* e = std::getenv("RH_VDX_S")) c->vdx_s = std::atof(e);
+            VLinModel* tmp = new VLinModel;
+            VDxLin hd;
+            build_vlin_model(*host_vienna, c->vdx_s, tmp);
+            build_vdx_lin(*host_vienna, c->vdx_s, &hd);
+            ok = hipMalloc((void**)&c->d_vdxl, sizeof(VLinModel)) == hipSuccess &&
+                 hipMemcpy(c->d_vdxl, tmp, sizeof(VLinModel), hipMemcpyHostToDevice) == hipSuccess &&
+                 hipMalloc((void**)&c->d_vdx, sizeof(VDxLin)) == hipSuccess &&
+                 hipMemcpy(c->d_vdx, &hd, sizeof(VDxLin), hipMemcpyHostToDevice) == hipSuccess;
+            delete tmp;
+        }
     }
     delete host_vienna;
     for (int k = 0; ok && k < 6; k++) ok = hipEventCreate(&c->ev[k]) == hipSuccess;
@@ -1311,7 +1362,7 @@ void rh_destroy(rh_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    void* bufs[] = {c->d_seq, c->d_n, c->d_mctab, c->d_f5, c->d_bp, c->d_up, c->d_dxtab, c->d_hp, c->d_logz, c->d_scal, c->d_mclogz, c->d_bad, c->d_cnt, c->d_cand, c->d_dxbad, c->d_zbar, c->d_zpart, c->d_gaps, c->d_coseq, c->d_con, c->d_cotab, c->d_pk, c->d_copk, c->d_rowp, c->d_corowp, c->d_cof5, c->d_cobp, c->d_cobad, c->d_allow, c->d_coallow, c->d_vlin, c->d_hplen, c->d_model, c->d_lin, c->d_dxlin, c->d_vienna};
+    void* bufs[] = {c->d_seq, c->d_n, c->d_mctab, c->d_f5, c->d_bp, c->d_up, c->d_dxtab, c->d_hp, c->d_logz, c->d_scal, c->d_mclogz, c->d_bad, c->d_cnt, c->d_cand, c->d_dxbad, c->d_zbar, c->d_zpart, c->d_gaps, c->d_coseq, c->d_con, c->d_cotab, c->d_pk, c->d_copk, c->d_rowp, c->d_corowp, c->d_cof5, c->d_cobp, c->d_cobad, c->d_allow, c->d_coallow, c->d_vlin, c->d_vdxl, c->d_vdx, c->d_hplen, c->d_model, c->d_lin, c->d_dxlin, c->d_vienna};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (GraphSlot* g : {&c->g_in, &c->g_out, &c->g_dx}) if (g->exec) (void)hipGraphExecDestroy(g->exec);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -1611,7 +1662,7 @@ int rh_batch_kernels(rh_ctx* c, const char* fine[3], const char* far[3], int n_f
     names[1] = !c->has_mc ? "" : lin ? ((pairs && (c->lin_w == 4 || c->lin_w == 8)) ? "lin_outside_pair<" + w + ", " + targs + ">" : pre + "outside_diag<" + (vienna ? "8" : w) + ", " + targs + ">")
                                      : vienna ? "mcv_outside_diag" : "mc_outside_diag";
     names[2] = !c->has_dx ? "" : vienna ? (c->hybrid == RH_HYBRID_COFOLD ? (c->last_dx_path == 1 ? "vlin_inside_diag<8, 16, true> + vlin_outside_diag<8, 16, true> (s1+s2)"
-                                                                                         : "mcv_inside_diag + mcv_outside_diag (s1+s2)") : "dxv_sweep_diag") : c->last_dx_path == 1 ? ((c->dx_quad && c->dx_w != 2 && c->dx_w != 8) ? std::string("dxl_sweep4") : "dxl_sweep<" + std::to_string(c->dx_w == 2 || c->dx_w == 8 ? c->dx_w : 4) + ">") : "dx_sweep_diag";
+                                                                                         : "mcv_inside_diag + mcv_outside_diag (s1+s2)") : (c->last_dx_path == 1 ? "dxvl_sweep4" : "dxv_sweep_diag")) : c->last_dx_path == 1 ? ((c->dx_quad && c->dx_w != 2 && c->dx_w != 8) ? std::string("dxl_sweep4") : "dxl_sweep<" + std::to_string(c->dx_w == 2 || c->dx_w == 8 ? c->dx_w : 4) + ">") : "dx_sweep_diag";
     const bool mfma = c->far_mfma && c->lin_bs != 0 && c->lin_bs != 32;
     const std::string fsuf = c->far_pk ? "_pk" : "_mfma";
     names[3] = (c->has_mc && lin && c->n_far[0]) ? (mfma ? "lin_far_inside" + fsuf : "lin_far_inside<" + bs + ">") : "";

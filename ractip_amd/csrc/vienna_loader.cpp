@@ -185,4 +185,13 @@ void build_vlin_model(const ViennaDx& V, double s, VLinModel* L)
     for (int l = 2; l <= kMaxSingle; l++) L->WB[l] = std::exp(V.shape[at(l, 0)].score) * std::pow(lam, l + 2);
 }
 
+void build_vdx_lin(const ViennaDx& V, double s, VDxLin* D)
+{
+    std::memset(D, 0, sizeof(*D));
+    for (int k = 0; k < 200; k++) D->E_mmI[k] = std::exp(V.mmI[k]);
+    for (int k = 0; k < 40; k++) { D->E_d5[k] = std::exp(V.dangle5[k]); D->E_d3[k] = std::exp(V.dangle3[k]); }
+    D->E_init = std::exp(V.duplex_init);
+    D->s = s; D->lam = std::exp(-s);
+}
+
 }  // namespace rh

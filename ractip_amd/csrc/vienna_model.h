@@ -80,4 +80,16 @@ struct VLinModel {
 };
 void build_vlin_model(const ViennaDx& V, double s, VLinModel* out);
 
+// ---- pf_duplex in SCALED LINEAR space (duplex_vlin.hip): IN~ = IN * lam^(a+b), OUT~ = OUT * lam^((L1+1-a)+(L2+1-b)) with
+// a = i, b = L2+1-j; loop weights come from a VLinModel built with the duplex scale (a loop of l1+l2 unpaired letters changes
+// a+b by l1+l2+2, the power the McCaskill tables already carry); what the duplex needs on top of it:
+struct VDxLin {
+    double E_mmI[8 * 25];   // exp(mismatchI[t][a][b])
+    double E_d5[8 * 5], E_d3[8 * 5];
+    double E_init;          // exp(DuplexInit)
+    double s, lam;
+    double pad_;
+};
+void build_vdx_lin(const ViennaDx& V, double s, VDxLin* out);
+
 }  // namespace rh

@@ -449,6 +449,34 @@ def test_vienna_bl_linear_path_falls_back_on_overflow(vctx):
     assert bp[o + 301:o + n + 1].sum() > 0.99              # a G in the middle of the run is paired (the helix may slip)
 
 
+def test_vienna_bl_linear_duplex_path_and_its_fallback(vctx):
+    """pf_duplex under the Vienna-BL model runs in scaled linear space (duplex_vlin.hip: four anti-diagonals per launch) and
+    equals the log-space kernels to rounding; two perfectly complementary 700-mers (log Z ~ 1.3 per letter pair, five times
+    the scale the tables are stored at) leave the double range, are flagged and recomputed in log space."""
+    if vctx.path_name != "auto":
+        pytest.skip("path selection belongs to the auto path")
+    import ractip_amd
+    ref = ractip_amd.Context(device=0, model=ractip_amd.hot.RH_MODEL_VIENNA_BL)
+    ref.set_mode(1)
+    rng = np.random.RandomState(17)
+    try:
+        vctx.set_hybrid(False)
+        for n1, n2 in ((61, 64), (125, 190), (331, 280)):   # around the 62-column groups of the four-diagonal kernel
+            s1, s2 = rnd(rng, n1), rnd(rng, n2)
+            hp, z = vctx.duplex(s1, s2)
+            assert vctx.last_hybrid_path() == 1
+            hp2, z2 = ref.duplex(s1, s2)
+            assert abs(z - z2) < 1e-10
+            assert_prob_close(hp, hp2, rel=1e-9, what="linear vs log pf_duplex %d/%d" % (n1, n2))
+        s1, s2 = "GC" * 350, "GC" * 350
+        hp, z = vctx.duplex(s1, s2)
+        assert vctx.last_hybrid_path() == 3
+        hp2, z2 = ref.duplex(s1, s2)
+        assert np.array_equal(hp, hp2) and z == z2 and np.isfinite(z) and z > 500
+    finally:
+        ref.close()
+
+
 def test_vienna_bl_pair_batch(vctx, golden):
     """Batched form under the Vienna-BL model: everything RactIP::solve consumes on its default path with --duplex
     (bp1, bp2, up1, up2 at width 15, hp), ragged lengths, plus the on-device threshold scans of up."""
