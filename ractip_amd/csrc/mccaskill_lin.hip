@@ -304,11 +304,7 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) RH_WPE_IN void lin_inside_
         const int ic = valid ? i : (ncell > 0 ? ncell : 1);   // invalid lanes read the last valid cell's operands
         const double* __restrict__ fm1c = tab + L_FM1 * ts + ic;
         const double* __restrict__ fmc = tab + L_FM * ts + ic;
-#ifdef RH_EXP_UF
-        constexpr int UF = RH_EXP_UF;
-#else
-        constexpr int UF = 8;
-#endif  // 2*UF (3*UF) row segments (512 B each) in flight per wavefront
+        constexpr int UF = 8;  // 2*UF (3*UF) row segments (512 B each) in flight per wavefront
         // uniform m-ranges that cover every lane's near set: [1, d-1], or its two ends when far blocks exist
         const bool split = BS > 0 && d - 1 > 4 * BS;
         const int lo0 = 1, hi0 = split ? 2 * BS : d - 1;
@@ -324,11 +320,7 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) RH_WPE_IN void lin_inside_
                 for (int u = 0; u < UF; u++) {
                     const int mm = m + u * W, mc = mm <= hi ? mm : hi;
                     a[u] = fm1c[mc * ld];
-#ifdef RH_EXP_HALFFM2
-                    b[u] = 1.0;
-#else
                     b[u] = fmc[(d - mc) * ld + mc];
-#endif
                     if (LA) bn[u] = fmc[(d1 - mc) * ld + mc];   // FM[d+1-m][i+m]: row d-(m-1), final for m >= 2
                 }
 #pragma unroll
@@ -351,11 +343,7 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) RH_WPE_IN void lin_inside_
     // once and each lane runs a (t+1)-tap filter over it; shape weights are wave-uniform (scalar loads).
     // t and 30-t go to the same wavefront so that every wavefront filters ~62 taps.
     // MODE 1: staged row r = 0..31 is table row d-1-r; it carries filter t = r-1 of diagonal d and filter t = r of d+1.
-#ifdef RH_EXP_NOFILT
-    if (d < 0) {
-#else
     if (LA ? d >= 1 : d >= 2) {
-#endif
         const int tmax = d - 2 < kMaxSingle ? d - 2 : kMaxSingle;
         const int i0 = 1 + slot * GS;
         const double* __restrict__ fcx = tab + L_FCX * ts;
@@ -862,11 +850,7 @@ __global__ __launch_bounds__(64 * W) RH_WPE_OUT void lin_outside_pair(McBatch B,
     if (!guard_m) { mineA = 0; mineB = 0; }
     if (!guard_m1) { mineA1 = 0; mineB1 = 0; }
     if (guard_m1) {   // guard_m implies guard_m1
-#ifdef RH_EXP_UO
-        constexpr int UO = RH_EXP_UO;
-#else
         constexpr int UO = 4;
-#endif
         // FMo[i,d] += FM2o[d+e][i-e] * FM1[e][i-e], e = 1..i-1            (ipp:4046-4064, pulled)
         // with blocks: only i' = i-e in blocks I-1, I are streamed; blocks <= I-2 come from FMOF
         {

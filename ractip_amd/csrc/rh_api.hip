@@ -259,7 +259,6 @@ struct rh_ctx {
     int lookahead = 2;             // inside sweep: 2 = two diagonals per launch (lin_inside_diag MODE 3), 1 = look-ahead pairs of launches
                                    // (MODE 1/2), 0 = one full launch per diagonal; RH_LOOKAHEAD
     bool far_pk = true;            // ... on packed operand tiles (lin_pack_tiles + lin_far_*_pk); RH_FAR_PK=0: gather per product
-    bool exp_nofar = false;        // RH_EXP_NOFAR=1: timing experiment only (block products skipped, results wrong)
     bool use_graphs = true;        // RH_NO_GRAPH=1 launches every kernel from the host instead
     GraphSlot g_in, g_out, g_dx;
     int mode = RH_MODE_AUTO;       // which McCaskill path rh_batch_compute takes
@@ -661,7 +660,6 @@ int launch_mc_vienna(rh_ctx* c, int pin)
 // returns the number of launches it counts: 1 (the pack launch rides with its product; bench.py adds its traffic to the product's)
 static int far_inside_step(rh_ctx* c, const McBatch& B, hipStream_t st, int D, int last_block)
 {
-    if (c->exp_nofar) return 0;
     if (!c->far_pk) { KLAUNCH(c, 1, lin_far_inside_mfma, dim3(last_block - D + 1, B.ns), dim3(256), st, B, D); return 1; }
     KLAUNCH(c, 1, lin_pack_tiles, dim3(B.nb - (D - 2), B.ns, 2), dim3(256), st, B, D - 2, 0);
     KLAUNCH(c, 1, lin_far_inside_pk, dim3(last_block - D + 1, B.ns), dim3(256), st, B, D);
@@ -669,14 +667,13 @@ static int far_inside_step(rh_ctx* c, const McBatch& B, hipStream_t st, int D, i
 }
 static int far_outside_begin(rh_ctx* c, const McBatch& B, hipStream_t st, int last_block)
 {
-    if (c->exp_nofar || !c->far_pk) return 0;
+    if (!c->far_pk) return 0;
     for (int Dblk = std::max(2, last_block - 1); Dblk <= last_block; Dblk++)
         KLAUNCH(c, 3, lin_pack_tiles, dim3(B.nb - Dblk, B.ns, 2), dim3(256), st, B, Dblk, 0);
     return 0;
 }
 static int far_outside_step(rh_ctx* c, const McBatch& B, hipStream_t st, int D, int last_block)
 {
-    if (c->exp_nofar) return 0;
     if (!c->far_pk) { KLAUNCH(c, 3, lin_far_outside_mfma, dim3(last_block - D + 1, B.ns, 2), dim3(256), st, B, D); return 1; }
     if (D + 2 <= last_block) KLAUNCH(c, 3, lin_pack_tiles, dim3(B.nb - (D + 2), B.ns, 1), dim3(256), st, B, D + 2, 1);
     KLAUNCH(c, 3, lin_far_outside_pk, dim3(last_block - D + 1, B.ns, 2), dim3(256), st, B, D);
@@ -850,7 +847,7 @@ int launch_mc_lin(rh_ctx* c, int pin, int phase)
             const int D = (d + 1) / BS + 1;
             if (D >= 4 && D <= last_block) {
                 if (BS == 16 && c->far_mfma) c->n_launch[0] += far_inside_step(c, B, c->s_mc, D, last_block);
-                else if (!c->exp_nofar) {
+                else {
                     KLAUNCH(c, 1, lin_far_inside<(BS > 0 ? BS : 16)>, dim3(last_block - D + 1, B.ns), dim3(256), c->s_mc, B, D);
                     c->n_launch[0]++;
                 }
@@ -864,7 +861,7 @@ int launch_mc_lin(rh_ctx* c, int pin, int phase)
     if (BS > 0)  // tiles whose first cell would come before the first outside diagonal: their far sums are empty
         for (int D = last_block; D >= 0 && (D + 1) * BS - 1 > B.nmax - 2; D--) {
             if (BS == 16 && c->far_mfma) c->n_launch[1] += far_outside_step(c, B, c->s_mc, D, last_block);
-            else if (!c->exp_nofar) {
+            else {
                 KLAUNCH(c, 3, lin_far_outside<(BS > 0 ? BS : 16)>, dim3(last_block - D + 1, B.ns, 2), dim3(256), c->s_mc, B, D);
                 c->n_launch[1]++;
             }
@@ -895,7 +892,7 @@ int launch_mc_lin(rh_ctx* c, int pin, int phase)
             const int D = (d + 1) / BS - 1;
             if (D >= 0 && D <= last_block) {
                 if (BS == 16 && c->far_mfma) c->n_launch[1] += far_outside_step(c, B, c->s_mc, D, last_block);
-                else if (!c->exp_nofar) {
+                else {
                     KLAUNCH(c, 3, lin_far_outside<(BS > 0 ? BS : 16)>, dim3(last_block - D + 1, B.ns, 2), dim3(256), c->s_mc, B, D);
                     c->n_launch[1]++;
                 }
@@ -1092,12 +1089,9 @@ int compute(rh_ctx* c)
     const int pin = (c->has_mc && c->mc.ns % 8 == 0) ? 1 : 0;
     int rc;
     // duplex first on its own stream: it is independent of the McCaskill sweeps and overlaps them
-    // RH_EXP_SKIP=dx|mc (tools/exp_time.py): timing experiments only -- results of the skipped engine are stale
-    const char* skip = std::getenv("RH_EXP_SKIP");
-    const bool skip_dx = skip && !std::strcmp(skip, "dx"), skip_mc = skip && !std::strcmp(skip, "mc");
     HIP_TRY(c, hipEventRecord(c->ev[3], c->s_dx));
     bool dx_lin_launched = false, co_lin_launched = false;
-    if (c->has_dx && !skip_dx && c->model == RH_MODEL_VIENNA_BL && c->hybrid == RH_HYBRID_COFOLD) {
+    if (c->has_dx && c->model == RH_MODEL_VIENNA_BL && c->hybrid == RH_HYBRID_COFOLD) {
         HIP_TRY(c, hipMemsetAsync(c->d_cobp, 0, sizeof(double) * c->co.tri_stride * c->co.ns, c->s_dx));
         bool co_log = c->mode == RH_MODE_LOG;
         if (!co_log) {   // scaled linear sweeps over s1+s2; out-of-range values send the batch to the log-space kernels
@@ -1114,7 +1108,7 @@ int compute(rh_ctx* c)
             if ((rc = launch_cofold(c))) return rc;
             if (c->last_dx_path != 3) c->last_dx_path = 2;
         }
-    } else if (c->has_dx && !skip_dx && c->model == RH_MODEL_VIENNA_BL) {
+    } else if (c->has_dx && c->model == RH_MODEL_VIENNA_BL) {
         if (c->mode != RH_MODE_LOG) {   // scaled linear sweeps; pairs outside the double range send the batch to the log-space kernels
             if ((rc = run_graphed(c, c->g_dx, shape_key(c, 2), c->s_dx, &c->n_launch[2], &c->n_far[2], [&] { return launch_dx_vlin(c); }))) return rc;
             dx_lin_launched = true;
@@ -1122,7 +1116,7 @@ int compute(rh_ctx* c)
             if ((rc = launch_dx_vlog(c))) return rc;
             c->last_dx_path = 2;
         }
-    } else if (c->has_dx && !skip_dx) {
+    } else if (c->has_dx) {
         if (c->mode != RH_MODE_LOG) {
             if ((rc = run_graphed(c, c->g_dx, shape_key(c, 2), c->s_dx, &c->n_launch[2], &c->n_far[2], [&] { return launch_dx_lin_any(c); }))) return rc;
             dx_lin_launched = true;
@@ -1135,8 +1129,8 @@ int compute(rh_ctx* c)
     if (!c->overlap) HIP_TRY(c, hipStreamSynchronize(c->s_dx));   // isolated phase timings: nothing else on the device
 
     HIP_TRY(c, hipEventRecord(c->ev[0], c->s_mc));
-    bool need_log = c->has_mc && c->mode == RH_MODE_LOG && !skip_mc && c->model != RH_MODEL_VIENNA_BL;
-    if (c->has_mc && c->model == RH_MODEL_VIENNA_BL && !skip_mc) {
+    bool need_log = c->has_mc && c->mode == RH_MODE_LOG && c->model != RH_MODEL_VIENNA_BL;
+    if (c->has_mc && c->model == RH_MODEL_VIENNA_BL) {
         bool log_path = c->mode == RH_MODE_LOG;
         if (!log_path) {   // scaled linear sweeps; a sequence that leaves the double range sends the batch to the log-space kernels
             const bool far = c->lin_bs != 0;
@@ -1162,7 +1156,7 @@ int compute(rh_ctx* c)
             if ((rc = launch_mc_vienna(c, pin))) return rc;
             if (c->last_path == 0) c->last_path = 2;
         }
-    } else if (c->has_mc && c->mode != RH_MODE_LOG && !skip_mc) {
+    } else if (c->has_mc && c->mode != RH_MODE_LOG) {
         if ((rc = run_graphed(c, c->g_in, shape_key(c, 0), c->s_mc, &c->n_launch[0], &c->n_far[0], [&] { return launch_mc_lin_any(c, pin, 0); }))) return rc;
         HIP_TRY(c, hipEventRecord(c->ev[1], c->s_mc));
         if ((rc = run_graphed(c, c->g_out, shape_key(c, 1), c->s_mc, &c->n_launch[1], &c->n_far[1], [&] { return launch_mc_lin_any(c, pin, 1); }))) return rc;
@@ -1313,7 +1307,6 @@ rh_ctx* rh_create(int device, int model, const char* param_file)
     if (const char* e = std::getenv("RH_LIN_BS")) c->lin_bs = std::atoi(e);
     if (const char* e = std::getenv("RH_NO_GRAPH")) c->use_graphs = std::atoi(e) == 0;
     if (const char* e = std::getenv("RH_FAR_MFMA")) c->far_mfma = std::atoi(e) != 0;
-    if (const char* e = std::getenv("RH_EXP_NOFAR")) c->exp_nofar = std::atoi(e) != 0;
     if (const char* e = std::getenv("RH_FAR_PK")) c->far_pk = std::atoi(e) != 0;
     if (const char* e = std::getenv("RH_LOOKAHEAD")) c->lookahead = std::atoi(e);
     if (const char* e = std::getenv("RH_DX_W")) c->dx_w = std::atoi(e);
