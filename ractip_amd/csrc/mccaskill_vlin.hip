@@ -1079,7 +1079,20 @@ __global__ __launch_bounds__(256) void vlin_acc_gaps(McBatch B, const VLinModel*
             win[NW - 1] = wn[u];
         }
     }
-    if (live) gaps[((size_t)(2 * sq + (right ? 1 : 0)) * ld + pos) * 32 + g] = acc / Z;
+    // layout [side][g][pos]: consecutive lanes = consecutive letters (vlin_acc_gsuf / vlin_acc_final read it the same way)
+    if (live) gaps[((size_t)(2 * sq + (right ? 1 : 0)) * 32 + g) * ld + pos] = acc / Z;
+}
+
+// gap probabilities -> suffix sums over the gap length: S[g][pos] = sum_{l >= g} G[l][pos]; one thread per (letter, side)
+__global__ __launch_bounds__(256) void vlin_acc_gsuf(McBatch B, double* __restrict__ gaps)
+{
+    const int sq = blockIdx.y, side = blockIdx.z;
+    const int ld = B.ld;
+    const int pos = blockIdx.x * blockDim.x + threadIdx.x + 1;
+    if (pos > B.n[sq]) return;
+    double* __restrict__ G = gaps + (size_t)(2 * sq + side) * 32 * ld + pos;
+    double run = 0.0;
+    for (int g = kMaxSingle; g >= 1; g--) { run += G[(size_t)g * ld]; G[(size_t)g * ld] = run; }
 }
 
 // up[(a-1)*max_w + w] = H part: sum_{p<a, q>a+w} Hp[p][q] from the column prefix sums C (square scratch); one wavefront per letter
@@ -1122,15 +1135,14 @@ __global__ __launch_bounds__(256) void vlin_acc_final(McBatch B, const VLinModel
     const double* __restrict__ f5i = B.f5i + (size_t)sq * ld;
     const double* __restrict__ f5o = B.f5o + (size_t)sq * ld;
     const double Z = f5i[n];
-    const double* __restrict__ gl = gaps + (size_t)(2 * sq) * ld * 32;
-    const double* __restrict__ gr = gaps + (size_t)(2 * sq + 1) * ld * 32;
+    const double* __restrict__ gl = gaps + (size_t)(2 * sq) * 32 * ld;       // suffix sums over the gap length, [g][pos]
+    const double* __restrict__ gr = gaps + (size_t)(2 * sq + 1) * 32 * ld;
     double lam_len = 1.0, mu_len = 1.0;
     for (int k = 0; k < len; k++) { lam_len *= L->lam; mu_len *= L->w_mu; }
     double acc = f5i[a - 1] * f5o[b] / Z * lam_len;                                          // E
-    for (int p = a - 1; p >= 1 && p >= b - kMaxSingle; p--)                                   // I, 5' gaps
-        for (int l = b - p; l <= kMaxSingle; l++) acc += gl[(size_t)p * 32 + l];
-    for (int q = b + 1; q <= n && q <= a + kMaxSingle; q++)                                   // I, 3' gaps
-        for (int l = q - a; l <= kMaxSingle; l++) acc += gr[(size_t)q * 32 + l];
+    // I: the region lies in the 5' gap of the loop whose outer 5' letter is p < a when that gap reaches b: length >= b-p
+    for (int p = a - 1; p >= 1 && p >= b - kMaxSingle; p--) acc += gl[(size_t)(b - p) * ld + p];
+    for (int q = b + 1; q <= n && q <= a + kMaxSingle; q++) acc += gr[(size_t)(q - a) * ld + q];   // ... 3' gaps
     double m = 0.0;
     if (a >= 2 && b <= n - 3) {     // M, run before a branch: FM1o[a-1, j] * FM1[b, j], j = a+e
         const double* __restrict__ x = tab + VL_FM1O * ts + (a - 1);

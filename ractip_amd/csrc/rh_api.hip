@@ -65,6 +65,7 @@ __global__ void mcv_acc_hscan(McBatch B, int slot);
 __global__ void vlin_acc_prep(McBatch B, const VLinModel* __restrict__ L, const double* __restrict__ hplen);
 __global__ void vlin_acc_gaps(McBatch B, const VLinModel* __restrict__ L, double* __restrict__ gaps);
 __global__ void vlin_acc_hsum(McBatch B, int max_w);
+__global__ void vlin_acc_gsuf(McBatch B, double* __restrict__ gaps);
 __global__ void vlin_acc_final(McBatch B, const VLinModel* __restrict__ L, const double* __restrict__ gaps, int max_w);
 __global__ void mcv_acc_gaps(McBatch B, const ViennaDx* __restrict__ V, double* __restrict__ gaps);
 __global__ void mcv_acc_final(McBatch B, const ViennaDx* __restrict__ V, const double* __restrict__ gaps, int max_w);
@@ -772,8 +773,9 @@ int launch_mc_vlin(rh_ctx* c, int pin, int phase, bool co)
     hipLaunchKernelGGL(mcv_acc_hscan, dim3((B.nmax + 1 + 255) / 256, B.ns), dim3(256), 0, st, B, 10 /* VL_FM2F */);
     hipLaunchKernelGGL(vlin_acc_hsum, dim3((B.nmax + 3) / 4, B.ns), dim3(256), 0, st, B, c->max_w);
     hipLaunchKernelGGL(vlin_acc_gaps, dim3((B.nmax + 255) / 256, B.ns, 60), dim3(256), 0, st, B, c->d_vlin, (double*)c->d_gaps);
+    hipLaunchKernelGGL(vlin_acc_gsuf, dim3((B.nmax + 255) / 256, B.ns, 2), dim3(256), 0, st, B, (double*)c->d_gaps);
     hipLaunchKernelGGL(vlin_acc_final, dim3((B.nmax + 255) / 256, B.ns, c->max_w), dim3(256), 0, st, B, c->d_vlin, (const double*)c->d_gaps, c->max_w);
-    c->n_launch[1] += 5;
+    c->n_launch[1] += 6;
     return RH_OK;
 }
 
