@@ -1029,7 +1029,7 @@ __global__ __launch_bounds__(256) void vlin_acc_gaps(McBatch B, const VLinModel*
     // largest interior inner span of any thread of this block (threads are consecutive letters)
     const int pos_lo = blockIdx.x * blockDim.x + 1, pos_hi = pos_lo + (int)blockDim.x - 1 < n ? pos_lo + (int)blockDim.x - 1 : n;
     const int rlim = right ? pos_hi - 1 - g - 2 : n - 1 - (pos_lo + 1 + g);
-    constexpr int UR = 4;   // inner spans per batch of loads (all loads of a batch are issued before any arithmetic)
+    constexpr int UR = 2;   // inner spans per batch of loads (measured: 2 best, 4 -3 %, 8 -9 % on the accessibility phase) (all loads of a batch are issued before any arithmetic)
     for (int r0 = 0; r0 <= rlim; r0 += UR) {
         double xs[UR], wn[UR], bo[UR], bi[UR];
         bool ok[UR];
