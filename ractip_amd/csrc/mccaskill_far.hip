@@ -261,7 +261,11 @@ enum PkCopy { PK_FM1_A = 0, PK_FM1_B, PK_FM_A, PK_FM_B, PK_FM2O_A, PK_FM2O_B };
 __device__ __forceinline__ size_t pk_tile(int nb, int P, int Q) { return ((size_t)P * nb - (size_t)P * (P - 1) / 2 + (Q - P)) * 256; }
 
 // grid = (tiles P of block diagonal Dblk, sequences, tables); outside = 0: FM1 and FM (blockIdx.z), outside = 1: FM2o
-__global__ __launch_bounds__(256) void lin_pack_tiles(McBatch B, int Dblk, int outside)
+// banded != 0 (strip kernels, mccaskill_strip.hip): the far range of a cell is k in [i+32, j-32], not whole blocks; its two partial
+// blocks are the tiles of block diagonal 2 with the entries (first index u, second index v), v < u, removed -- the same mask
+// whichever product uses the tile (FM1 as the K = I+2 operand inside / the K = I-2 operand of FMOF, FM as K = J-2 / K = J+2),
+// and such a tile is used by no other product, so it is simply packed masked.
+__global__ __launch_bounds__(256) void lin_pack_tiles(McBatch B, int Dblk, int outside, int banded)
 {
     __shared__ double T[16][17];
     const int sq = blockIdx.y;
@@ -276,7 +280,7 @@ __global__ __launch_bounds__(256) void lin_pack_tiles(McBatch B, int Dblk, int o
 #pragma unroll
         for (int pass = 0; pass < 2; pass++) {
             const int v = u + (threadIdx.x >> 4) + 16 * pass - 15;
-            if (v >= 0 && v < 16) T[u][v] = cellv(src, B.ld, n, P * 16 + u, Q * 16 + v);
+            if (v >= 0 && v < 16) T[u][v] = (banded && !outside && Dblk == 2 && v < u) ? 0.0 : cellv(src, B.ld, n, P * 16 + u, Q * 16 + v);
         }
     }
     __syncthreads();

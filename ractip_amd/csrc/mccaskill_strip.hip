@@ -1,0 +1,874 @@
+// mccaskill_strip.hip -- McCaskill inside / outside sweeps in SCALED LINEAR space, KD diagonals per launch.
+//
+// Same recurrences and the same diagonal-major tables as mccaskill_lin.hip (reference:
+// /root/reference/src/contrafold/InferenceEngine.ipp:3356-3722 inside, 3731-4080 outside, 4498-4828 posterior).
+// What changes is the unit of work.  The per-diagonal kernels re-read, for every diagonal, the ~32 most recent rows of
+// FM / FM1 / FCX (their L2 hit rate is 25 %: profiles/r02_a_baseline_pmc_l2.txt) and move ~1.3 KB per cell.  Here one
+// workgroup owns a STRIP: 64 columns x KD consecutive diagonals d0 .. d0+KD-1.
+//   * Every operand row that is final before the launch is staged ONCE in LDS (about 75 KB per workgroup, two
+//     workgroups per CU) and serves all KD diagonals: HBM traffic per cell falls by about (32+2)/2 : (32+KD)/KD.
+//   * pre-phase (all W wavefronts): the terms whose operands are final, for all KD diagonals at once.  The wavefronts
+//     split the TERMS, not the diagonals: a wavefront keeps FM1[m][i] of "its" m in a register and walks the KD
+//     diagonals over the staged FM rows (one LDS read per FMA); the single-branch filter reads each staged FCX value
+//     once and feeds up to KD diagonals from it, with wave-uniform weights from a zero-padded transposed table
+//     (no masks, no per-lane branches).
+//   * chain (KD short steps, one wavefront each, a workgroup barrier in between): adds the few terms that touch
+//     rows d0 .. d-1 of this strip (kept in LDS), runs the cell epilogue and stores the row.
+//   * cell (i, d0+k) needs columns i .. i+k of the strip's own rows, so a group's lanes shrink by one per diagonal
+//     (a trapezoid): groups advance by 64-(KD-1) columns and the overlap is recomputed.
+//
+// Banded near/far split of the O(n^3) terms (replaces the block-aligned split of mccaskill_lin.hip for these kernels):
+//   FM2[i,j] = sum_{m=1}^{31} + sum_{e=1}^{31} (m = d-e)        near: streamed here, the same for every lane
+//            + FM2F[i,j] = sum_{k=i+32}^{j-32} FM1[i,k] FM[k,j]  far : block products (mccaskill_far.hip), d >= 64
+// The far range is not block-aligned; the two partial blocks K = I+2 and K = J-2 of a 16x16 tile product are exactly
+// the tiles of block diagonal 2, each masked upper-triangular (second index >= first), so lin_pack_tiles packs those
+// tiles masked (`banded`) and the product kernels are unchanged.
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include "batch.h"
+#include "lin_model.h"
+
+namespace rh {
+
+namespace {
+
+constexpr uint32_t kPairMaskS = (1u << (0 * 5 + 3)) | (1u << (3 * 5 + 0)) | (1u << (1 * 5 + 2)) |
+                                (1u << (2 * 5 + 1)) | (1u << (2 * 5 + 3)) | (1u << (3 * 5 + 2));
+__device__ __forceinline__ bool pairs_s(int a, int b) { return (kPairMaskS >> (a * 5 + b)) & 1u; }
+__device__ __forceinline__ size_t tri_off_s(int n, int i) { return (size_t)i * (size_t)(2 * (n + 1) - i - 1) / 2; }
+
+__device__ __forceinline__ double wsum_s(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int V> using IC = std::integral_constant<int, V>;
+// workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the wavefront's outstanding GLOBAL stores and
+// loads (s_waitcnt vmcnt(0)): inside the chain that would expose one HBM round trip per diagonal.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// volatile LDS pointer: keeps every read a plain ds_read_b64 (256 B/clk/CU); merged into ds_read2_b64 two reads cost 8 cycles on CDNA4
+typedef const volatile __attribute__((address_space(3))) double* lds_vp;
+
+}  // namespace
+
+#ifdef RH_STAMPS
+// tuning build only (tools/build_variant.py stamps -DRH_STAMPS): per-phase cycle totals of the strip kernels, summed over workgroups
+__device__ unsigned long long g_stamps[16];
+#define RH_STAMP(k) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_stamps[k], t_ - t_prev_); t_prev_ = t_; } } while (0)
+#define RH_STAMP_BEGIN() unsigned long long t_prev_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) atomicAdd(&g_stamps[15], 1ull)
+extern "C" int rh_debug_stamps(unsigned long long* out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(g_stamps)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#else
+#define RH_STAMP(k) do { } while (0)
+#define RH_STAMP_BEGIN() do { } while (0)
+#endif
+
+enum StripTable { S_FC = 0, S_FCX, S_FCA, S_FM1, S_FM, S_FCO, S_FCOX, S_FM2O, S_FMO, S_FM1O, S_FM2F, S_FMOF, S_FM1OF };
+
+// LDS plan of the inside strip kernel (doubles)
+template <int KD, int W>
+struct InStripPlan {
+    static constexpr int GS = 64 - (KD - 1);
+    static constexpr int NM = 31;                 // near terms per end of the FM2 sum
+    static constexpr int RD = NM + KD, CD = 72;   // FM rows e = 1 .. (row e-1), columns i0+d0-e .. +71; rows e > 31 are zero
+    static constexpr int RA = NM + KD - 1, CA = 96;   // FM rows d0-31 .. d0-1, columns i0+1 .. +95; 7 zero rows behind them
+    static constexpr int RE = 32, CE = 96;        // FCX rows d0-1-rho, rho = 0..31, columns i0+1 .. +95
+    static constexpr int SZ = RD * CD + RA * CA + RE * CE;
+    // after the pre-phase everything behind the first KD rows of the fixed FM rows is dead and is reused:
+    static constexpr int CS = 72;                 // row pitch of the strip's own rows
+    static constexpr int TS = 4;                  // term sets: wavefront w accumulates term set w % TS for diagonals (w / TS) * KD*TS/W ..
+    static constexpr int OFF_PART = KD * CD;      // [TS][KD][2][64] partial sums
+    static constexpr int OFF_S = OFF_PART + TS * KD * 2 * 64;   // [5][KD][CS] rows FM, FM1, FCX, FC, FCA of this strip
+    static_assert(OFF_S + 5 * KD * CS <= SZ, "overlay does not fit");
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// inside, diagonals d0 .. d0+KD-1 (d0 >= 32, d0 % KD == 0).  Last group: F5i[f5_lo .. d0+1] (rows <= d0-1 of FCA).
+// wT[l1*kWTS + t + 1] = shape_w(l1, t-l1) for 0 <= l1 <= t <= 30, else 0.
+constexpr int kWTS = 40;
+
+template <int KD, int W>
+__global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_inside_strip(McBatch B, const LinModel* __restrict__ L, const double* __restrict__ wT, int d0, int f5_lo,
+                                                              double lam_d0, int pin)
+{
+    using P = InStripPlan<KD, W>;
+    constexpr int GS = P::GS, NM = P::NM, CD = P::CD, CA = P::CA, CE = P::CE, CS = P::CS;
+    constexpr int NSL = KD / W;                     // chain steps per wavefront
+    constexpr int TS = P::TS, KH = KD * TS / W;     // term sets; diagonals per wavefront in the pre-phase
+    static_assert(KD % W == 0 && KD <= 8 && W % TS == 0 && KD % (W / TS) == 0 && (NM + 1) % W == 0, "8 terms per end and term set, 32/W staged rows per wavefront and region");
+    __shared__ double lds[P::SZ];
+    __shared__ double red[W];
+    const int sq = pin ? blockIdx.x : blockIdx.y;
+    const int slot = pin ? blockIdx.y : blockIdx.x;
+    if (sq >= B.ns) return;
+    const int n = B.n[sq];
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int wt = w % TS, kb = (w / TS) * KH;     // term set; first diagonal of this wavefront's pre-phase sums
+    const int ld = B.ld;
+    const size_t ts = B.tab_stride;
+    const uint8_t* __restrict__ s = B.seq + (size_t)sq * B.lds;
+    double* __restrict__ tab = B.tab + (size_t)sq * B.seq_stride;
+    double* __restrict__ f5i = B.f5i + (size_t)sq * ld;
+    const int ncell0 = n - 1 - d0 > 0 ? n - 1 - d0 : 0;
+    const int ngroup = (ncell0 + GS - 1) / GS;
+    if (slot > ngroup) return;
+
+    if (slot == ngroup) {
+        // F5i[jj] = F5i[jj-1]*ext_unpaired + sum_{k<=jj-2} F5i[k]*FCA[k+1,jj-1]*ext_paired   (ipp:3692-3717)
+        const double* __restrict__ fca = tab + S_FCA * ts;
+#pragma unroll 1
+        for (int jj = f5_lo; jj <= d0 + 1; jj++) {
+            if (jj < 1 || jj > n) continue;
+            double acc = 0.0;
+            for (int k = threadIdx.x; k <= jj - 2; k += 64 * W) acc = fma(f5i[k], fca[(size_t)(jj - 2 - k) * ld + (k + 1)], acc);
+            acc = wsum_s(acc);
+            if (lane == 0) red[w] = acc;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                double t = 0.0;
+#pragma unroll
+                for (int k = 0; k < W; k++) t += red[k];
+                f5i[jj] = f5i[jj - 1] * L->w_eu + t * L->w_ep2;
+            }
+            __syncthreads();   // F5i[jj] is an operand of F5i[jj+1]
+        }
+        return;
+    }
+
+    RH_STAMP_BEGIN();
+    const int i0 = 1 + slot * GS;
+    const int i = i0 + lane;
+    const int ic = i < ld ? i : ld - 1;
+    double* const LDm = lds;                        // fixed FM rows e = 1..
+    double* const LA = lds + P::RD * CD;            // sliding FM rows
+    double* const LE = LA + P::RA * CA;             // sliding FCX rows
+    const double* __restrict__ fm = tab + S_FM * ts;
+    const double* __restrict__ fm1 = tab + S_FM1 * ts;
+    const double* __restrict__ fcx = tab + S_FCX * ts;
+
+    // sequence letters of this wavefront's chain steps k = w + W*sl (their table gathers follow as soon as the staging loads are out)
+    int s_j[NSL], s_jp1[NSL], s_jp2[NSL];
+    const int s_im1 = i - 1 < B.lds ? s[i - 1] : 4, s_i = i < B.lds ? s[i] : 4, s_ip1 = i + 1 < B.lds ? s[i + 1] : 4;
+#pragma unroll
+    for (int sl = 0; sl < NSL; sl++) {
+        const int d = d0 + w + W * sl, j = i + d;
+        const bool v = i <= n - 1 - d;
+        s_j[sl] = v ? s[j] : 4; s_jp1[sl] = v ? s[j + 1] : 4; s_jp2[sl] = v ? s[j + 2] : 4;
+    }
+    // ---- global loads of everything this wavefront stages or keeps: issued back to back (64 row segments in flight), then written to LDS.
+    // Cells outside the interior of their row are staged as 0: stale bytes never enter a product.
+    constexpr int NR = (NM + 1) / W;   // staged rows per wavefront and region
+    constexpr int NT = (NM + 1) / TS;  // terms per end of this wavefront's term set
+    double vA0[NR], vA1[NR], vD0[NR], vD1[NR], vE0[NR], vE1[NR], a_lo[NT], a_hi[NT];
+    const int ca0 = i0 + 1 + lane, ca1 = i0 + 65 + (lane & 31);
+#pragma unroll
+    for (int q = 0; q < NR; q++) {
+        {   // A: FM row d0-31+ra, columns i0+1 ..
+            const int ra = w + W * q, rr = ra < NM ? ra : NM - 1, R = d0 - NM + rr;
+            const double* __restrict__ row = fm + (size_t)R * ld;
+            vA0[q] = row[ca0 < ld ? ca0 : ld - 1];
+            vA1[q] = row[ca1 < ld ? ca1 : ld - 1];
+        }
+        {   // D: FM row e, columns i0+d0-e ..
+            const int e = 1 + w + W * q, ee = e <= NM ? e : NM, c0 = i0 + d0 - ee + lane, c1 = i0 + d0 - ee + 64 + (lane & 7);
+            const double* __restrict__ row = fm + (size_t)ee * ld;
+            vD0[q] = row[c0 < ld ? c0 : ld - 1];
+            vD1[q] = row[c1 < ld ? c1 : ld - 1];
+        }
+        {   // E: FCX row d0-1-rho, columns i0+1 ..
+            const int rho = w + W * q, R = d0 - 1 - rho;
+            const double* __restrict__ row = fcx + (size_t)R * ld;
+            vE0[q] = row[ca0 < ld ? ca0 : ld - 1];
+            vE1[q] = row[ca1 < ld ? ca1 : ld - 1];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NT; q++) {   // this term set's FM1 values: rows m = 1+wt+TS*q (low end) and d0-x, x = 1+wt+TS*q (high end), column i
+        const int m = 1 + wt + TS * q, mm = m <= NM ? m : NM;
+        const double v = fm1[(size_t)mm * ld + ic];
+        a_lo[q] = (m <= NM && i <= n - 1 - m) ? v : 0.0;
+        const int R = d0 - mm;
+        const double u = fm1[(size_t)R * ld + ic];
+        a_hi[q] = (m <= NM && m <= d0 - 32 && i <= n - 1 - R) ? u : 0.0;   // e = k+x <= d-32: rows m' = d-e >= 32 only
+    }
+    // ---- operands of this wavefront's chain steps, raw: issued behind the staging loads, consumed after the filter
+    double r_tjb[NSL], r_tja[NSL], r_tst[NSL], r_bp[NSL], r_tjbd[NSL], r_tjad[NSL], r_b01[NSL], r_b10[NSL], r_11[NSL], p_far[NSL];
+    double p_x01 = 0, p_x10 = 0, p_x11 = 0, p_fc = 0, p_fca = 0, p_fm1 = 0, p_fm = 0;   // only step k < 4 reads rows < d0 here
+    {
+#pragma unroll
+        for (int sl = 0; sl < NSL; sl++) {
+            const int d = d0 + w + W * sl;
+            const bool v = i <= n - 1 - d;
+            const int idx = 25 * (5 * s_i + s_ip1) + 5 * s_jp1[sl] + s_j[sl];       // (i,j)   as enclosing pair
+            const int idd = 25 * (5 * s_jp1[sl] + s_jp2[sl]) + 5 * s_i + s_im1;     // (j+1,i-1) as enclosed pair
+            r_tjb[sl] = L->TJB[idx]; r_tja[sl] = L->TJA[idx]; r_tst[sl] = L->TST[idx];
+            r_bp[sl] = L->E_bp[s_i * 5 + s_jp1[sl]];
+            r_tjbd[sl] = L->TJB[idd]; r_tjad[sl] = L->TJA[idd];
+            r_b01[sl] = L->E_b01[s_j[sl]]; r_b10[sl] = L->E_b10[s_ip1]; r_11[sl] = L->E_11[s_ip1 * 5 + s_j[sl]];
+            p_far[sl] = (v && d >= 64) ? tab[S_FM2F * ts + (size_t)d * ld + i] : 0.0;
+        }
+        const int k0 = w, d = d0 + k0;   // the first of its steps may still need rows < d0
+        const bool v = i <= n - 1 - d;
+        const int c1 = i + 1 < ld ? i + 1 : ld - 1, c2 = i + 2 < ld ? i + 2 : ld - 1;
+        if (k0 < 3) { p_x01 = v ? fcx[(size_t)(d - 3) * ld + c1] : 0.0; p_x10 = v ? fcx[(size_t)(d - 3) * ld + c2] : 0.0; }
+        if (k0 < 4) p_x11 = v ? fcx[(size_t)(d - 4) * ld + c2] : 0.0;
+        if (k0 < 2) { p_fc = v ? tab[S_FC * ts + (size_t)(d - 2) * ld + c1] : 0.0; p_fca = v ? tab[S_FCA * ts + (size_t)(d - 2) * ld + c1] : 0.0; }
+        if (k0 < 1) { p_fm1 = v ? fm1[(size_t)(d - 1) * ld + c1] : 0.0; p_fm = v ? fm[(size_t)(d - 1) * ld + ic] : 0.0; }
+    }
+#pragma unroll
+    for (int q = 0; q < NR; q++) {
+        {
+            const int ra = w + W * q, R = d0 - NM + ra, cmax = n - 1 - R;
+            if (ra < NM) {
+                LA[ra * CA + lane] = ca0 <= cmax ? vA0[q] : 0.0;
+                if (lane < 32) LA[ra * CA + 64 + lane] = ca1 <= cmax ? vA1[q] : 0.0;
+            }
+        }
+        {
+            const int e = 1 + w + W * q, c0 = i0 + d0 - e + lane, c1 = i0 + d0 - e + 64 + (lane & 7), cmax = n - 1 - e;
+            if (e <= NM) {
+                LDm[(e - 1) * CD + lane] = c0 <= cmax ? vD0[q] : 0.0;
+                if (lane < 8) LDm[(e - 1) * CD + 64 + lane] = c1 <= cmax ? vD1[q] : 0.0;
+            }
+        }
+        {
+            const int rho = w + W * q, R = d0 - 1 - rho, cmax = n - 1 - R;
+            LE[rho * CE + lane] = ca0 <= cmax ? vE0[q] : 0.0;
+            if (lane < 32) LE[rho * CE + 64 + lane] = ca1 <= cmax ? vE1[q] : 0.0;
+        }
+    }
+    for (int k = threadIdx.x; k < (P::RA - NM) * CA; k += 64 * W) LA[NM * CA + k] = 0.0;
+    for (int k = threadIdx.x; k < (P::RD - NM) * CD; k += 64 * W) LDm[NM * CD + k] = 0.0;
+    RH_STAMP(0);
+    __syncthreads();
+    RH_STAMP(1);
+
+    // ---- pre-phase: the terms whose operands were final before the launch, all KD diagonals
+    double acc2[KH], accg[KH];
+#pragma unroll
+    for (int k = 0; k < KH; k++) { acc2[k] = 0.0; accg[k] = 0.0; }
+    {
+        // two LDS operands per term and diagonal; software-pipelined by hand (the reads of term q+1 are issued before the
+        // FMAs of term q) and pinned, because left alone the scheduler hoists every read of this block and spills.  The
+        // volatile pointer keeps the reads as ds_read_b64: merged into ds_read2_b64 they run at half the LDS rate on CDNA4.
+        const lds_vp vLA = (lds_vp)LA;
+        const lds_vp vLD = (lds_vp)LDm;
+        double va[KH], vb[KH], na[KH], nb[KH];
+        auto issue = [&](int q, double* ra, double* rb) {
+            // low end: FM1[m][i] * FM[d-m][i+m]; FM row d0+k-m sits in staged row 31+k-m (rows >= 31 are zero: the strip's own rows, added by the chain)
+            const int m = 1 + wt + TS * q, mm = m <= NM ? m : NM;
+            const lds_vp pa = vLA + (NM - mm + kb) * CA + lane + mm - 1;
+            // high end: FM1[d0-x][i] * FM[e][i+d0-x], e = k+x, staged row e-1 at column index lane+k (rows e > 31 are zero)
+            const int x = 1 + wt + TS * q, xx = x <= NM + 1 ? x : NM + 1;
+            const lds_vp pd = vLD + (xx - 1 + kb) * CD + lane + kb;
+#pragma unroll
+            for (int k = 0; k < KH; k++) { ra[k] = pa[k * CA]; rb[k] = pd[k * (CD + 1)]; }
+        };
+        issue(0, va, vb);
+#pragma unroll
+        for (int q = 0; q < NT; q++) {
+            if (q + 1 < NT) issue(q + 1, na, nb);
+            const double a = a_lo[q], b = a_hi[q];
+#pragma unroll
+            for (int k = 0; k < KH; k++) acc2[k] = fma(b, vb[k], fma(a, va[k], acc2[k]));
+#pragma unroll
+            for (int k = 0; k < KH; k++) asm volatile("" : "+v"(acc2[k]));   // pins this term's FMAs before the next term's (volatile) reads
+#pragma unroll
+            for (int k = 0; k < KH; k++) { va[k] = na[k]; vb[k] = nb[k]; }
+        }
+    }
+    RH_STAMP(2);
+    double f1[KD - 1];   // FM1[m][i], m = 1..KD-1: low-end operands of the chain's own-row terms (latency hides behind the filter)
+#pragma unroll
+    for (int m = 1; m < KD; m++) f1[m - 1] = i <= n - 1 - m ? fm1[(size_t)m * ld + ic] : 0.0;
+    RH_STAMP(3);
+    // single-branch filter: staged row rho is table row d0-1-rho = d-2-t with t = rho-1+k for diagonal d0+k; tap l1 reads column
+    // i+1+l1 of it.  One LDS read feeds all KD diagonals.  The weight of (row rho, diagonal k, tap l1) is wT[l1][rho+k] (zero where
+    // the shape does not exist), so for one tap the 8 rows x 8 diagonals of this wavefront are 36 consecutive entries of the
+    // transposed table: wave-uniform scalar loads, 20 doubles per half (rows q = 0..3 / 4..7) and 32 FMAs behind each.
+    // The first half of the term set's rows (rho <= wt + TS*3) has no tap beyond l1 = rho+kb+KH-2: skipped for larger l1.
+    {
+        constexpr int HR = NT / 2;
+        const lds_vp xrow = (lds_vp)LE + wt * CE + lane;
+#pragma unroll 1
+        for (int l1 = 0; l1 <= kMaxSingle; l1++) {
+            const double* __restrict__ wp = wT + l1 * kWTS + wt + kb;
+            if (l1 <= wt + (HR - 1) * TS + kb + KH - 2) {
+                double x[HR];
+#pragma unroll
+                for (int q = 0; q < HR; q++) x[q] = xrow[q * TS * CE + l1];
+#pragma unroll
+                for (int q = 0; q < HR; q++)
+#pragma unroll
+                    for (int k = 0; k < KH; k++) accg[k] = fma(wp[TS * q + k], x[q], accg[k]);
+            }
+            {
+                double x[HR];
+#pragma unroll
+                for (int q = 0; q < HR; q++) x[q] = xrow[(q + HR) * TS * CE + l1];
+#pragma unroll
+                for (int q = 0; q < HR; q++)
+#pragma unroll
+                    for (int k = 0; k < KH; k++) accg[k] = fma(wp[TS * (q + HR) + k], x[q], accg[k]);
+            }
+        }
+    }
+    // chain coefficients from the raw gathers (0 for a cell that is no pair: its FC is 0)
+    double p_tjb[NSL], p_cst[NSL], p_ctja[NSL], p_cbx[NSL], p_cba[NSL], p_c01[NSL], p_c10[NSL], p_c11[NSL];
+#pragma unroll
+    for (int sl = 0; sl < NSL; sl++) {
+        const int d = d0 + w + W * sl;
+        const bool pr = i <= n - 1 - d && pairs_s(s_i, s_jp1[sl]);
+        p_tjb[sl] = pr ? r_tjb[sl] : 0.0;
+        p_ctja[sl] = pr ? r_tja[sl] * L->e_mpmb : 0.0;
+        p_cst[sl] = pr ? r_tst[sl] * L->lam2 : 0.0;
+        p_cbx[sl] = r_bp[sl] * r_tjbd[sl];
+        p_cba[sl] = r_bp[sl] * r_tjad[sl];
+        p_c01[sl] = L->w01 * r_b01[sl];
+        p_c10[sl] = L->w10 * r_b10[sl];
+        p_c11[sl] = L->w11 * r_11[sl];
+    }
+    RH_STAMP(4);
+    __syncthreads();   // every wavefront is done with the staged rows: the region behind the first KD fixed rows is reused
+    RH_STAMP(5);
+    double* const PART = lds + P::OFF_PART;
+    double* const SFM = lds + P::OFF_S;
+    double* const SFM1 = SFM + KD * CS;
+    double* const SFCX = SFM1 + KD * CS;
+    double* const SFC = SFCX + KD * CS;
+    double* const SFCA = SFC + KD * CS;
+#pragma unroll
+    for (int k = 0; k < KH; k++) {
+        PART[((wt * KD + kb + k) * 2 + 0) * 64 + lane] = acc2[k];
+        PART[((wt * KD + kb + k) * 2 + 1) * 64 + lane] = accg[k];
+    }
+    __syncthreads();
+
+    // ---- chain: step K finishes diagonal d0+K on wavefront K % W.  Only the terms that touch row K-1 (and the epilogue) are on the
+    // critical path: in time slot T wavefront T % W finishes step T (fin) while the next wavefront gathers, for step T+1, the
+    // partial sums and every term of rows <= T-1 (pre).
+    const double w_mu = L->w_mu, w_mp2 = L->w_mp2;
+    const double hp30 = L->E_hairpin[30], lam = L->lam;
+    double fm2s[NSL], gs[NSL];
+    auto pre = [&](auto KC) {
+        constexpr int K = decltype(KC)::value, SL = K / W;
+        const int d = d0 + K;
+        double fm2 = p_far[SL], g = 0.0;
+#pragma unroll
+        for (int q = 0; q < TS; q++) { fm2 += PART[((q * KD + K) * 2 + 0) * 64 + lane]; g += PART[((q * KD + K) * 2 + 1) * 64 + lane]; }
+#pragma unroll
+        for (int dp = 0; dp + 2 <= K; dp++) {
+            const int m = K - dp;
+            fm2 = fma(f1[m - 1], SFM[dp * CS + lane + m], fm2);                                  // FM1[m][i] * FM[d0+dp][i+m]
+            if (m <= d - 32) fm2 = fma(SFM1[dp * CS + lane], LDm[(m - 1) * CD + lane + K], fm2);   // FM1[d0+dp][i] * FM[e = m][i+d0+dp]
+            const int t = K - 2 - dp;
+#pragma unroll
+            for (int l1 = 0; l1 <= t; l1++) g = fma(L->shape_w[t * (t + 1) / 2 + l1], SFCX[dp * CS + lane + 1 + l1], g);
+        }
+        fm2s[SL] = fm2; gs[SL] = g;
+    };
+    auto fin = [&](auto KC) {
+        constexpr int K = decltype(KC)::value, SL = K / W;
+        const int d = d0 + K;
+        const bool v = i <= n - 1 - d;
+        double fm2 = fm2s[SL];
+        const double g = gs[SL];
+        if constexpr (K >= 1) {   // the two terms that touch row K-1
+            fm2 = fma(f1[0], SFM[(K - 1) * CS + lane + 1], fm2);
+            if (1 <= d - 32) fm2 = fma(SFM1[(K - 1) * CS + lane], LDm[lane + K], fm2);
+        }
+        double x01 = p_x01, x10 = p_x10, x11 = p_x11, o_fc = p_fc, o_fca = p_fca, o_fm1 = p_fm1, o_fm = p_fm;
+        if constexpr (K >= 3) { x01 = SFCX[(K - 3) * CS + lane + 1]; x10 = SFCX[(K - 3) * CS + lane + 2]; }
+        if constexpr (K >= 4) x11 = SFCX[(K - 4) * CS + lane + 2];
+        if constexpr (K >= 2) { o_fc = SFC[(K - 2) * CS + lane + 1]; o_fca = SFCA[(K - 2) * CS + lane + 1]; }
+        if constexpr (K >= 1) { o_fm1 = SFM1[(K - 1) * CS + lane + 1]; o_fm = SFM[(K - 1) * CS + lane]; }
+        double lk = lam_d0;
+#pragma unroll
+        for (int q = 0; q < K; q++) lk *= lam;
+        const double hp = lk * hp30;                                                   // ScoreHairpin, d >= 30 (ipp:2123-2152)
+        const double sp = p_c01[SL] * x01 + p_c10[SL] * x10 + p_c11[SL] * x11;
+        double fc = p_tjb[SL] * (g + sp + hp) + p_cst[SL] * o_fc + fm2 * p_ctja[SL];   // ipp:3573-3622 (coefficients are 0 for a non-pair)
+        double fm1v = o_fca * w_mp2 + o_fm1 * w_mu;                                    // ipp:3641-3688
+        double fmv = fm2 + o_fm * w_mu + fm1v;
+        if (!v) { fc = 0.0; fm1v = 0.0; fmv = 0.0; }
+        const double fcxv = fc * p_cbx[SL], fcav = fc * p_cba[SL];
+        SFM[K * CS + lane] = fmv; SFM1[K * CS + lane] = fm1v; SFCX[K * CS + lane] = fcxv; SFC[K * CS + lane] = fc; SFCA[K * CS + lane] = fcav;
+    };
+    RH_STAMP(6);
+    if (w == 0) pre(IC<0>{});
+#define RH_SLOT(T)                                                      \
+    if constexpr (T < KD) {                                             \
+        if (w == T % W) fin(IC<T>{});                                   \
+        if constexpr (T + 1 < KD) {                                     \
+            if (w == (T + 1) % W) pre(IC<(T + 1 < KD ? T + 1 : 0)>{}); \
+            lds_barrier();                                              \
+        }                                                               \
+    }
+    RH_SLOT(0) RH_SLOT(1) RH_SLOT(2) RH_SLOT(3) RH_SLOT(4) RH_SLOT(5) RH_SLOT(6) RH_SLOT(7)
+#undef RH_SLOT
+    RH_STAMP(7);
+    lds_barrier();
+    // ---- the strip's rows go to HBM now, off the chain: row r = (table, diagonal) by wavefront r % W, columns of this group only
+    if (lane < GS) {
+#pragma unroll 1
+        for (int r = w; r < 5 * KD; r += W) {
+            const int tb = r / KD, k = r - tb * KD, d = d0 + k;   // S row order: FM, FM1, FCX, FC, FCA
+            const int slot_of[5] = {S_FM, S_FM1, S_FCX, S_FC, S_FCA};
+            if (i <= n - 1 - d) tab[slot_of[tb] * ts + (size_t)d * ld + i] = SFM[r * CS + lane];
+        }
+    }
+    RH_STAMP(8);
+}
+
+// F5i[jj], jj = jlo .. n, once every row of FCA is final (after the last strip)
+__global__ __launch_bounds__(256) void lin_f5i_tail(McBatch B, const LinModel* __restrict__ L, int jlo)
+{
+    __shared__ double red[4];
+    const int sq = blockIdx.x;
+    if (sq >= B.ns) return;
+    const int n = B.n[sq], ld = B.ld;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double* __restrict__ f5i = B.f5i + (size_t)sq * ld;
+    const double* __restrict__ fca = B.tab + (size_t)sq * B.seq_stride + S_FCA * B.tab_stride;
+#pragma unroll 1
+    for (int jj = jlo < 1 ? 1 : jlo; jj <= n; jj++) {
+        double acc = 0.0;
+        for (int k = threadIdx.x; k <= jj - 2; k += 256) acc = fma(f5i[k], fca[(size_t)(jj - 2 - k) * ld + (k + 1)], acc);
+        acc = wsum_s(acc);
+        if (lane == 0) red[w] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) f5i[jj] = f5i[jj - 1] * L->w_eu + (red[0] + red[1] + red[2] + red[3]) * L->w_ep2;
+        __syncthreads();
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// outside (pull form) + posterior, diagonals d0, d0-1, .., d0-KD+1 (d0 % KD == KD-1); the mirror image of the inside strip:
+//   FMo [i,d] = sum_{e=1}^{31} FM2o[d+e][i-e] * FM1[e][i-e] + FMOF [i,d]   (far: i' <= i-32, block products)     ipp:4046-4064, pulled
+//   FM1o[i,d] = sum_{e=1}^{31} FM2o[d+e][i]   * FM [e][i+d] + FM1OF[i,d]   (far: j' >= j+32)
+//   FCo gather: sum_t sum_l1 w(l1,t-l1) * FCoX[d+2+t][i-1-l1]                                                       ipp:4004-4024, pulled
+// The sliding rows are d0+1 .. d0+32 (final before the launch), the strip's own rows are reached to the LEFT (columns i-e), so
+// the trapezoid shrinks from lane 0: step k is valid for lanes >= k, a group stores lanes KD-1 .. 63 and groups advance by
+// 64-(KD-1) columns.  Last group: F5o[f5_hi .. f5_lo] (descending), what the NEXT launch's cells read.
+template <int KD, int W>
+struct OutStripPlan {
+    static constexpr int GS = 64 - (KD - 1);
+    static constexpr int NM = 31;
+    static constexpr int TS = 4;
+    static constexpr int RD = NM + KD, CD = 72;       // FM rows e = 1.. (row e-1), columns i0+d0-(KD-1) .. +71; rows e > 31 zero
+    static constexpr int RA = NM + KD - 1, CA = 96;   // KD-1 zero rows, then FM2o rows d0+1 .. d0+31; columns i0-31 .. i0+64
+    static constexpr int RE = 32, CE = 96;            // FCoX rows d0+1+rho; columns i0-32 .. i0+63
+    static constexpr int SZ = RD * CD + RA * CA + RE * CE + 512;
+    static constexpr int PADL = 8, CS = 72;           // strip rows: lane l at index l+PADL
+    static constexpr int KEEP = (KD - 1) * CD;        // fixed FM rows e = 1..KD-1 stay live through the chain
+    static constexpr int OFF_PART = KEEP;             // [TS][KD][3][64] partial sums; row k is reused for the posterior of diagonal k
+    static constexpr int OFF_S = OFF_PART + TS * KD * 3 * 64;   // [5][KD][CS] rows FM2o, FMo, FM1o, FCo, FCoX of this strip
+    static_assert(OFF_S + 5 * KD * CS <= SZ, "overlay does not fit");
+    static_assert(SZ * 8 <= 80 * 1024, "two workgroups per CU");
+};
+
+// F5o[k] = F5o[k+1]*ext_unpaired + sum_{jj>=k+2} F5o[jj]*FCA[k+1,jj-1]*ext_paired, k = khi .. klo descending   (ipp:3751-3780, pulled)
+template <int W>
+__device__ __forceinline__ void f5o_range(const double* __restrict__ fca_tab, double* __restrict__ f5o, const LinModel* __restrict__ L, int n, int ld,
+                                          int khi, int klo, double* red)
+{
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll 1
+    for (int k = khi; k >= klo && k >= 1; k--) {
+        if (k > n - 1) continue;
+        const double* __restrict__ fca = fca_tab + (k + 1);
+        double acc = 0.0;
+        for (int jj = k + 2 + threadIdx.x; jj <= n; jj += 64 * W) acc = fma(f5o[jj], fca[(size_t)(jj - 2 - k) * ld], acc);
+        acc = wsum_s(acc);
+        if (lane == 0) red[w] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+#pragma unroll
+            for (int q = 0; q < W; q++) t += red[q];
+            f5o[k] = f5o[k + 1] * L->w_eu + t * L->w_ep2;
+        }
+        __syncthreads();   // F5o[k] is an operand of F5o[k-1]
+    }
+}
+
+// F5o[khi .. klo] of every sequence before the first outside strip
+__global__ __launch_bounds__(256) void lin_f5o_head(McBatch B, const LinModel* __restrict__ L, int khi, int klo)
+{
+    __shared__ double red[4];
+    const int sq = blockIdx.x;
+    if (sq >= B.ns) return;
+    f5o_range<4>(B.tab + (size_t)sq * B.seq_stride + S_FCA * B.tab_stride, B.f5o + (size_t)sq * B.ld, L, B.n[sq], B.ld, khi, klo, red);
+}
+
+template <int KD, int W>
+__global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_outside_strip(McBatch B, const LinModel* __restrict__ L, const double* __restrict__ wT, int d0, int f5_hi,
+                                                                              int f5_lo, int pin, int* __restrict__ bad)
+{
+    using P = OutStripPlan<KD, W>;
+    constexpr int GS = P::GS, NM = P::NM, CD = P::CD, CA = P::CA, CE = P::CE, CS = P::CS, PADL = P::PADL;
+    constexpr int NSL = KD / W;
+    constexpr int TS = P::TS, KH = KD * TS / W;
+    static_assert(KD % W == 0 && KD <= 8 && W % TS == 0 && KD % (W / TS) == 0 && (NM + 1) % W == 0, "8 terms per end and term set, 32/W staged rows per wavefront and region");
+    __shared__ double lds[P::SZ];
+    __shared__ double red[W];
+    const int sq = pin ? blockIdx.x : blockIdx.y;
+    const int slot = pin ? blockIdx.y : blockIdx.x;
+    if (sq >= B.ns) return;
+    const int n = B.n[sq];
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int wt = w % TS, kb = (w / TS) * KH;
+    const int ld = B.ld;
+    const size_t ts = B.tab_stride;
+    const uint8_t* __restrict__ s = B.seq + (size_t)sq * B.lds;
+    double* __restrict__ tab = B.tab + (size_t)sq * B.seq_stride;
+    const double* __restrict__ f5i = B.f5i + (size_t)sq * ld;
+    double* __restrict__ f5o = B.f5o + (size_t)sq * ld;
+    const int dlow = d0 - (KD - 1);                        // the longest diagonal of the strip
+    const int ncell_max = n - 1 - dlow > 0 ? n - 1 - dlow : 0;
+    const int ngroup = (ncell_max + GS - 1) / GS;
+    if (slot > ngroup) return;
+    if (slot == ngroup) {
+        f5o_range<W>(tab + S_FCA * ts, f5o, L, n, ld, f5_hi, f5_lo, red);
+        return;
+    }
+
+    RH_STAMP_BEGIN();
+    const int i0 = 1 + slot * GS - (KD - 1);               // lane l <-> column i0+l; lanes >= KD-1 are this group's own columns
+    const int i = i0 + lane;
+    const bool icol = i >= 1 && i < ld;
+    const int ic = i < 1 ? 1 : (i < ld ? i : ld - 1);
+    double* const LDm = lds;                               // fixed FM rows e = 1..
+    double* const LA = lds + P::RD * CD;                   // zero rows + sliding FM2o rows
+    double* const LE = LA + P::RA * CA;                    // sliding FCoX rows
+    const double* __restrict__ fm = tab + S_FM * ts;
+    const double* __restrict__ fm1 = tab + S_FM1 * ts;
+    const double* __restrict__ fm2o = tab + S_FM2O * ts;
+    const double* __restrict__ fcox = tab + S_FCOX * ts;
+
+    // sequence letters of this wavefront's chain steps k = w + W*sl
+    int s_j[NSL], s_jp1[NSL], s_jp2[NSL], s_jm[NSL];
+    const int s_im1 = (i >= 1 && i - 1 < B.lds) ? s[i - 1] : 4, s_i = (i >= 0 && i < B.lds) ? s[i] : 4, s_ip1 = (i >= -1 && i + 1 < B.lds) ? s[i + 1] : 4;
+#pragma unroll
+    for (int sl = 0; sl < NSL; sl++) {
+        const int d = d0 - (w + W * sl), j = i + d;
+        const bool v = i >= 1 && d >= 0 && i <= n - 1 - d;
+        s_j[sl] = v ? s[j] : 4; s_jp1[sl] = v ? s[j + 1] : 4; s_jp2[sl] = v ? s[j + 2] : 4;
+        s_jm[sl] = 0;
+    }
+
+    // ---- global loads of everything this wavefront stages or keeps, issued back to back
+    constexpr int NR = (NM + 1) / W;
+    constexpr int NT = (NM + 1) / TS;
+    double vA0[NR], vA1[NR], vD0[NR], vD1[NR], vE0[NR], vE1[NR], a_lo[NT], a_hi[NT];
+    auto clampc = [&](int c) { return c < 0 ? 0 : (c < ld ? c : ld - 1); };
+    auto clampr = [&](int r) { return r < 0 ? 0 : (r < ld ? r : ld - 1); };
+    const int cA0 = i0 - 31 + lane, cA1 = i0 - 31 + 64 + (lane & 31);     // A: columns i0-31 ..
+    const int cE0 = i0 - 32 + lane, cE1 = i0 - 32 + 64 + (lane & 31);     // E: columns i0-32 ..
+    const int cD0 = i0 + d0 - (KD - 1) + lane, cD1 = i0 + d0 - (KD - 1) + 64 + (lane & 7);   // D: columns i0+d0-(KD-1) ..
+#pragma unroll
+    for (int q = 0; q < NR; q++) {
+        {   // A: FM2o row d0+1+ra
+            const int ra = w + W * q, R = d0 + 1 + (ra < NM ? ra : NM - 1);
+            const double* __restrict__ row = fm2o + (size_t)clampr(R) * ld;
+            vA0[q] = row[clampc(cA0)];
+            vA1[q] = row[clampc(cA1)];
+        }
+        {   // D: FM row e
+            const int e = 1 + w + W * q, ee = e <= NM ? e : NM;
+            const double* __restrict__ row = fm + (size_t)ee * ld;
+            vD0[q] = row[clampc(cD0)];
+            vD1[q] = row[clampc(cD1)];
+        }
+        {   // E: FCoX row d0+1+rho
+            const int rho = w + W * q, R = d0 + 1 + rho;
+            const double* __restrict__ row = fcox + (size_t)clampr(R) * ld;
+            vE0[q] = row[clampc(cE0)];
+            vE1[q] = row[clampc(cE1)];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NT; q++) {   // this term set's own-column values: FM1[e][i-e] (FMo terms), FM2o[d0+x][i] (FM1o terms), e = x = 1+wt+TS*q
+        const int e = 1 + wt + TS * q, ee = e <= NM ? e : NM;
+        const double v = fm1[(size_t)ee * ld + clampc(i - ee)];
+        a_lo[q] = (e <= NM && i - e >= 1 && i <= n - 1) ? v : 0.0;          // cell (i-e, i): i <= n-1
+        const int R = d0 + ee;
+        const double u = fm2o[(size_t)clampr(R) * ld + ic];
+        a_hi[q] = (e <= NM && icol && i <= n - 1 - R) ? u : 0.0;            // cell (i, i+R) interior
+    }
+    // ---- operands of this wavefront's chain steps, raw: issued behind the staging loads, consumed after the filter
+    double r_tjb[NSL], r_tja[NSL], r_tst[NSL], r_bp[NSL], r_tjbd[NSL], r_tjad[NSL], r_b01[NSL], r_b10[NSL], r_11[NSL];
+    double p_far_m[NSL], p_far_1[NSL], p_fc[NSL], p_f5o[NSL];
+    double p_x01 = 0, p_x10 = 0, p_x11 = 0, p_fmo = 0, p_fm1o = 0, p_fm1o_up = 0, p_fco_up = 0;   // only step k < 4 reads rows > d0 here
+    const double p_f5i = (i >= 1 && i - 1 <= n) ? f5i[i - 1] : 0.0;
+    const double o_z = f5i[n];
+    {
+#pragma unroll
+        for (int sl = 0; sl < NSL; sl++) {
+            const int d = d0 - (w + W * sl), j = i + d;
+            const bool v = i >= 1 && d >= 0 && i <= n - 1 - d;
+            const int idx = 25 * (5 * s_i + s_ip1) + 5 * s_jp1[sl] + s_j[sl];
+            const int idd = 25 * (5 * s_jp1[sl] + s_jp2[sl]) + 5 * s_i + s_im1;
+            r_tjb[sl] = L->TJB[idx]; r_tja[sl] = L->TJA[idx];
+            r_tst[sl] = L->TST[25 * (5 * s_im1 + s_i) + 5 * s_jp2[sl] + s_jp1[sl]];
+            r_bp[sl] = L->E_bp[s_i * 5 + s_jp1[sl]];
+            r_tjbd[sl] = L->TJB[idd]; r_tjad[sl] = L->TJA[idd];
+            r_b01[sl] = L->E_b01[s_jp2[sl]]; r_b10[sl] = L->E_b10[s_im1]; r_11[sl] = L->E_11[s_im1 * 5 + s_jp2[sl]];
+            const size_t at = (size_t)(d < 0 ? 0 : d) * ld + ic;
+            p_far_m[sl] = v ? tab[S_FMOF * ts + at] : 0.0;
+            p_far_1[sl] = v ? tab[S_FM1OF * ts + at] : 0.0;
+            p_fc[sl] = v ? tab[S_FC * ts + at] : 0.0;
+            p_f5o[sl] = v ? f5o[j + 1] : 0.0;
+        }
+        const int k0 = w, d = d0 - k0, j = i + d;   // the first of its steps may still need rows > d0
+        const bool v = i >= 1 && d >= 0 && i <= n - 1 - d;
+        const bool right_ok = v && j + 1 <= n - 1, left_ok = v && i - 1 >= 1;
+        if (k0 < 1) {
+            p_fmo = right_ok ? tab[S_FMO * ts + (size_t)(d + 1) * ld + ic] : 0.0;                        // FMo [d+1][i]     ipp:3806
+            p_fm1o = left_ok ? tab[S_FM1O * ts + (size_t)(d + 1) * ld + ic - 1] : 0.0;                    // FM1o[d+1][i-1]   ipp:3833
+        }
+        if (k0 < 2) {
+            const bool up_ok = left_ok && right_ok;                                                      // the cell (i-1, j+1) is interior
+            p_fm1o_up = up_ok ? tab[S_FM1O * ts + (size_t)(d + 2) * ld + ic - 1] : 0.0;                   // ipp:3828
+            p_fco_up = up_ok ? tab[S_FCO * ts + (size_t)(d + 2) * ld + ic - 1] : 0.0;
+        }
+        if (k0 < 3) {
+            p_x01 = (left_ok && j + 2 <= n - 1) ? fcox[(size_t)(d + 3) * ld + ic - 1] : 0.0;
+            p_x10 = (v && i - 2 >= 1 && j + 1 <= n - 1) ? fcox[(size_t)(d + 3) * ld + ic - 2] : 0.0;
+        }
+        if (k0 < 4) p_x11 = (v && i - 2 >= 1 && j + 2 <= n - 1) ? fcox[(size_t)(d + 4) * ld + ic - 2] : 0.0;
+    }
+    // ---- staged rows -> LDS (cells outside the interior of their row are staged as 0)
+#pragma unroll
+    for (int q = 0; q < NR; q++) {
+        {
+            const int ra = w + W * q, R = d0 + 1 + ra, cmax = n - 1 - R;
+            if (ra < NM) {
+                LA[(KD - 1 + ra) * CA + lane] = (cA0 >= 1 && cA0 <= cmax) ? vA0[q] : 0.0;
+                if (lane < 32) LA[(KD - 1 + ra) * CA + 64 + lane] = (cA1 >= 1 && cA1 <= cmax) ? vA1[q] : 0.0;
+            }
+        }
+        {
+            const int e = 1 + w + W * q, cmax = n - 1 - e;
+            if (e <= NM) {
+                LDm[(e - 1) * CD + lane] = (cD0 >= 1 && cD0 <= cmax) ? vD0[q] : 0.0;
+                if (lane < 8) LDm[(e - 1) * CD + 64 + lane] = (cD1 >= 1 && cD1 <= cmax) ? vD1[q] : 0.0;
+            }
+        }
+        {
+            const int rho = w + W * q, R = d0 + 1 + rho, cmax = n - 1 - R;
+            LE[rho * CE + lane] = (cE0 >= 1 && cE0 <= cmax) ? vE0[q] : 0.0;
+            if (lane < 32) LE[rho * CE + 64 + lane] = (cE1 >= 1 && cE1 <= cmax) ? vE1[q] : 0.0;
+        }
+    }
+    for (int k = threadIdx.x; k < (KD - 1) * CA; k += 64 * W) LA[k] = 0.0;
+    for (int k = threadIdx.x; k < (P::RD - NM) * CD; k += 64 * W) LDm[NM * CD + k] = 0.0;
+    RH_STAMP(0);
+    __syncthreads();
+    RH_STAMP(1);
+
+    // ---- pre-phase: the terms whose operands were final before the launch, this wavefront's KH diagonals k = kb ..
+    double accm[KH], acc1[KH], accg[KH];
+#pragma unroll
+    for (int k = 0; k < KH; k++) { accm[k] = 0.0; acc1[k] = 0.0; accg[k] = 0.0; }
+    {
+        const lds_vp vLA = (lds_vp)LA;
+        const lds_vp vLD = (lds_vp)LDm;
+        double va[KH], vb[KH], na[KH], nb[KH];
+        auto issue = [&](int q, double* ra, double* rb) {
+            // FMo: FM1[e][i-e] * FM2o[d0-k+e][i-e]; that row sits in staged row (KD-1) + e-k-1 (rows < KD-1 are zero: the strip's own rows), column index lane-e+31
+            const int e = 1 + wt + TS * q, ee = e <= NM ? e : NM;
+            const lds_vp pa = vLA + (KD - 1 + ee - 1 - kb) * CA + lane - ee + 31;
+            // FM1o: FM2o[d0+x][i] * FM[x+k][i+d0-k]: staged row x+k-1 (rows e > 31 are zero), column index lane + (KD-1) - k
+            const int x = 1 + wt + TS * q, xx = x <= NM + 1 ? x : NM + 1;
+            const lds_vp pd = vLD + (xx - 1 + kb) * CD + lane + (KD - 1) - kb;
+#pragma unroll
+            for (int k = 0; k < KH; k++) { ra[k] = pa[-k * CA]; rb[k] = pd[k * (CD - 1)]; }
+        };
+        issue(0, va, vb);
+#pragma unroll
+        for (int q = 0; q < NT; q++) {
+            if (q + 1 < NT) issue(q + 1, na, nb);
+            const double a = a_lo[q], b = a_hi[q];
+#pragma unroll
+            for (int k = 0; k < KH; k++) { accm[k] = fma(a, va[k], accm[k]); acc1[k] = fma(b, vb[k], acc1[k]); }
+#pragma unroll
+            for (int k = 0; k < KH; k++) { asm volatile("" : "+v"(accm[k])); asm volatile("" : "+v"(acc1[k])); }
+#pragma unroll
+            for (int k = 0; k < KH; k++) { va[k] = na[k]; vb[k] = nb[k]; }
+        }
+    }
+    RH_STAMP(2);
+    double f1e[KD - 1];   // FM1[e][i-e], e = 1..KD-1: operands of the chain's own-row FMo terms
+#pragma unroll
+    for (int e = 1; e < KD; e++) f1e[e - 1] = (i - e >= 1 && i <= n - 1) ? fm1[(size_t)e * ld + clampc(i - e)] : 0.0;
+    RH_STAMP(3);
+    // enclosing single-branch loops: staged row rho is table row d0+1+rho = d+2+t with t = rho-1+k for diagonal d0-k; tap l1 reads column
+    // i-1-l1 of it (index lane+31-l1).  Weights as in the inside strip: wT[l1][rho+k].
+    {
+        constexpr int HR = NT / 2;
+        const lds_vp xrow = (lds_vp)LE + wt * CE + lane + 31;
+#pragma unroll 1
+        for (int l1 = 0; l1 <= kMaxSingle; l1++) {
+            const double* __restrict__ wp = wT + l1 * kWTS + wt + kb;
+            if (l1 <= wt + (HR - 1) * TS + kb + KH - 2) {
+                double x[HR];
+#pragma unroll
+                for (int q = 0; q < HR; q++) x[q] = xrow[q * TS * CE - l1];
+#pragma unroll
+                for (int q = 0; q < HR; q++)
+#pragma unroll
+                    for (int k = 0; k < KH; k++) accg[k] = fma(wp[TS * q + k], x[q], accg[k]);
+            }
+            {
+                double x[HR];
+#pragma unroll
+                for (int q = 0; q < HR; q++) x[q] = xrow[(q + HR) * TS * CE - l1];
+#pragma unroll
+                for (int q = 0; q < HR; q++)
+#pragma unroll
+                    for (int k = 0; k < KH; k++) accg[k] = fma(wp[TS * (q + HR) + k], x[q], accg[k]);
+            }
+        }
+    }
+    // chain coefficients from the raw gathers (0 for a cell that is no pair: its FCo is 0)
+    double p_cbd[NSL], p_cad[NSL], p_cst[NSL], p_ctja[NSL], p_tjbx[NSL], p_c01[NSL], p_c10[NSL], p_c11[NSL];
+#pragma unroll
+    for (int sl = 0; sl < NSL; sl++) {
+        const int d = d0 - (w + W * sl);
+        const bool pr = i >= 1 && d >= 0 && i <= n - 1 - d && pairs_s(s_i, s_jp1[sl]);
+        p_cbd[sl] = pr ? r_bp[sl] * r_tjbd[sl] : 0.0;      // e_bp * e_tjbd
+        p_cad[sl] = pr ? r_bp[sl] * r_tjad[sl] : 0.0;      // e_bp * e_tjad
+        p_cst[sl] = pr ? r_tst[sl] * L->lam2 : 0.0;
+        p_ctja[sl] = r_tja[sl] * L->e_mpmb;
+        p_tjbx[sl] = r_tjb[sl];
+        p_c01[sl] = L->w01 * r_b01[sl];
+        p_c10[sl] = L->w10 * r_b10[sl];
+        p_c11[sl] = L->w11 * r_11[sl];
+    }
+    RH_STAMP(4);
+    __syncthreads();   // every wavefront is done with the staged rows
+    RH_STAMP(5);
+    double* const PART = lds + P::OFF_PART;
+    double* const SFM2O = lds + P::OFF_S;
+    double* const SFMO = SFM2O + KD * CS;
+    double* const SFM1O = SFMO + KD * CS;
+    double* const SFCO = SFM1O + KD * CS;
+    double* const SFCOX = SFCO + KD * CS;
+#pragma unroll
+    for (int k = 0; k < KH; k++) {
+        PART[((wt * KD + kb + k) * 3 + 0) * 64 + lane] = accm[k];
+        PART[((wt * KD + kb + k) * 3 + 1) * 64 + lane] = acc1[k];
+        PART[((wt * KD + kb + k) * 3 + 2) * 64 + lane] = accg[k];
+    }
+    for (int k = threadIdx.x; k < 5 * KD; k += 64 * W) {   // the left pad of the strip rows (read by lanes < 8 only)
+#pragma unroll
+        for (int c = 0; c < PADL; c++) SFM2O[k * CS + c] = 0.0;
+    }
+    __syncthreads();
+
+    // ---- chain (see the inside strip): time slot T: wavefront T % W finishes diagonal d0-T, the next wavefront gathers for d0-T-1
+    const double w_mu = L->w_mu, w_mp2 = L->w_mp2, w_ep2 = L->w_ep2;
+    double sms[NSL], s1s[NSL], gs[NSL];
+    auto pre = [&](auto KC) {
+        constexpr int K = decltype(KC)::value, SL = K / W;
+        double sm = p_far_m[SL], s1 = p_far_1[SL], g = 0.0;
+#pragma unroll
+        for (int q = 0; q < TS; q++) {
+            sm += PART[((q * KD + K) * 3 + 0) * 64 + lane];
+            s1 += PART[((q * KD + K) * 3 + 1) * 64 + lane];
+            g += PART[((q * KD + K) * 3 + 2) * 64 + lane];
+        }
+#pragma unroll
+        for (int kp = 0; kp + 2 <= K; kp++) {
+            const int e = K - kp;
+            sm = fma(f1e[e - 1], SFM2O[kp * CS + PADL + lane - e], sm);                               // FM1[e][i-e] * FM2o[d0-kp][i-e]
+            s1 = fma(SFM2O[kp * CS + PADL + lane], LDm[(e - 1) * CD + lane + (KD - 1) - K], s1);       // FM2o[d0-kp][i] * FM[e][j]
+            const int t = K - 2 - kp;
+#pragma unroll
+            for (int l1 = 0; l1 <= t; l1++) g = fma(L->shape_w[t * (t + 1) / 2 + l1], SFCOX[kp * CS + PADL + lane - 1 - l1], g);
+        }
+        sms[SL] = sm; s1s[SL] = s1; gs[SL] = g;
+    };
+    auto fin = [&](auto KC) {
+        constexpr int K = decltype(KC)::value, SL = K / W;
+        const int d = d0 - K, j = i + d;
+        const bool v = i >= 1 && d >= 0 && i <= n - 1 - d;
+        double sm = sms[SL], s1 = s1s[SL];
+        const double g = gs[SL];
+        if constexpr (K >= 1) {   // the two terms that touch row K-1 (e = 1)
+            sm = fma(f1e[0], SFM2O[(K - 1) * CS + PADL + lane - 1], sm);
+            s1 = fma(SFM2O[(K - 1) * CS + PADL + lane], LDm[lane + (KD - 1) - K], s1);
+        }
+        double x01 = p_x01, x10 = p_x10, x11 = p_x11, o_fmo = p_fmo, o_fm1o = p_fm1o, o_fm1o_up = p_fm1o_up, o_fco_up = p_fco_up;
+        if constexpr (K >= 1) { o_fmo = SFMO[(K - 1) * CS + PADL + lane]; o_fm1o = SFM1O[(K - 1) * CS + PADL + lane - 1]; }
+        if constexpr (K >= 2) { o_fm1o_up = SFM1O[(K - 2) * CS + PADL + lane - 1]; o_fco_up = SFCO[(K - 2) * CS + PADL + lane - 1]; }
+        if constexpr (K >= 3) { x01 = SFCOX[(K - 3) * CS + PADL + lane - 1]; x10 = SFCOX[(K - 3) * CS + PADL + lane - 2]; }
+        if constexpr (K >= 4) x11 = SFCOX[(K - 4) * CS + PADL + lane - 2];
+        double fmo = 0.0, fm1o = 0.0;
+        if (d >= 2) {
+            fmo = sm + o_fmo * w_mu;                      // ipp:3806
+            fm1o = s1 + fmo + o_fm1o * w_mu;              // ipp:3809, 3833
+        }
+        const double ext = p_f5o[SL] * p_f5i * w_ep2;     // exterior loop, ipp:3768-3776
+        const double multi = o_fm1o_up * w_mp2;           // branch of a multiloop, ipp:3828
+        const double sp = p_c01[SL] * x01 + p_c10[SL] * x10 + p_c11[SL] * x11;
+        double fco = p_cad[SL] * (ext + multi) + p_cbd[SL] * (g + sp) + p_cst[SL] * o_fco_up;   // coefficients are 0 for a non-pair
+        double fm2o = fmo + fco * p_ctja[SL];                                                  // ipp:3803, 4027
+        if (!v) { fco = 0.0; fmo = 0.0; fm1o = 0.0; fm2o = 0.0; }
+        // posterior of pair (i, j+1) = FCo * FCi / Z, clipped to [0,1]                 (ipp:4689-4827)
+        double p = fco * p_fc[SL] / o_z;
+        if (v && lane >= KD - 1 && (!(p == p) || p > 1e300)) { atomicOr(&bad[sq], 1); p = 0.0; }
+        p = p > 1.0 ? 1.0 : (p < 0.0 ? 0.0 : p);
+        if (!(p == p)) p = 0.0;
+        SFM2O[K * CS + PADL + lane] = fm2o; SFMO[K * CS + PADL + lane] = fmo; SFM1O[K * CS + PADL + lane] = fm1o;
+        SFCO[K * CS + PADL + lane] = fco; SFCOX[K * CS + PADL + lane] = fco * p_tjbx[SL];
+        PART[(K * 3) * 64 + lane] = p;   // row (term set 0, diagonal K): consumed by pre<K> before this point
+    };
+    RH_STAMP(6);
+    if (w == 0) pre(IC<0>{});
+#define RH_SLOT(T)                                                      \
+    if constexpr (T < KD) {                                             \
+        if (w == T % W) fin(IC<T>{});                                   \
+        if constexpr (T + 1 < KD) {                                     \
+            if (w == (T + 1) % W) pre(IC<(T + 1 < KD ? T + 1 : 0)>{}); \
+            lds_barrier();                                              \
+        }                                                               \
+    }
+    RH_SLOT(0) RH_SLOT(1) RH_SLOT(2) RH_SLOT(3) RH_SLOT(4) RH_SLOT(5) RH_SLOT(6) RH_SLOT(7)
+#undef RH_SLOT
+    RH_STAMP(7);
+    lds_barrier();
+    // ---- the strip's rows go to HBM now, off the chain
+    if (lane >= KD - 1 && i >= 1) {
+#pragma unroll 1
+        for (int r = w; r < 5 * KD; r += W) {
+            const int tb = r / KD, k = r - tb * KD, d = d0 - k;   // S row order: FM2o, FMo, FM1o, FCo, FCoX
+            const int slot_of[5] = {S_FM2O, S_FMO, S_FM1O, S_FCO, S_FCOX};
+            if (d >= 0 && i <= n - 1 - d) tab[slot_of[tb] * ts + (size_t)d * ld + i] = SFM2O[r * CS + PADL + lane];
+        }
+    }
+    // posterior: KD consecutive entries of row i of the triangular table, written by KD adjacent threads
+    for (int t = threadIdx.x; t < 64 * KD; t += 64 * W) {
+        const int c = t / KD, k = t - c * KD, ii = i0 + c, d = d0 - k;
+        if (c >= KD - 1 && ii >= 1 && d >= 0 && ii <= n - 1 - d)
+            B.bp[(size_t)sq * B.tri_stride + tri_off_s(n, ii) + (ii + d + 1)] = PART[(k * 3) * 64 + c];
+    }
+    RH_STAMP(8);
+}
+
+template __global__ void lin_inside_strip<8, 4>(McBatch, const LinModel*, const double*, int, int, double, int);
+template __global__ void lin_inside_strip<8, 8>(McBatch, const LinModel*, const double*, int, int, double, int);
+template __global__ void lin_outside_strip<8, 4>(McBatch, const LinModel*, const double*, int, int, int, int, int*);
+template __global__ void lin_outside_strip<8, 8>(McBatch, const LinModel*, const double*, int, int, int, int, int*);
+
+}  // namespace rh

@@ -39,7 +39,11 @@ template <int BS> __global__ void lin_far_inside(McBatch B, int D);
 template <int BS> __global__ void lin_far_outside(McBatch B, int D);
 __global__ void lin_far_inside_mfma(McBatch B, int D);
 __global__ void lin_far_outside_mfma(McBatch B, int D);
-__global__ void lin_pack_tiles(McBatch B, int Dblk, int outside);
+__global__ void lin_pack_tiles(McBatch B, int Dblk, int outside, int banded);
+template <int KD, int W> __global__ void lin_inside_strip(McBatch B, const LinModel* __restrict__ L, const double* __restrict__ wT, int d0, int f5_lo, double lam_d0, int pin);
+template <int KD, int W> __global__ void lin_outside_strip(McBatch B, const LinModel* __restrict__ L, const double* __restrict__ wT, int d0, int f5_hi, int f5_lo, int pin, int* __restrict__ bad);
+__global__ void lin_f5i_tail(McBatch B, const LinModel* __restrict__ L, int jlo);
+__global__ void lin_f5o_head(McBatch B, const LinModel* __restrict__ L, int khi, int klo);
 __global__ void lin_far_inside_pk(McBatch B, int D);
 __global__ void lin_far_outside_pk(McBatch B, int D);
 __global__ void lin_finish(McBatch B, const LinModel* __restrict__ L, double* __restrict__ logz, int* __restrict__ bad);
@@ -259,6 +263,10 @@ struct rh_ctx {
     bool far_mfma = true;          // block products on v_mfma_f64_16x16x4_f64 (BS = 16); RH_FAR_MFMA=0: LDS/FMA kernel
     int lookahead = 2;             // inside sweep: 2 = two diagonals per launch (lin_inside_diag MODE 3), 1 = look-ahead pairs of launches
                                    // (MODE 1/2), 0 = one full launch per diagonal; RH_LOOKAHEAD
+    int strip = 3;                 // CONTRAfold linear path: KD = 8 diagonals per launch (mccaskill_strip.hip) with the banded near/far split;
+                                   // RH_STRIP=0: the per-diagonal-pair kernels of mccaskill_lin.hip.  Bit 0 = inside sweep, bit 1 = outside sweep
+    int strip_w = 8;               // wavefronts per strip workgroup (RH_STRIP_W = 4 | 8)
+    double* d_wT = nullptr;        // transposed, zero-padded single-branch weights wT[l1][t+1] of the strip kernels
     bool far_pk = true;            // ... on packed operand tiles (lin_pack_tiles + lin_far_*_pk); RH_FAR_PK=0: gather per product
     bool use_graphs = true;        // RH_NO_GRAPH=1 launches every kernel from the host instead
     GraphSlot g_in, g_out, g_dx;
@@ -659,24 +667,26 @@ int launch_mc_vienna(rh_ctx* c, int pin)
 //   outside: far(D) uses FM2o tiles of block diagonals >= D+2 (final before fine diagonal (D+1)*16-1) and FM1/FM tiles of
 //            every block diagonal (the last two are packed when the outside phase starts)
 // returns the number of launches it counts: 1 (the pack launch rides with its product; bench.py adds its traffic to the product's)
-static int far_inside_step(rh_ctx* c, const McBatch& B, hipStream_t st, int D, int last_block)
+static int far_inside_step(rh_ctx* c, const McBatch& B, hipStream_t st, int D, int last_block, int banded = 0)
 {
     if (!c->far_pk) { KLAUNCH(c, 1, lin_far_inside_mfma, dim3(last_block - D + 1, B.ns), dim3(256), st, B, D); return 1; }
-    KLAUNCH(c, 1, lin_pack_tiles, dim3(B.nb - (D - 2), B.ns, 2), dim3(256), st, B, D - 2, 0);
+    KLAUNCH(c, 1, lin_pack_tiles, dim3(B.nb - (D - 2), B.ns, 2), dim3(256), st, B, D - 2, 0, banded);
     KLAUNCH(c, 1, lin_far_inside_pk, dim3(last_block - D + 1, B.ns), dim3(256), st, B, D);
     return 1;
 }
-static int far_outside_begin(rh_ctx* c, const McBatch& B, hipStream_t st, int last_block)
+// repack2: the inside sweep left block diagonal 2 packed in the other form (masked for the banded split / plain for the block split)
+static int far_outside_begin(rh_ctx* c, const McBatch& B, hipStream_t st, int last_block, int banded = 0, bool repack2 = false)
 {
     if (!c->far_pk) return 0;
+    if (repack2 && last_block - 1 > 2) KLAUNCH(c, 3, lin_pack_tiles, dim3(B.nb - 2, B.ns, 2), dim3(256), st, B, 2, 0, banded);
     for (int Dblk = std::max(2, last_block - 1); Dblk <= last_block; Dblk++)
-        KLAUNCH(c, 3, lin_pack_tiles, dim3(B.nb - Dblk, B.ns, 2), dim3(256), st, B, Dblk, 0);
+        KLAUNCH(c, 3, lin_pack_tiles, dim3(B.nb - Dblk, B.ns, 2), dim3(256), st, B, Dblk, 0, banded);
     return 0;
 }
 static int far_outside_step(rh_ctx* c, const McBatch& B, hipStream_t st, int D, int last_block)
 {
     if (!c->far_pk) { KLAUNCH(c, 3, lin_far_outside_mfma, dim3(last_block - D + 1, B.ns, 2), dim3(256), st, B, D); return 1; }
-    if (D + 2 <= last_block) KLAUNCH(c, 3, lin_pack_tiles, dim3(B.nb - (D + 2), B.ns, 1), dim3(256), st, B, D + 2, 1);
+    if (D + 2 <= last_block) KLAUNCH(c, 3, lin_pack_tiles, dim3(B.nb - (D + 2), B.ns, 1), dim3(256), st, B, D + 2, 1, 0);
     KLAUNCH(c, 3, lin_far_outside_pk, dim3(last_block - D + 1, B.ns, 2), dim3(256), st, B, D);
     return 1;
 }
@@ -805,6 +815,10 @@ int launch_cofold(rh_ctx* c)
 // BS > 0: block products (mccaskill_far.hip) take the k-terms of complete blocks; schedule:
 //   inside : far(D) right after fine diagonal (D-1)*BS-1  (its operands are final, tile (I,I+D) starts at (D-1)*BS+1)
 //   outside: far(D) right before fine diagonal (D+1)*BS-1 (operands: spans >= (D+1)*BS+1, already final)
+// the strip kernels need the packed block products (masked tiles) and at least one strip behind the 32 bootstrap diagonals
+static bool strip_inside(const rh_ctx* c, const McBatch& B) { return (c->strip & 1) && c->far_pk && c->far_mfma && c->lin_bs == 16 && B.nmax >= 40; }
+static bool strip_outside(const rh_ctx* c, const McBatch& B) { return (c->strip & 2) && c->far_pk && c->far_mfma && c->lin_bs == 16 && B.nmax >= 40; }
+
 template <int W, int BS>
 int launch_mc_lin(rh_ctx* c, int pin, int phase)
 {
@@ -814,6 +828,33 @@ int launch_mc_lin(rh_ctx* c, int pin, int phase)
     if (phase == 0) {
     hipLaunchKernelGGL(lin_init, dim3((B.ns + 63) / 64), dim3(64), 0, c->s_mc, B, c->d_lin, bad);
     if constexpr (W == 4 && BS == 16) {
+        if (strip_inside(c, B)) {
+            // diagonals 0..31 by pairs (every row is "near" there), then strips of kStripKD diagonals (mccaskill_strip.hip)
+            constexpr int KD = 8, GS = 64 - (KD - 1);
+            for (int d = 0; d < 32; d += 2) {
+                const int groups = (std::max(B.nmax - 1 - d, 0) + 62) / 63 + 1;
+                KLAUNCH(c, 0, (lin_inside_diag<4, 16, 3>), pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(64 * W), c->s_mc, B, c->d_lin, d,
+                        std::exp(-c->h_lin.s * d), pin);
+                c->n_launch[0]++;
+            }
+            int d0 = 32;
+            for (; d0 <= B.nmax - 2; d0 += KD) {
+                const int groups = (std::max(B.nmax - 1 - d0, 0) + GS - 1) / GS + 1;
+                if (c->strip_w == 4)
+                    KLAUNCH(c, 0, (lin_inside_strip<KD, 4>), pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(256), c->s_mc, B, c->d_lin, c->d_wT, d0,
+                            d0 == 32 ? 32 : d0 - KD + 2, std::exp(-c->h_lin.s * d0), pin);
+                else
+                    KLAUNCH(c, 0, (lin_inside_strip<KD, 8>), pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(512), c->s_mc, B, c->d_lin, c->d_wT, d0,
+                            d0 == 32 ? 32 : d0 - KD + 2, std::exp(-c->h_lin.s * d0), pin);
+                c->n_launch[0]++;
+                if ((d0 + KD) % BS == 0) {
+                    const int D = (d0 + KD) / BS + 1;
+                    if (D >= 4 && D <= last_block) { c->n_launch[0] += far_inside_step(c, B, c->s_mc, D, last_block, 1); c->n_far[0]++; }
+                }
+            }
+            hipLaunchKernelGGL(lin_f5i_tail, dim3(B.ns), dim3(256), 0, c->s_mc, B, c->d_lin, d0 - KD + 2);
+            return RH_OK;
+        }
         if (c->lookahead == 2) {   // two diagonals per launch (lin_inside_diag MODE 3); the last launch may hold only F5i[nmax]
             for (int d = 0; d <= B.nmax; d += 2) {
                 const int groups = (std::max(B.nmax - 1 - d, 0) + 62) / 63 + 1;
@@ -859,7 +900,35 @@ int launch_mc_lin(rh_ctx* c, int pin, int phase)
     }
     return RH_OK;
     }
-    if (BS == 16 && c->far_mfma) c->n_launch[1] += far_outside_begin(c, B, c->s_mc, last_block);
+    const bool in_banded = (W == 4 && BS == 16) && strip_inside(c, B);
+    if constexpr (W == 4 && BS == 16) {
+        if (strip_outside(c, B)) {
+            // strips of KD diagonals from the top (mccaskill_strip.hip), banded near/far split: block diagonal 2 of FM1 / FM is packed masked
+            constexpr int KD = 8, GS = 64 - (KD - 1);
+            c->n_launch[1] += far_outside_begin(c, B, c->s_mc, last_block, 1, !in_banded);
+            const int d0_top = (B.nmax - 2) | (KD - 1);
+            for (int D = last_block; D >= 0 && (D + 1) * BS - 1 > d0_top; D--) { c->n_launch[1] += far_outside_step(c, B, c->s_mc, D, last_block); c->n_far[1]++; }
+            hipLaunchKernelGGL(lin_f5o_head, dim3(B.ns), dim3(256), 0, c->s_mc, B, c->d_lin, B.nmax - 1, d0_top - 5);
+            for (int d0 = d0_top; d0 >= KD - 1; d0 -= KD) {
+                if ((d0 + 1) % BS == 0) {
+                    const int D = (d0 + 1) / BS - 1;
+                    if (D >= 0 && D <= last_block) { c->n_launch[1] += far_outside_step(c, B, c->s_mc, D, last_block); c->n_far[1]++; }
+                }
+                const int groups = (std::max(B.nmax - 1 - (d0 - (KD - 1)), 0) + GS - 1) / GS + 1;
+                if (c->strip_w == 4)
+                    KLAUNCH(c, 2, (lin_outside_strip<KD, 4>), pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(256), c->s_mc, B, c->d_lin, c->d_wT, d0,
+                            d0 - 6, d0 - 13, pin, bad);
+                else
+                    KLAUNCH(c, 2, (lin_outside_strip<KD, 8>), pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(512), c->s_mc, B, c->d_lin, c->d_wT, d0,
+                            d0 - 6, d0 - 13, pin, bad);
+                c->n_launch[1]++;
+            }
+            hipLaunchKernelGGL(lin_finish, dim3((B.ns + 63) / 64), dim3(64), 0, c->s_mc, B, c->d_lin, (double*)c->d_mclogz, bad);
+            hipLaunchKernelGGL(mc_unpaired, dim3((B.nmax + 3) / 4, B.ns), dim3(256), 0, c->s_mc, B);
+            return RH_OK;
+        }
+    }
+    if (BS == 16 && c->far_mfma) c->n_launch[1] += far_outside_begin(c, B, c->s_mc, last_block, 0, in_banded);
     if (BS > 0)  // tiles whose first cell would come before the first outside diagonal: their far sums are empty
         for (int D = last_block; D >= 0 && (D + 1) * BS - 1 > B.nmax - 2; D--) {
             if (BS == 16 && c->far_mfma) c->n_launch[1] += far_outside_step(c, B, c->s_mc, D, last_block);
@@ -1070,7 +1139,7 @@ size_t shape_key(const rh_ctx* c, int which)
         for (size_t v : {(size_t)B.ns, (size_t)B.nmax, (size_t)B.ld, (size_t)B.lds, (size_t)B.tab, (size_t)B.seq, (size_t)B.n,
                          (size_t)B.f5i, (size_t)B.bp, (size_t)B.up, (size_t)c->d_bad, (size_t)c->d_mclogz, (size_t)c->lin_w, (size_t)c->lin_w_in,
                          (size_t)c->lin_bs, (size_t)B.tri_stride, (size_t)c->far_mfma, (size_t)c->max_w, (size_t)c->d_gaps,
-                         (size_t)c->d_hplen, (size_t)B.allow, (size_t)B.pk, (size_t)c->far_pk, (size_t)B.rowp, (size_t)c->lookahead})
+                         (size_t)c->d_hplen, (size_t)B.allow, (size_t)B.pk, (size_t)c->far_pk, (size_t)B.rowp, (size_t)c->lookahead, (size_t)c->strip, (size_t)c->d_wT, (size_t)c->strip_w})
             h = mix(h, v);
     } else {
         const DxLinBatch& X = c->dxl;
@@ -1311,6 +1380,8 @@ rh_ctx* rh_create(int device, int model, const char* param_file)
     if (const char* e = std::getenv("RH_FAR_MFMA")) c->far_mfma = std::atoi(e) != 0;
     if (const char* e = std::getenv("RH_FAR_PK")) c->far_pk = std::atoi(e) != 0;
     if (const char* e = std::getenv("RH_LOOKAHEAD")) c->lookahead = std::atoi(e);
+    if (const char* e = std::getenv("RH_STRIP")) c->strip = std::atoi(e);
+    if (const char* e = std::getenv("RH_STRIP_W")) c->strip_w = std::atoi(e) == 4 ? 4 : 8;
     if (const char* e = std::getenv("RH_DX_W")) c->dx_w = std::atoi(e);
     if (const char* e = std::getenv("RH_DX_QUAD")) c->dx_quad = std::atoi(e) != 0;
     bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&c->s_mc, hipStreamNonBlocking) == hipSuccess &&
@@ -1321,6 +1392,13 @@ rh_ctx* rh_create(int device, int model, const char* param_file)
               hipMemcpy(c->d_lin, &c->h_lin, sizeof(LinModel), hipMemcpyHostToDevice) == hipSuccess &&
               hipMalloc((void**)&c->d_dxlin, sizeof(DxLinModel)) == hipSuccess &&
               hipMemcpy(c->d_dxlin, &c->h_dxlin, sizeof(DxLinModel), hipMemcpyHostToDevice) == hipSuccess;
+    if (ok) {   // single-branch weights of the strip kernels: wT[l1*40 + t+1] = shape_w(l1, t-l1), zero where the shape does not exist
+        std::vector<double> wT(31 * 40, 0.0);
+        for (int t = 0; t <= kMaxSingle; t++)
+            for (int l1 = 0; l1 <= t; l1++) wT[(size_t)l1 * 40 + t + 1] = c->h_lin.shape_w[t * (t + 1) / 2 + l1];
+        ok = hipMalloc((void**)&c->d_wT, sizeof(double) * wT.size()) == hipSuccess &&
+             hipMemcpy(c->d_wT, wT.data(), sizeof(double) * wT.size(), hipMemcpyHostToDevice) == hipSuccess;
+    }
     if (ok && host_vienna) {
         c->h_vlin = new VLinModel;
         // scale exponent: log Z per nucleotide of random ACGU under the BL* energies is 0.21..0.33 for n = 200..500 (up to 0.45 on the bundled RNAs)
@@ -1357,7 +1435,7 @@ void rh_destroy(rh_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    void* bufs[] = {c->d_seq, c->d_n, c->d_mctab, c->d_f5, c->d_bp, c->d_up, c->d_dxtab, c->d_hp, c->d_logz, c->d_scal, c->d_mclogz, c->d_bad, c->d_cnt, c->d_cand, c->d_dxbad, c->d_zbar, c->d_zpart, c->d_gaps, c->d_coseq, c->d_con, c->d_cotab, c->d_pk, c->d_copk, c->d_rowp, c->d_corowp, c->d_cof5, c->d_cobp, c->d_cobad, c->d_allow, c->d_coallow, c->d_vlin, c->d_vdxl, c->d_vdx, c->d_hplen, c->d_model, c->d_lin, c->d_dxlin, c->d_vienna};
+    void* bufs[] = {c->d_seq, c->d_n, c->d_mctab, c->d_f5, c->d_bp, c->d_up, c->d_dxtab, c->d_hp, c->d_logz, c->d_scal, c->d_mclogz, c->d_bad, c->d_cnt, c->d_cand, c->d_dxbad, c->d_zbar, c->d_zpart, c->d_gaps, c->d_coseq, c->d_con, c->d_cotab, c->d_pk, c->d_copk, c->d_rowp, c->d_corowp, c->d_cof5, c->d_cobp, c->d_cobad, c->d_allow, c->d_coallow, c->d_vlin, c->d_vdxl, c->d_vdx, c->d_hplen, c->d_model, c->d_lin, c->d_dxlin, c->d_vienna, c->d_wT};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (GraphSlot* g : {&c->g_in, &c->g_out, &c->g_dx}) if (g->exec) (void)hipGraphExecDestroy(g->exec);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -1654,7 +1732,9 @@ int rh_batch_kernels(rh_ctx* c, const char* fine[3], const char* far[3], int n_f
     const std::string targs = vienna ? bs + ", false" : bs;
     names[0] = !c->has_mc ? "" : lin ? pre + "inside_diag<" + (vienna ? "8" : w_in) + ", " + targs + (vienna ? "" : (pairs && c->lin_w_in == 4) ? ", 3" : (c->lookahead == 1 && c->lin_w_in == 4 && c->lin_bs == 16) ? ", 1" : ", 0") + ">"
                                      : vienna ? "mcv_inside_diag" : "mc_inside_diag";
-    names[1] = !c->has_mc ? "" : lin ? ((pairs && (c->lin_w == 4 || c->lin_w == 8)) ? "lin_outside_pair<" + w + ", " + targs + ">" : pre + "outside_diag<" + (vienna ? "8" : w) + ", " + targs + ">")
+    if (c->has_mc && lin && !vienna && strip_inside(c, c->mc)) names[0] = c->strip_w == 4 ? "lin_inside_strip<8, 4>" : "lin_inside_strip<8, 8>";
+    const bool ostrip = c->has_mc && lin && !vienna && strip_outside(c, c->mc);
+    names[1] = ostrip ? (c->strip_w == 4 ? "lin_outside_strip<8, 4>" : "lin_outside_strip<8, 8>") : !c->has_mc ? "" : lin ? ((pairs && (c->lin_w == 4 || c->lin_w == 8)) ? "lin_outside_pair<" + w + ", " + targs + ">" : pre + "outside_diag<" + (vienna ? "8" : w) + ", " + targs + ">")
                                      : vienna ? "mcv_outside_diag" : "mc_outside_diag";
     names[2] = !c->has_dx ? "" : vienna ? (c->hybrid == RH_HYBRID_COFOLD ? (c->last_dx_path == 1 ? "vlin_inside_diag<8, 16, true> + vlin_outside_diag<8, 16, true> (s1+s2)"
                                                                                          : "mcv_inside_diag + mcv_outside_diag (s1+s2)") : (c->last_dx_path == 1 ? "dxvl_sweep4" : "dxv_sweep_diag")) : c->last_dx_path == 1 ? ((c->dx_quad && c->dx_w != 2 && c->dx_w != 8) ? std::string("dxl_sweep4") : "dxl_sweep<" + std::to_string(c->dx_w == 2 || c->dx_w == 8 ? c->dx_w : 4) + ">") : "dx_sweep_diag";
