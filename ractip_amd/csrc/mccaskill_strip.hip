@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
+#include <utility>
 
 #include "batch.h"
 #include "lin_model.h"
@@ -47,6 +48,8 @@ __device__ __forceinline__ double wsum_s(double v)
 }
 
 template <int V> using IC = std::integral_constant<int, V>;
+template <class F, int... Is> __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(IC<Is>{}), ...); }
+template <int N, class F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 // workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the wavefront's outstanding GLOBAL stores and
 // loads (s_waitcnt vmcnt(0)): inside the chain that would expose one HBM round trip per diagonal.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -79,9 +82,10 @@ struct InStripPlan {
     static constexpr int GS = 64 - (KD - 1);
     static constexpr int NM = 31;                 // near terms per end of the FM2 sum
     static constexpr int RD = NM + KD, CD = 72;   // FM rows e = 1 .. (row e-1), columns i0+d0-e .. +71; rows e > 31 are zero
-    static constexpr int RA = NM + KD - 1, CA = 96;   // FM rows d0-31 .. d0-1, columns i0+1 .. +95; 7 zero rows behind them
+    static constexpr int RA = NM + KD, CA = 96;   // FM rows d0-31 .. d0-1, columns i0+1 .. +95; KD zero rows behind them
     static constexpr int RE = 32, CE = 96;        // FCX rows d0-1-rho, rho = 0..31, columns i0+1 .. +95
-    static constexpr int SZ = RD * CD + RA * CA + RE * CE;
+    static constexpr int OFF_DUMMY = RD * CD + RA * CA + RE * CE;   // one row that is never read: the sink of the staging slots that hold no row
+    static constexpr int SZ = OFF_DUMMY + CA;
     // after the pre-phase everything behind the first KD rows of the fixed FM rows is dead and is reused:
     static constexpr int CS = 72;                 // row pitch of the strip's own rows
     static constexpr int TS = 4;                  // term sets: wavefront w accumulates term set w % TS for diagonals (w / TS) * KD*TS/W ..
@@ -143,6 +147,12 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_inside_strip(McB
         return;
     }
 
+#ifdef RH_STAGGER
+    {   // tuning build: offset the second workgroup of every CU by about half a workgroup lifetime (lock-step rounds)
+        const unsigned lin = blockIdx.x + blockIdx.y * gridDim.x;
+        if (lin >= 256 && lin < 512) for (int q = 0; q < RH_STAGGER; q++) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     RH_STAMP_BEGIN();
     const int i0 = 1 + slot * GS;
     const int i = i0 + lane;
@@ -154,50 +164,76 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_inside_strip(McB
     const double* __restrict__ fm1 = tab + S_FM1 * ts;
     const double* __restrict__ fcx = tab + S_FCX * ts;
 
-    // sequence letters of this wavefront's chain steps k = w + W*sl (their table gathers follow as soon as the staging loads are out)
+    // sequence letters of this wavefront's chain steps k = w + W*sl: the FIRST loads issued (their table gathers follow as soon as the
+    // staging loads are out, and vmcnt counts in order).  Unconditional loads at clamped positions, selected afterwards: a
+    // branch around a load makes the compiler drain every outstanding load at the join.
     int s_j[NSL], s_jp1[NSL], s_jp2[NSL];
-    const int s_im1 = i - 1 < B.lds ? s[i - 1] : 4, s_i = i < B.lds ? s[i] : 4, s_ip1 = i + 1 < B.lds ? s[i + 1] : 4;
+    int s_im1, s_i, s_ip1;
+    int rb0, rb1, rb2, r0[NSL], r1[NSL], r2[NSL];
+    {
+        const int top = B.lds - 1;
+        const int c_i = i < top ? i : top - 1;                   // i >= 1 here
+        rb0 = s[c_i - 1]; rb1 = s[c_i]; rb2 = s[c_i + 1];
 #pragma unroll
-    for (int sl = 0; sl < NSL; sl++) {
-        const int d = d0 + w + W * sl, j = i + d;
-        const bool v = i <= n - 1 - d;
-        s_j[sl] = v ? s[j] : 4; s_jp1[sl] = v ? s[j + 1] : 4; s_jp2[sl] = v ? s[j + 2] : 4;
+        for (int sl = 0; sl < NSL; sl++) {
+            const int j = i + d0 + w + W * sl, cj = j + 2 <= top ? j : top - 2;
+            r0[sl] = s[cj]; r1[sl] = s[cj + 1]; r2[sl] = s[cj + 2];
+        }
     }
     // ---- global loads of everything this wavefront stages or keeps: issued back to back (64 row segments in flight), then written to LDS.
     // Cells outside the interior of their row are staged as 0: stale bytes never enter a product.
+    // No address clamps: a column past the end of its row (or a row past its table) still lies inside this sequence's table
+    // block, and whatever is read there is replaced by 0 on the way into LDS.  The 32-column (8-column) tails of two (NR)
+    // rows share one load: lane halves (eighths) select the row.
     constexpr int NR = (NM + 1) / W;   // staged rows per wavefront and region
     constexpr int NT = (NM + 1) / TS;  // terms per end of this wavefront's term set
-    double vA0[NR], vA1[NR], vD0[NR], vD1[NR], vE0[NR], vE1[NR], a_lo[NT], a_hi[NT];
-    const int ca0 = i0 + 1 + lane, ca1 = i0 + 65 + (lane & 31);
+    static_assert(NR % 2 == 0 && NR <= 8, "row tails are paired");
+    double vA0[NR], vA1[NR / 2], vD0[NR], vD1, vE0[NR], vE1[NR / 2], a_lo[NT], a_hi[NT];
+    const int lhalf = lane >> 5, lsub = lane & 31;
+    const int ca0 = i0 + 1 + lane, ca1 = i0 + 65 + lsub;            // columns of the 64-wide part / of the tail
+    const int dsel = lane >> 3, dsub = lane & 7;                     // D tails: row = dsel (< NR), 8 columns each
+    const int eD = 1 + w + W * dsel, cD1 = i0 + d0 - eD + 64 + dsub;
+    {
+        const unsigned oA0 = (unsigned)ca0, oA1 = (unsigned)(ca1 + lhalf * W * ld);
+        const unsigned oD0 = (unsigned)(i0 + d0 + lane);
 #pragma unroll
-    for (int q = 0; q < NR; q++) {
-        {   // A: FM row d0-31+ra, columns i0+1 ..
-            const int ra = w + W * q, rr = ra < NM ? ra : NM - 1, R = d0 - NM + rr;
-            const double* __restrict__ row = fm + (size_t)R * ld;
-            vA0[q] = row[ca0 < ld ? ca0 : ld - 1];
-            vA1[q] = row[ca1 < ld ? ca1 : ld - 1];
+        for (int q = 0; q < NR; q++) {
+            const int ra = w + W * q;                                // A row d0-31+ra (ra = 31: a zero row, anything may be read), E row d0-1-rho, rho = ra
+            vA0[q] = fm[(unsigned)((d0 - NM + (ra < NM ? ra : NM - 1)) * ld) + oA0];
+            vE0[q] = fcx[(unsigned)((d0 - 1 - ra) * ld) + oA0];
+            const int e = 1 + w + W * q, ee = e <= NM ? e : NM;      // D row e, columns i0+d0-e ..
+            vD0[q] = fm[(unsigned)(ee * (ld - 1)) + oD0];
         }
-        {   // D: FM row e, columns i0+d0-e ..
-            const int e = 1 + w + W * q, ee = e <= NM ? e : NM, c0 = i0 + d0 - ee + lane, c1 = i0 + d0 - ee + 64 + (lane & 7);
-            const double* __restrict__ row = fm + (size_t)ee * ld;
-            vD0[q] = row[c0 < ld ? c0 : ld - 1];
-            vD1[q] = row[c1 < ld ? c1 : ld - 1];
+#pragma unroll
+        for (int p2 = 0; p2 < NR / 2; p2++) {
+            const int ra = w + W * 2 * p2;                           // lanes 0..31: row ra, lanes 32..63: row ra+W
+            vA1[p2] = fm[(unsigned)((d0 - NM + ra) * ld) + oA1];                                  // (row ra+W = 31 is a zero row: masked below)
+            vE1[p2] = fcx[(unsigned)((d0 - 1 - ra - W) * ld) + (unsigned)(ca1 + (1 - lhalf) * W * ld)];   // E rows run downwards: row ra in lanes 0..31
         }
-        {   // E: FCX row d0-1-rho, columns i0+1 ..
-            const int rho = w + W * q, R = d0 - 1 - rho;
-            const double* __restrict__ row = fcx + (size_t)R * ld;
-            vE0[q] = row[ca0 < ld ? ca0 : ld - 1];
-            vE1[q] = row[ca1 < ld ? ca1 : ld - 1];
-        }
+        vD1 = fm[(unsigned)((eD <= NM ? eD : NM) * ld) + (unsigned)(cD1 > 0 ? cD1 : 0)];
     }
 #pragma unroll
-    for (int q = 0; q < NT; q++) {   // this term set's FM1 values: rows m = 1+wt+TS*q (low end) and d0-x, x = 1+wt+TS*q (high end), column i
-        const int m = 1 + wt + TS * q, mm = m <= NM ? m : NM;
-        const double v = fm1[(size_t)mm * ld + ic];
-        a_lo[q] = (m <= NM && i <= n - 1 - m) ? v : 0.0;
-        const int R = d0 - mm;
-        const double u = fm1[(size_t)R * ld + ic];
-        a_hi[q] = (m <= NM && m <= d0 - 32 && i <= n - 1 - R) ? u : 0.0;   // e = k+x <= d-32: rows m' = d-e >= 32 only
+    for (int q = 0; q < NT; q++) {   // this term set's FM1 values: rows m = 1+wt+TS*q (low end) and d0-m (high end), column i.  Slot m = 32 is
+        // no term: it is paired with zero rows below.  Per-lane validity is a select; the wave-uniform condition of the high end
+        // (m <= d0-32) is a 0/1 factor applied at use -- a uniform select on a load becomes a branch with a full drain behind it.
+        const int m = 1 + wt + TS * q, R = d0 - m;
+        const double v = fm1[(unsigned)(m * ld) + (unsigned)i], u = fm1[(unsigned)(R * ld) + (unsigned)i];
+        a_lo[q] = i <= n - 1 - m ? v : 0.0;
+        a_hi[q] = i <= n - 1 - R ? u : 0.0;
+    }
+    // the letters are first touched HERE, behind the staging loads (fence + pins: their wait must not move above those loads)
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" : "+v"(rb0)); asm volatile("" : "+v"(rb1)); asm volatile("" : "+v"(rb2));
+#pragma unroll
+    for (int sl = 0; sl < NSL; sl++) { asm volatile("" : "+v"(r0[sl])); asm volatile("" : "+v"(r1[sl])); asm volatile("" : "+v"(r2[sl])); }
+    {
+        const bool vi = i <= n;
+        s_im1 = vi ? rb0 : 4; s_i = vi ? rb1 : 4; s_ip1 = vi ? rb2 : 4;
+#pragma unroll
+        for (int sl = 0; sl < NSL; sl++) {
+            const bool v = i <= n - 1 - (d0 + w + W * sl);
+            s_j[sl] = v ? r0[sl] : 4; s_jp1[sl] = v ? r1[sl] : 4; s_jp2[sl] = v ? r2[sl] : 4;
+        }
     }
     // ---- operands of this wavefront's chain steps, raw: issued behind the staging loads, consumed after the filter
     double r_tjb[NSL], r_tja[NSL], r_tst[NSL], r_bp[NSL], r_tjbd[NSL], r_tjad[NSL], r_b01[NSL], r_b10[NSL], r_11[NSL], p_far[NSL];
@@ -213,37 +249,50 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_inside_strip(McB
             r_bp[sl] = L->E_bp[s_i * 5 + s_jp1[sl]];
             r_tjbd[sl] = L->TJB[idd]; r_tjad[sl] = L->TJA[idd];
             r_b01[sl] = L->E_b01[s_j[sl]]; r_b10[sl] = L->E_b10[s_ip1]; r_11[sl] = L->E_11[s_ip1 * 5 + s_j[sl]];
-            p_far[sl] = (v && d >= 64) ? tab[S_FM2F * ts + (size_t)d * ld + i] : 0.0;
+            const double far = tab[S_FM2F * ts + (unsigned)(d * ld) + (unsigned)i];   // (rows < 64 hold nothing: selected away)
+            p_far[sl] = (v & (d >= 64)) ? far : 0.0;
         }
-        const int k0 = w, d = d0 + k0;   // the first of its steps may still need rows < d0
+        // the first of its steps may still need rows < d0 (unconditional loads, selected afterwards)
+        const int k0 = w, d = d0 + k0;
         const bool v = i <= n - 1 - d;
-        const int c1 = i + 1 < ld ? i + 1 : ld - 1, c2 = i + 2 < ld ? i + 2 : ld - 1;
-        if (k0 < 3) { p_x01 = v ? fcx[(size_t)(d - 3) * ld + c1] : 0.0; p_x10 = v ? fcx[(size_t)(d - 3) * ld + c2] : 0.0; }
-        if (k0 < 4) p_x11 = v ? fcx[(size_t)(d - 4) * ld + c2] : 0.0;
-        if (k0 < 2) { p_fc = v ? tab[S_FC * ts + (size_t)(d - 2) * ld + c1] : 0.0; p_fca = v ? tab[S_FCA * ts + (size_t)(d - 2) * ld + c1] : 0.0; }
-        if (k0 < 1) { p_fm1 = v ? fm1[(size_t)(d - 1) * ld + c1] : 0.0; p_fm = v ? fm[(size_t)(d - 1) * ld + ic] : 0.0; }
+        {
+            const unsigned c1 = (unsigned)(i + 1), c2 = (unsigned)(i + 2);
+            const double x01 = fcx[(unsigned)((d - 3) * ld) + c1], x10 = fcx[(unsigned)((d - 3) * ld) + c2], x11 = fcx[(unsigned)((d - 4) * ld) + c2];
+            const double fc = tab[S_FC * ts + (unsigned)((d - 2) * ld) + c1], fca = tab[S_FCA * ts + (unsigned)((d - 2) * ld) + c1];
+            const double xm1 = fm1[(unsigned)((d - 1) * ld) + c1], xm = fm[(unsigned)((d - 1) * ld) + (unsigned)i];
+            p_x01 = (v & (k0 < 3)) ? x01 : 0.0; p_x10 = (v & (k0 < 3)) ? x10 : 0.0;
+            p_x11 = (v & (k0 < 4)) ? x11 : 0.0;
+            p_fc = (v & (k0 < 2)) ? fc : 0.0; p_fca = (v & (k0 < 2)) ? fca : 0.0;
+            p_fm1 = (v & (k0 < 1)) ? xm1 : 0.0; p_fm = (v & (k0 < 1)) ? xm : 0.0;
+        }
+    }
+    // Every staged value is stored unconditionally (slots that hold no row go to a dummy row) and pinned here: otherwise the
+    // compiler sinks a LOAD into the (branchy) select at its store and waits for it there, one round trip per row.
+    double* const LX = lds + P::OFF_DUMMY;
+#pragma unroll
+    for (int q = 0; q < NR; q++) { asm volatile("" : "+v"(vA0[q])); asm volatile("" : "+v"(vE0[q])); asm volatile("" : "+v"(vD0[q])); }
+#pragma unroll
+    for (int q = 0; q < NR / 2; q++) { asm volatile("" : "+v"(vA1[q])); asm volatile("" : "+v"(vE1[q])); }
+    asm volatile("" : "+v"(vD1));
+#pragma unroll
+    for (int q = 0; q < NR; q++) {   // 64-wide parts
+        const int ra = w + W * q, e = 1 + w + W * q;
+        double* const dA = ra < NM ? LA + ra * CA : LX;
+        double* const dD = e <= NM ? LDm + (e - 1) * CD : LX;
+        dA[lane] = ca0 <= n - 1 - (d0 - NM + ra) ? vA0[q] : 0.0;
+        LE[ra * CE + lane] = ca0 <= n - 1 - (d0 - 1 - ra) ? vE0[q] : 0.0;
+        dD[lane] = i0 + d0 - e + lane <= n - 1 - e ? vD0[q] : 0.0;
     }
 #pragma unroll
-    for (int q = 0; q < NR; q++) {
-        {
-            const int ra = w + W * q, R = d0 - NM + ra, cmax = n - 1 - R;
-            if (ra < NM) {
-                LA[ra * CA + lane] = ca0 <= cmax ? vA0[q] : 0.0;
-                if (lane < 32) LA[ra * CA + 64 + lane] = ca1 <= cmax ? vA1[q] : 0.0;
-            }
-        }
-        {
-            const int e = 1 + w + W * q, c0 = i0 + d0 - e + lane, c1 = i0 + d0 - e + 64 + (lane & 7), cmax = n - 1 - e;
-            if (e <= NM) {
-                LDm[(e - 1) * CD + lane] = c0 <= cmax ? vD0[q] : 0.0;
-                if (lane < 8) LDm[(e - 1) * CD + 64 + lane] = c1 <= cmax ? vD1[q] : 0.0;
-            }
-        }
-        {
-            const int rho = w + W * q, R = d0 - 1 - rho, cmax = n - 1 - R;
-            LE[rho * CE + lane] = ca0 <= cmax ? vE0[q] : 0.0;
-            if (lane < 32) LE[rho * CE + 64 + lane] = ca1 <= cmax ? vE1[q] : 0.0;
-        }
+    for (int p2 = 0; p2 < NR / 2; p2++) {   // tails of rows ra (lanes 0..31) and ra+W (lanes 32..63)
+        const int ra = w + W * 2 * p2, rl = ra + lhalf * W;
+        double* const dA = rl < NM ? LA + rl * CA : LX;
+        dA[64 + lsub] = ca1 <= n - 1 - (d0 - NM + rl) ? vA1[p2] : 0.0;
+        LE[rl * CE + 64 + lsub] = ca1 <= n - 1 - (d0 - 1 - rl) ? vE1[p2] : 0.0;
+    }
+    {
+        double* const dD = (dsel < NR && eD <= NM) ? LDm + (eD - 1) * CD : LX;
+        dD[64 + dsub] = cD1 <= n - 1 - eD ? vD1 : 0.0;
     }
     for (int k = threadIdx.x; k < (P::RA - NM) * CA; k += 64 * W) LA[NM * CA + k] = 0.0;
     for (int k = threadIdx.x; k < (P::RD - NM) * CD; k += 64 * W) LDm[NM * CD + k] = 0.0;
@@ -263,12 +312,13 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_inside_strip(McB
         const lds_vp vLD = (lds_vp)LDm;
         double va[KH], vb[KH], na[KH], nb[KH];
         auto issue = [&](int q, double* ra, double* rb) {
-            // low end: FM1[m][i] * FM[d-m][i+m]; FM row d0+k-m sits in staged row 31+k-m (rows >= 31 are zero: the strip's own rows, added by the chain)
-            const int m = 1 + wt + TS * q, mm = m <= NM ? m : NM;
-            const lds_vp pa = vLA + (NM - mm + kb) * CA + lane + mm - 1;
+            // low end: FM1[m][i] * FM[d-m][i+m]; FM row d0+k-m sits in staged row 31+k-m (rows >= 31 are zero: the strip's own rows, added by
+            // the chain; slot m = 32 reads zero rows only)
+            const int m = 1 + wt + TS * q;
+            const lds_vp pa = vLA + ((m <= NM ? NM - m : NM) + kb) * CA + lane + (m <= NM ? m : NM) - 1;
             // high end: FM1[d0-x][i] * FM[e][i+d0-x], e = k+x, staged row e-1 at column index lane+k (rows e > 31 are zero)
-            const int x = 1 + wt + TS * q, xx = x <= NM + 1 ? x : NM + 1;
-            const lds_vp pd = vLD + (xx - 1 + kb) * CD + lane + kb;
+            const int x = m;
+            const lds_vp pd = vLD + (x - 1 + kb) * CD + lane + kb;
 #pragma unroll
             for (int k = 0; k < KH; k++) { ra[k] = pa[k * CA]; rb[k] = pd[k * (CD + 1)]; }
         };
@@ -276,7 +326,7 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_inside_strip(McB
 #pragma unroll
         for (int q = 0; q < NT; q++) {
             if (q + 1 < NT) issue(q + 1, na, nb);
-            const double a = a_lo[q], b = a_hi[q];
+            const double a = a_lo[q], b = a_hi[q] * ((1 + wt + TS * q) <= d0 - 32 ? 1.0 : 0.0);   // e = k+x <= d-32: rows m' = d-e >= 32 only
 #pragma unroll
             for (int k = 0; k < KH; k++) acc2[k] = fma(b, vb[k], fma(a, va[k], acc2[k]));
 #pragma unroll
@@ -288,7 +338,7 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_inside_strip(McB
     RH_STAMP(2);
     double f1[KD - 1];   // FM1[m][i], m = 1..KD-1: low-end operands of the chain's own-row terms (latency hides behind the filter)
 #pragma unroll
-    for (int m = 1; m < KD; m++) f1[m - 1] = i <= n - 1 - m ? fm1[(size_t)m * ld + ic] : 0.0;
+    for (int m = 1; m < KD; m++) { const double v = fm1[(unsigned)(m * ld) + (unsigned)i]; f1[m - 1] = i <= n - 1 - m ? v : 0.0; }
     RH_STAMP(3);
     // single-branch filter: staged row rho is table row d0-1-rho = d-2-t with t = rho-1+k for diagonal d0+k; tap l1 reads column
     // i+1+l1 of it.  One LDS read feeds all KD diagonals.  The weight of (row rho, diagonal k, tap l1) is wT[l1][rho+k] (zero where
@@ -321,6 +371,9 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_inside_strip(McB
             }
         }
     }
+    double cw[(KD - 1) * (KD - 2) / 2];   // single-branch weights of the chain's own-row taps (t <= KD-3), wave-uniform
+#pragma unroll
+    for (int k = 0; k < (KD - 1) * (KD - 2) / 2; k++) cw[k] = L->shape_w[k];
     // chain coefficients from the raw gathers (0 for a cell that is no pair: its FC is 0)
     double p_tjb[NSL], p_cst[NSL], p_ctja[NSL], p_cbx[NSL], p_cba[NSL], p_c01[NSL], p_c10[NSL], p_c11[NSL];
 #pragma unroll
@@ -358,22 +411,27 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_inside_strip(McB
     const double w_mu = L->w_mu, w_mp2 = L->w_mp2;
     const double hp30 = L->E_hairpin[30], lam = L->lam;
     double fm2s[NSL], gs[NSL];
-    auto pre = [&](auto KC) {
-        constexpr int K = decltype(KC)::value, SL = K / W;
-        const int d = d0 + K;
-        double fm2 = p_far[SL], g = 0.0;
+    // every step starts from the far sum and the four term sets' partial sums
+#pragma unroll
+    for (int sl = 0; sl < NSL; sl++) {
+        const int K = w + W * sl;
+        double fm2 = p_far[sl], g = 0.0;
 #pragma unroll
         for (int q = 0; q < TS; q++) { fm2 += PART[((q * KD + K) * 2 + 0) * 64 + lane]; g += PART[((q * KD + K) * 2 + 1) * 64 + lane]; }
+        fm2s[sl] = fm2; gs[sl] = g;
+    }
+    // the terms of step K that touch the strip's own row R <= K-2 (FM2: m = K-R at both ends; filter: t = K-2-R)
+    auto addrow = [&](auto RC, auto KC) {
+        constexpr int R = decltype(RC)::value, K = decltype(KC)::value, SL = K / W, m = K - R, t = K - 2 - R;
+        double fm2 = fm2s[SL], g0 = 0.0, g1 = 0.0;
+        fm2 = fma(f1[m - 1], SFM[R * CS + lane + m], fm2);                                            // FM1[m][i] * FM[d0+R][i+m]
+        if (m <= d0 + K - 32) fm2 = fma(SFM1[R * CS + lane], LDm[(m - 1) * CD + lane + K], fm2);        // FM1[d0+R][i] * FM[e = m][i+d0+R]
 #pragma unroll
-        for (int dp = 0; dp + 2 <= K; dp++) {
-            const int m = K - dp;
-            fm2 = fma(f1[m - 1], SFM[dp * CS + lane + m], fm2);                                  // FM1[m][i] * FM[d0+dp][i+m]
-            if (m <= d - 32) fm2 = fma(SFM1[dp * CS + lane], LDm[(m - 1) * CD + lane + K], fm2);   // FM1[d0+dp][i] * FM[e = m][i+d0+dp]
-            const int t = K - 2 - dp;
-#pragma unroll
-            for (int l1 = 0; l1 <= t; l1++) g = fma(L->shape_w[t * (t + 1) / 2 + l1], SFCX[dp * CS + lane + 1 + l1], g);
+        for (int l1 = 0; l1 <= t; l1++) {
+            const double x = SFCX[R * CS + lane + 1 + l1];
+            if (l1 & 1) g1 = fma(cw[t * (t + 1) / 2 + l1], x, g1); else g0 = fma(cw[t * (t + 1) / 2 + l1], x, g0);
         }
-        fm2s[SL] = fm2; gs[SL] = g;
+        fm2s[SL] = fm2; gs[SL] += g0 + g1;
     };
     auto fin = [&](auto KC) {
         constexpr int K = decltype(KC)::value, SL = K / W;
@@ -403,14 +461,17 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_inside_strip(McB
         SFM[K * CS + lane] = fmv; SFM1[K * CS + lane] = fm1v; SFCX[K * CS + lane] = fcxv; SFC[K * CS + lane] = fc; SFCA[K * CS + lane] = fcav;
     };
     RH_STAMP(6);
-    if (w == 0) pre(IC<0>{});
-#define RH_SLOT(T)                                                      \
-    if constexpr (T < KD) {                                             \
-        if (w == T % W) fin(IC<T>{});                                   \
-        if constexpr (T + 1 < KD) {                                     \
-            if (w == (T + 1) % W) pre(IC<(T + 1 < KD ? T + 1 : 0)>{}); \
-            lds_barrier();                                              \
-        }                                                               \
+    // time slot T: wavefront T % W finishes step T (fin: the two terms of row T-1 + the epilogue); every later step K > T, on
+    // its own wavefront, adds the terms of row T-1, which the previous slot completed
+#define RH_SLOT(T)                                                                                  \
+    if constexpr (T < KD) {                                                                         \
+        if (w == T % W) fin(IC<T>{});                                                               \
+        if constexpr (T >= 1 && T + 1 < KD)                                                         \
+            static_for<KD>([&](auto KC) {                                                           \
+                constexpr int K = decltype(KC)::value;                                              \
+                if constexpr (K > T) { if (w == K % W) addrow(IC<(T >= 1 ? T - 1 : 0)>{}, KC); }    \
+            });                                                                                     \
+        if constexpr (T + 1 < KD) lds_barrier();                                                    \
     }
     RH_SLOT(0) RH_SLOT(1) RH_SLOT(2) RH_SLOT(3) RH_SLOT(4) RH_SLOT(5) RH_SLOT(6) RH_SLOT(7)
 #undef RH_SLOT
@@ -465,9 +526,10 @@ struct OutStripPlan {
     static constexpr int NM = 31;
     static constexpr int TS = 4;
     static constexpr int RD = NM + KD, CD = 72;       // FM rows e = 1.. (row e-1), columns i0+d0-(KD-1) .. +71; rows e > 31 zero
-    static constexpr int RA = NM + KD - 1, CA = 96;   // KD-1 zero rows, then FM2o rows d0+1 .. d0+31; columns i0-31 .. i0+64
+    static constexpr int RA = NM + KD, CA = 96;       // KD zero rows, then FM2o rows d0+1 .. d0+31; columns i0-31 .. i0+64
     static constexpr int RE = 32, CE = 96;            // FCoX rows d0+1+rho; columns i0-32 .. i0+63
-    static constexpr int SZ = RD * CD + RA * CA + RE * CE + 512;
+    static constexpr int OFF_DUMMY = RD * CD + RA * CA + RE * CE;   // one row that is never read: the sink of the staging slots that hold no row
+    static constexpr int SZ = OFF_DUMMY + CA + 320;
     static constexpr int PADL = 8, CS = 72;           // strip rows: lane l at index l+PADL
     static constexpr int KEEP = (KD - 1) * CD;        // fixed FM rows e = 1..KD-1 stay live through the chain
     static constexpr int OFF_PART = KEEP;             // [TS][KD][3][64] partial sums; row k is reused for the posterior of diagonal k
@@ -542,11 +604,15 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_outside_strip(Mc
         return;
     }
 
+#ifdef RH_STAGGER
+    {   // tuning build: offset the second workgroup of every CU by about half a workgroup lifetime (lock-step rounds)
+        const unsigned lin = blockIdx.x + blockIdx.y * gridDim.x;
+        if (lin >= 256 && lin < 512) for (int q = 0; q < RH_STAGGER; q++) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     RH_STAMP_BEGIN();
     const int i0 = 1 + slot * GS - (KD - 1);               // lane l <-> column i0+l; lanes >= KD-1 are this group's own columns
     const int i = i0 + lane;
-    const bool icol = i >= 1 && i < ld;
-    const int ic = i < 1 ? 1 : (i < ld ? i : ld - 1);
     double* const LDm = lds;                               // fixed FM rows e = 1..
     double* const LA = lds + P::RD * CD;                   // zero rows + sliding FM2o rows
     double* const LE = LA + P::RA * CA;                    // sliding FCoX rows
@@ -555,67 +621,88 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_outside_strip(Mc
     const double* __restrict__ fm2o = tab + S_FM2O * ts;
     const double* __restrict__ fcox = tab + S_FCOX * ts;
 
-    // sequence letters of this wavefront's chain steps k = w + W*sl
-    int s_j[NSL], s_jp1[NSL], s_jp2[NSL], s_jm[NSL];
-    const int s_im1 = (i >= 1 && i - 1 < B.lds) ? s[i - 1] : 4, s_i = (i >= 0 && i < B.lds) ? s[i] : 4, s_ip1 = (i >= -1 && i + 1 < B.lds) ? s[i + 1] : 4;
+    // sequence letters of this wavefront's chain steps k = w + W*sl: the first loads issued, unconditional at clamped positions
+    // (see the inside strip for why nothing here is loaded under a branch)
+    int s_j[NSL], s_jp1[NSL], s_jp2[NSL];
+    int s_im1, s_i, s_ip1;
+    int rb0, rb1, rb2, r0[NSL], r1[NSL], r2[NSL];
+    {
+        const int top = B.lds - 1;
+        const int c_i = i < 1 ? 1 : (i < top ? i : top - 1);
+        rb0 = s[c_i - 1]; rb1 = s[c_i]; rb2 = s[c_i + 1];
 #pragma unroll
-    for (int sl = 0; sl < NSL; sl++) {
-        const int d = d0 - (w + W * sl), j = i + d;
-        const bool v = i >= 1 && d >= 0 && i <= n - 1 - d;
-        s_j[sl] = v ? s[j] : 4; s_jp1[sl] = v ? s[j + 1] : 4; s_jp2[sl] = v ? s[j + 2] : 4;
-        s_jm[sl] = 0;
+        for (int sl = 0; sl < NSL; sl++) {
+            const int j = i + d0 - (w + W * sl), cj = j < 0 ? 0 : (j + 2 <= top ? j : top - 2);
+            r0[sl] = s[cj]; r1[sl] = s[cj + 1]; r2[sl] = s[cj + 2];
+        }
     }
 
-    // ---- global loads of everything this wavefront stages or keeps, issued back to back
+    // ---- global loads of everything this wavefront stages or keeps, issued back to back.  No address clamps: a column left of
+    // or past its row, or a row past its table, still lies inside this sequence's table block (rows >= 1 here), and whatever
+    // is read there is replaced by 0 on the way into LDS.  Row tails share loads as in the inside strip.
     constexpr int NR = (NM + 1) / W;
     constexpr int NT = (NM + 1) / TS;
-    double vA0[NR], vA1[NR], vD0[NR], vD1[NR], vE0[NR], vE1[NR], a_lo[NT], a_hi[NT];
-    auto clampc = [&](int c) { return c < 0 ? 0 : (c < ld ? c : ld - 1); };
-    auto clampr = [&](int r) { return r < 0 ? 0 : (r < ld ? r : ld - 1); };
-    const int cA0 = i0 - 31 + lane, cA1 = i0 - 31 + 64 + (lane & 31);     // A: columns i0-31 ..
-    const int cE0 = i0 - 32 + lane, cE1 = i0 - 32 + 64 + (lane & 31);     // E: columns i0-32 ..
-    const int cD0 = i0 + d0 - (KD - 1) + lane, cD1 = i0 + d0 - (KD - 1) + 64 + (lane & 7);   // D: columns i0+d0-(KD-1) ..
+    static_assert(NR % 2 == 0 && NR <= 8, "row tails are paired");
+    double vA0[NR], vA1[NR / 2], vD0[NR], vD1, vE0[NR], vE1[NR / 2], a_lo[NT], a_hi[NT];
+    const int lhalf = lane >> 5, lsub = lane & 31;
+    const int cA0 = i0 - 31 + lane, cA1 = i0 - 31 + 64 + lsub;       // A: columns i0-31 ..
+    const int cE0 = i0 - 32 + lane, cE1 = i0 - 32 + 64 + lsub;       // E: columns i0-32 ..
+    const int cD0 = i0 + d0 - (KD - 1) + lane;                        // D: columns i0+d0-(KD-1) ..
+    const int dsel = lane >> 3, dsub = lane & 7;                      // D tails: row = dsel (< NR), 8 columns each
+    const int eD = 1 + w + W * dsel, cD1 = i0 + d0 - (KD - 1) + 64 + dsub;
 #pragma unroll
     for (int q = 0; q < NR; q++) {
-        {   // A: FM2o row d0+1+ra
-            const int ra = w + W * q, R = d0 + 1 + (ra < NM ? ra : NM - 1);
-            const double* __restrict__ row = fm2o + (size_t)clampr(R) * ld;
-            vA0[q] = row[clampc(cA0)];
-            vA1[q] = row[clampc(cA1)];
-        }
-        {   // D: FM row e
-            const int e = 1 + w + W * q, ee = e <= NM ? e : NM;
-            const double* __restrict__ row = fm + (size_t)ee * ld;
-            vD0[q] = row[clampc(cD0)];
-            vD1[q] = row[clampc(cD1)];
-        }
-        {   // E: FCoX row d0+1+rho
-            const int rho = w + W * q, R = d0 + 1 + rho;
-            const double* __restrict__ row = fcox + (size_t)clampr(R) * ld;
-            vE0[q] = row[clampc(cE0)];
-            vE1[q] = row[clampc(cE1)];
-        }
+        const int ra = w + W * q;                                     // A row d0+1+ra (slot 31: no row), E row d0+1+rho, rho = ra
+        vA0[q] = fm2o[(unsigned)((d0 + 1 + ra) * ld + cA0)];
+        vE0[q] = fcox[(unsigned)((d0 + 1 + ra) * ld + cE0)];
+        const int e = 1 + w + W * q, ee = e <= NM ? e : NM;           // D row e
+        vD0[q] = fm[(unsigned)(ee * ld + cD0)];
     }
 #pragma unroll
-    for (int q = 0; q < NT; q++) {   // this term set's own-column values: FM1[e][i-e] (FMo terms), FM2o[d0+x][i] (FM1o terms), e = x = 1+wt+TS*q
-        const int e = 1 + wt + TS * q, ee = e <= NM ? e : NM;
-        const double v = fm1[(size_t)ee * ld + clampc(i - ee)];
-        a_lo[q] = (e <= NM && i - e >= 1 && i <= n - 1) ? v : 0.0;          // cell (i-e, i): i <= n-1
-        const int R = d0 + ee;
-        const double u = fm2o[(size_t)clampr(R) * ld + ic];
-        a_hi[q] = (e <= NM && icol && i <= n - 1 - R) ? u : 0.0;            // cell (i, i+R) interior
+    for (int p2 = 0; p2 < NR / 2; p2++) {                             // lanes 0..31: row ra, lanes 32..63: row ra+W
+        const int ra = w + W * 2 * p2;
+        vA1[p2] = fm2o[(unsigned)((d0 + 1 + ra + lhalf * W) * ld + cA1)];
+        vE1[p2] = fcox[(unsigned)((d0 + 1 + ra + lhalf * W) * ld + cE1)];
+    }
+    vD1 = fm[(unsigned)((eD <= NM ? eD : NM) * ld + cD1)];
+#pragma unroll
+    for (int q = 0; q < NT; q++) {   // this term set's own-column values: FM1[e][i-e] (FMo terms), FM2o[d0+e][i] (FM1o terms), e = 1+wt+TS*q.
+        // Slot e = 32 is no term: it is paired with zero rows below.
+        const int e = 1 + wt + TS * q, R = d0 + e;
+        const double v = fm1[(unsigned)(e * ld + i - e)], u = fm2o[(unsigned)(R * ld + i)];
+        a_lo[q] = (i - e >= 1 && i <= n - 1) ? v : 0.0;          // cell (i-e, i)
+        a_hi[q] = (i >= 1 && i <= n - 1 - R) ? u : 0.0;          // cell (i, i+R)
+    }
+    // the letters are first touched HERE, behind the staging loads
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" : "+v"(rb0)); asm volatile("" : "+v"(rb1)); asm volatile("" : "+v"(rb2));
+#pragma unroll
+    for (int sl = 0; sl < NSL; sl++) { asm volatile("" : "+v"(r0[sl])); asm volatile("" : "+v"(r1[sl])); asm volatile("" : "+v"(r2[sl])); }
+    {
+        const bool vi = i >= 1 && i <= n;
+        s_im1 = vi ? rb0 : 4; s_i = vi ? rb1 : 4; s_ip1 = vi ? rb2 : 4;
+#pragma unroll
+        for (int sl = 0; sl < NSL; sl++) {
+            const int d = d0 - (w + W * sl);
+            const bool v = i >= 1 && i <= n - 1 - d;
+            s_j[sl] = v ? r0[sl] : 4; s_jp1[sl] = v ? r1[sl] : 4; s_jp2[sl] = v ? r2[sl] : 4;
+        }
     }
     // ---- operands of this wavefront's chain steps, raw: issued behind the staging loads, consumed after the filter
     double r_tjb[NSL], r_tja[NSL], r_tst[NSL], r_bp[NSL], r_tjbd[NSL], r_tjad[NSL], r_b01[NSL], r_b10[NSL], r_11[NSL];
     double p_far_m[NSL], p_far_1[NSL], p_fc[NSL], p_f5o[NSL];
-    double p_x01 = 0, p_x10 = 0, p_x11 = 0, p_fmo = 0, p_fm1o = 0, p_fm1o_up = 0, p_fco_up = 0;   // only step k < 4 reads rows > d0 here
-    const double p_f5i = (i >= 1 && i - 1 <= n) ? f5i[i - 1] : 0.0;
-    const double o_z = f5i[n];
+    double p_x01, p_x10, p_x11, p_fmo, p_fm1o, p_fm1o_up, p_fco_up;   // only step k < 4 reads rows > d0 here
+    const int ic = i < 1 ? 1 : i;
+    double p_f5i;
+    double r_z;
     {
+        const double f5v = f5i[ic - 1 <= n ? ic - 1 : n];
+        p_f5i = (i >= 1 && i - 1 <= n) ? f5v : 0.0;
+        r_z = 1.0 / f5i[n];   // (one division per lane, not one per diagonal on the chain)
 #pragma unroll
         for (int sl = 0; sl < NSL; sl++) {
             const int d = d0 - (w + W * sl), j = i + d;
-            const bool v = i >= 1 && d >= 0 && i <= n - 1 - d;
+            const bool v = i >= 1 && i <= n - 1 - d;
             const int idx = 25 * (5 * s_i + s_ip1) + 5 * s_jp1[sl] + s_j[sl];
             const int idd = 25 * (5 * s_jp1[sl] + s_jp2[sl]) + 5 * s_i + s_im1;
             r_tjb[sl] = L->TJB[idx]; r_tja[sl] = L->TJA[idx];
@@ -623,54 +710,59 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_outside_strip(Mc
             r_bp[sl] = L->E_bp[s_i * 5 + s_jp1[sl]];
             r_tjbd[sl] = L->TJB[idd]; r_tjad[sl] = L->TJA[idd];
             r_b01[sl] = L->E_b01[s_jp2[sl]]; r_b10[sl] = L->E_b10[s_im1]; r_11[sl] = L->E_11[s_im1 * 5 + s_jp2[sl]];
-            const size_t at = (size_t)(d < 0 ? 0 : d) * ld + ic;
-            p_far_m[sl] = v ? tab[S_FMOF * ts + at] : 0.0;
-            p_far_1[sl] = v ? tab[S_FM1OF * ts + at] : 0.0;
-            p_fc[sl] = v ? tab[S_FC * ts + at] : 0.0;
-            p_f5o[sl] = v ? f5o[j + 1] : 0.0;
+            const unsigned at = (unsigned)(d * ld + ic);
+            const double fmof = tab[S_FMOF * ts + at], fm1of = tab[S_FM1OF * ts + at], fcv = tab[S_FC * ts + at];
+            const double f5ov = f5o[j + 1 < 0 ? 0 : (j + 1 <= n ? j + 1 : n)];
+            p_far_m[sl] = v ? fmof : 0.0;
+            p_far_1[sl] = v ? fm1of : 0.0;
+            p_fc[sl] = v ? fcv : 0.0;
+            p_f5o[sl] = v ? f5ov : 0.0;
         }
-        const int k0 = w, d = d0 - k0, j = i + d;   // the first of its steps may still need rows > d0
-        const bool v = i >= 1 && d >= 0 && i <= n - 1 - d;
+        // the first of its steps may still need rows > d0 (unconditional loads, selected afterwards)
+        const int k0 = w, d = d0 - k0, j = i + d;
+        const bool v = i >= 1 && i <= n - 1 - d;
         const bool right_ok = v && j + 1 <= n - 1, left_ok = v && i - 1 >= 1;
-        if (k0 < 1) {
-            p_fmo = right_ok ? tab[S_FMO * ts + (size_t)(d + 1) * ld + ic] : 0.0;                        // FMo [d+1][i]     ipp:3806
-            p_fm1o = left_ok ? tab[S_FM1O * ts + (size_t)(d + 1) * ld + ic - 1] : 0.0;                    // FM1o[d+1][i-1]   ipp:3833
-        }
-        if (k0 < 2) {
-            const bool up_ok = left_ok && right_ok;                                                      // the cell (i-1, j+1) is interior
-            p_fm1o_up = up_ok ? tab[S_FM1O * ts + (size_t)(d + 2) * ld + ic - 1] : 0.0;                   // ipp:3828
-            p_fco_up = up_ok ? tab[S_FCO * ts + (size_t)(d + 2) * ld + ic - 1] : 0.0;
-        }
-        if (k0 < 3) {
-            p_x01 = (left_ok && j + 2 <= n - 1) ? fcox[(size_t)(d + 3) * ld + ic - 1] : 0.0;
-            p_x10 = (v && i - 2 >= 1 && j + 1 <= n - 1) ? fcox[(size_t)(d + 3) * ld + ic - 2] : 0.0;
-        }
-        if (k0 < 4) p_x11 = (v && i - 2 >= 1 && j + 2 <= n - 1) ? fcox[(size_t)(d + 4) * ld + ic - 2] : 0.0;
+        const unsigned a1 = (unsigned)((d + 1) * ld + ic), a2 = (unsigned)((d + 2) * ld + ic), a3 = (unsigned)((d + 3) * ld + ic), a4 = (unsigned)((d + 4) * ld + ic);
+        const double l_fmo = tab[S_FMO * ts + a1], l_fm1o = tab[S_FM1O * ts + a1 - 1];                    // FMo[d+1][i], FM1o[d+1][i-1]   ipp:3806, 3833
+        const double l_fm1o_up = tab[S_FM1O * ts + a2 - 1], l_fco_up = tab[S_FCO * ts + a2 - 1];          // ipp:3828
+        const double l_x01 = fcox[a3 - 1], l_x10 = fcox[a3 - 2], l_x11 = fcox[a4 - 2];
+        p_fmo = (right_ok & (k0 < 1)) ? l_fmo : 0.0;
+        p_fm1o = (left_ok & (k0 < 1)) ? l_fm1o : 0.0;
+        const bool up_ok = left_ok && right_ok;                                                          // the cell (i-1, j+1) is interior
+        p_fm1o_up = (up_ok & (k0 < 2)) ? l_fm1o_up : 0.0;
+        p_fco_up = (up_ok & (k0 < 2)) ? l_fco_up : 0.0;
+        p_x01 = (left_ok && j + 2 <= n - 1 && k0 < 3) ? l_x01 : 0.0;
+        p_x10 = (v && i - 2 >= 1 && j + 1 <= n - 1 && k0 < 3) ? l_x10 : 0.0;
+        p_x11 = (v && i - 2 >= 1 && j + 2 <= n - 1 && k0 < 4) ? l_x11 : 0.0;
     }
-    // ---- staged rows -> LDS (cells outside the interior of their row are staged as 0)
+    // ---- staged rows -> LDS (cells outside the interior of their row are staged as 0); unconditional stores, pinned values
+    double* const LX = lds + P::OFF_DUMMY;
+#pragma unroll
+    for (int q = 0; q < NR; q++) { asm volatile("" : "+v"(vA0[q])); asm volatile("" : "+v"(vE0[q])); asm volatile("" : "+v"(vD0[q])); }
+#pragma unroll
+    for (int q = 0; q < NR / 2; q++) { asm volatile("" : "+v"(vA1[q])); asm volatile("" : "+v"(vE1[q])); }
+    asm volatile("" : "+v"(vD1));
 #pragma unroll
     for (int q = 0; q < NR; q++) {
-        {
-            const int ra = w + W * q, R = d0 + 1 + ra, cmax = n - 1 - R;
-            if (ra < NM) {
-                LA[(KD - 1 + ra) * CA + lane] = (cA0 >= 1 && cA0 <= cmax) ? vA0[q] : 0.0;
-                if (lane < 32) LA[(KD - 1 + ra) * CA + 64 + lane] = (cA1 >= 1 && cA1 <= cmax) ? vA1[q] : 0.0;
-            }
-        }
-        {
-            const int e = 1 + w + W * q, cmax = n - 1 - e;
-            if (e <= NM) {
-                LDm[(e - 1) * CD + lane] = (cD0 >= 1 && cD0 <= cmax) ? vD0[q] : 0.0;
-                if (lane < 8) LDm[(e - 1) * CD + 64 + lane] = (cD1 >= 1 && cD1 <= cmax) ? vD1[q] : 0.0;
-            }
-        }
-        {
-            const int rho = w + W * q, R = d0 + 1 + rho, cmax = n - 1 - R;
-            LE[rho * CE + lane] = (cE0 >= 1 && cE0 <= cmax) ? vE0[q] : 0.0;
-            if (lane < 32) LE[rho * CE + 64 + lane] = (cE1 >= 1 && cE1 <= cmax) ? vE1[q] : 0.0;
-        }
+        const int ra = w + W * q, e = 1 + w + W * q, R = d0 + 1 + ra;
+        double* const dA = ra < NM ? LA + (KD + ra) * CA : LX;
+        double* const dD = e <= NM ? LDm + (e - 1) * CD : LX;
+        dA[lane] = (cA0 >= 1 && cA0 <= n - 1 - R) ? vA0[q] : 0.0;
+        LE[ra * CE + lane] = (cE0 >= 1 && cE0 <= n - 1 - R) ? vE0[q] : 0.0;
+        dD[lane] = (cD0 >= 1 && cD0 <= n - 1 - e) ? vD0[q] : 0.0;
     }
-    for (int k = threadIdx.x; k < (KD - 1) * CA; k += 64 * W) LA[k] = 0.0;
+#pragma unroll
+    for (int p2 = 0; p2 < NR / 2; p2++) {
+        const int rl = w + W * 2 * p2 + lhalf * W, R = d0 + 1 + rl;
+        double* const dA = rl < NM ? LA + (KD + rl) * CA : LX;
+        dA[64 + lsub] = (cA1 >= 1 && cA1 <= n - 1 - R) ? vA1[p2] : 0.0;
+        LE[rl * CE + 64 + lsub] = (cE1 >= 1 && cE1 <= n - 1 - R) ? vE1[p2] : 0.0;
+    }
+    {
+        double* const dD = (dsel < NR && eD <= NM) ? LDm + (eD - 1) * CD : LX;
+        dD[64 + dsub] = (cD1 >= 1 && cD1 <= n - 1 - eD) ? vD1 : 0.0;
+    }
+    for (int k = threadIdx.x; k < KD * CA; k += 64 * W) LA[k] = 0.0;
     for (int k = threadIdx.x; k < (P::RD - NM) * CD; k += 64 * W) LDm[NM * CD + k] = 0.0;
     RH_STAMP(0);
     __syncthreads();
@@ -685,12 +777,13 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_outside_strip(Mc
         const lds_vp vLD = (lds_vp)LDm;
         double va[KH], vb[KH], na[KH], nb[KH];
         auto issue = [&](int q, double* ra, double* rb) {
-            // FMo: FM1[e][i-e] * FM2o[d0-k+e][i-e]; that row sits in staged row (KD-1) + e-k-1 (rows < KD-1 are zero: the strip's own rows), column index lane-e+31
-            const int e = 1 + wt + TS * q, ee = e <= NM ? e : NM;
-            const lds_vp pa = vLA + (KD - 1 + ee - 1 - kb) * CA + lane - ee + 31;
+            // FMo: FM1[e][i-e] * FM2o[d0-k+e][i-e]; that row sits in staged row KD + e-k-1 (rows < KD are zero: the strip's own rows; slot
+            // e = 32 reads zero rows only), column index lane-e+31
+            const int e = 1 + wt + TS * q;
+            const lds_vp pa = vLA + ((e <= NM ? KD + e - 1 : KD - 1) - kb) * CA + lane - (e <= NM ? e : NM) + 31;
             // FM1o: FM2o[d0+x][i] * FM[x+k][i+d0-k]: staged row x+k-1 (rows e > 31 are zero), column index lane + (KD-1) - k
-            const int x = 1 + wt + TS * q, xx = x <= NM + 1 ? x : NM + 1;
-            const lds_vp pd = vLD + (xx - 1 + kb) * CD + lane + (KD - 1) - kb;
+            const int x = e;
+            const lds_vp pd = vLD + (x - 1 + kb) * CD + lane + (KD - 1) - kb;
 #pragma unroll
             for (int k = 0; k < KH; k++) { ra[k] = pa[-k * CA]; rb[k] = pd[k * (CD - 1)]; }
         };
@@ -710,7 +803,7 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_outside_strip(Mc
     RH_STAMP(2);
     double f1e[KD - 1];   // FM1[e][i-e], e = 1..KD-1: operands of the chain's own-row FMo terms
 #pragma unroll
-    for (int e = 1; e < KD; e++) f1e[e - 1] = (i - e >= 1 && i <= n - 1) ? fm1[(size_t)e * ld + clampc(i - e)] : 0.0;
+    for (int e = 1; e < KD; e++) { const double v = fm1[(unsigned)(e * ld + i - e)]; f1e[e - 1] = (i - e >= 1 && i <= n - 1) ? v : 0.0; }
     RH_STAMP(3);
     // enclosing single-branch loops: staged row rho is table row d0+1+rho = d+2+t with t = rho-1+k for diagonal d0-k; tap l1 reads column
     // i-1-l1 of it (index lane+31-l1).  Weights as in the inside strip: wT[l1][rho+k].
@@ -740,6 +833,9 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_outside_strip(Mc
             }
         }
     }
+    double cw[(KD - 1) * (KD - 2) / 2];   // single-branch weights of the chain's own-row taps (t <= KD-3), wave-uniform
+#pragma unroll
+    for (int k = 0; k < (KD - 1) * (KD - 2) / 2; k++) cw[k] = L->shape_w[k];
     // chain coefficients from the raw gathers (0 for a cell that is no pair: its FCo is 0)
     double p_cbd[NSL], p_cad[NSL], p_cst[NSL], p_ctja[NSL], p_tjbx[NSL], p_c01[NSL], p_c10[NSL], p_c11[NSL];
 #pragma unroll
@@ -779,29 +875,35 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_outside_strip(Mc
     // ---- chain (see the inside strip): time slot T: wavefront T % W finishes diagonal d0-T, the next wavefront gathers for d0-T-1
     const double w_mu = L->w_mu, w_mp2 = L->w_mp2, w_ep2 = L->w_ep2;
     double sms[NSL], s1s[NSL], gs[NSL];
-    auto pre = [&](auto KC) {
-        constexpr int K = decltype(KC)::value, SL = K / W;
-        double sm = p_far_m[SL], s1 = p_far_1[SL], g = 0.0;
+#pragma unroll
+    for (int sl = 0; sl < NSL; sl++) {
+        const int K = w + W * sl;
+        double sm = p_far_m[sl], s1 = p_far_1[sl], g = 0.0;
 #pragma unroll
         for (int q = 0; q < TS; q++) {
             sm += PART[((q * KD + K) * 3 + 0) * 64 + lane];
             s1 += PART[((q * KD + K) * 3 + 1) * 64 + lane];
             g += PART[((q * KD + K) * 3 + 2) * 64 + lane];
         }
+        sms[sl] = sm; s1s[sl] = s1; gs[sl] = g;
+    }
+    // (the posterior of diagonal K later reuses partial-sum row (0, K, 0): read above and written in fin<K> by the same wavefront)
+    // the terms of step K that touch the strip's own row R <= K-2 (e = K-R in both sums; filter: t = K-2-R)
+    auto addrow = [&](auto RC, auto KC) {
+        constexpr int R = decltype(RC)::value, K = decltype(KC)::value, SL = K / W, e = K - R, t = K - 2 - R;
+        double g0 = 0.0, g1 = 0.0;
+        sms[SL] = fma(f1e[e - 1], SFM2O[R * CS + PADL + lane - e], sms[SL]);                             // FM1[e][i-e] * FM2o[d0-R][i-e]
+        s1s[SL] = fma(SFM2O[R * CS + PADL + lane], LDm[(e - 1) * CD + lane + (KD - 1) - K], s1s[SL]);     // FM2o[d0-R][i] * FM[e][j]
 #pragma unroll
-        for (int kp = 0; kp + 2 <= K; kp++) {
-            const int e = K - kp;
-            sm = fma(f1e[e - 1], SFM2O[kp * CS + PADL + lane - e], sm);                               // FM1[e][i-e] * FM2o[d0-kp][i-e]
-            s1 = fma(SFM2O[kp * CS + PADL + lane], LDm[(e - 1) * CD + lane + (KD - 1) - K], s1);       // FM2o[d0-kp][i] * FM[e][j]
-            const int t = K - 2 - kp;
-#pragma unroll
-            for (int l1 = 0; l1 <= t; l1++) g = fma(L->shape_w[t * (t + 1) / 2 + l1], SFCOX[kp * CS + PADL + lane - 1 - l1], g);
+        for (int l1 = 0; l1 <= t; l1++) {
+            const double x = SFCOX[R * CS + PADL + lane - 1 - l1];
+            if (l1 & 1) g1 = fma(cw[t * (t + 1) / 2 + l1], x, g1); else g0 = fma(cw[t * (t + 1) / 2 + l1], x, g0);
         }
-        sms[SL] = sm; s1s[SL] = s1; gs[SL] = g;
+        gs[SL] += g0 + g1;
     };
     auto fin = [&](auto KC) {
         constexpr int K = decltype(KC)::value, SL = K / W;
-        const int d = d0 - K, j = i + d;
+        const int d = d0 - K;
         const bool v = i >= 1 && d >= 0 && i <= n - 1 - d;
         double sm = sms[SL], s1 = s1s[SL];
         const double g = gs[SL];
@@ -826,7 +928,7 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_outside_strip(Mc
         double fm2o = fmo + fco * p_ctja[SL];                                                  // ipp:3803, 4027
         if (!v) { fco = 0.0; fmo = 0.0; fm1o = 0.0; fm2o = 0.0; }
         // posterior of pair (i, j+1) = FCo * FCi / Z, clipped to [0,1]                 (ipp:4689-4827)
-        double p = fco * p_fc[SL] / o_z;
+        double p = fco * p_fc[SL] * r_z;
         if (v && lane >= KD - 1 && (!(p == p) || p > 1e300)) { atomicOr(&bad[sq], 1); p = 0.0; }
         p = p > 1.0 ? 1.0 : (p < 0.0 ? 0.0 : p);
         if (!(p == p)) p = 0.0;
@@ -835,14 +937,17 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_outside_strip(Mc
         PART[(K * 3) * 64 + lane] = p;   // row (term set 0, diagonal K): consumed by pre<K> before this point
     };
     RH_STAMP(6);
-    if (w == 0) pre(IC<0>{});
-#define RH_SLOT(T)                                                      \
-    if constexpr (T < KD) {                                             \
-        if (w == T % W) fin(IC<T>{});                                   \
-        if constexpr (T + 1 < KD) {                                     \
-            if (w == (T + 1) % W) pre(IC<(T + 1 < KD ? T + 1 : 0)>{}); \
-            lds_barrier();                                              \
-        }                                                               \
+    // time slot T: wavefront T % W finishes step T (fin: the two terms of row T-1 + the epilogue); every later step K > T, on
+    // its own wavefront, adds the terms of row T-1, which the previous slot completed
+#define RH_SLOT(T)                                                                                  \
+    if constexpr (T < KD) {                                                                         \
+        if (w == T % W) fin(IC<T>{});                                                               \
+        if constexpr (T >= 1 && T + 1 < KD)                                                         \
+            static_for<KD>([&](auto KC) {                                                           \
+                constexpr int K = decltype(KC)::value;                                              \
+                if constexpr (K > T) { if (w == K % W) addrow(IC<(T >= 1 ? T - 1 : 0)>{}, KC); }    \
+            });                                                                                     \
+        if constexpr (T + 1 < KD) lds_barrier();                                                    \
     }
     RH_SLOT(0) RH_SLOT(1) RH_SLOT(2) RH_SLOT(3) RH_SLOT(4) RH_SLOT(5) RH_SLOT(6) RH_SLOT(7)
 #undef RH_SLOT

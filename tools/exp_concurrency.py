@@ -22,5 +22,5 @@ def run(nctx, batch, n=500, steps=8):
     for c in ctxs: c.close()
     return nctx * batch * steps / dt
 
-for nctx, batch in ((1, 64), (2, 32), (2, 64), (4, 32), (4, 64), (1, 128), (1, 256)):
+for nctx, batch in ((1, 256), (2, 128), (4, 64), (2, 256), (1, 512), (3, 96)):
     print("contexts %d x %3d pairs: %8.1f pairs/s" % (nctx, batch, run(nctx, batch)), flush=True)
