@@ -2,10 +2,15 @@
 """bench.py -- sequence-pairs/s of the RactIP probability-matrix hot path on MI355X.
 
 Metric (BASELINE.json): sequence-pairs/sec incl. bp+hp+ap DP at n=500, with the
-achieved algorithmic HBM GB/s against the roofline.  One "step" = one pass of the
-hot path (2x McCaskill inside/outside/posterior + up + duplex fw/bk/posterior)
-over one batch of synthetic pairs (mt19937(12345) stream),
-inputs already resident in HBM when the timed region starts.
+achieved HBM GB/s against the roofline.  One "step" = one pass of the hot path
+(2x McCaskill inside/outside/posterior + up + duplex fw/bk/posterior) over one
+batch of synthetic pairs (mt19937(12345) stream).
+
+`value` is the SURVEY 8(d) quantity: host strings in -> thresholded matrices out.  A step is
+rh_batch_upload -> rh_batch_compute -> rh_batch_candidates_all x5 (the five threshold scans of
+src/ractip.cpp:557-647, compacted on the device, results on the host); steps alternate between two
+contexts on two host threads so that one context's PCIe legs overlap the other's kernels.  The
+device-resident rate (inputs in HBM, nothing copied back) is reported beside it.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--seqlen 500] [--batch B]
 
@@ -138,24 +143,98 @@ def cpu_baseline(pairs, budget_s=20.0):
                 done, len(pairs[0][0]), len(pairs[0][1]), dt)}
 
 
+SCANS = ((0, 0.5), (1, 0.5), (2, 0.1), (3, 0.003), (4, 0.003))   # which, threshold: src/cmdline.c defaults (bp1, bp2, hp, up1, up2)
+FP64_PEAK_TFLOPS = 78.6   # MI355X vector / matrix FP64 (spec)
+
+
+def source_hash():
+    """sha256 over the kernel sources: stamps profiles/pmc_traffic.json entries, so that counter traffic measured on other
+    kernels is never reported for these."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "ractip_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def timed_steps(ctxs, pairs, steps, body, fence):
+    """`steps` steps, step k on context k % len(ctxs), one host thread per context; wall time of all of them."""
+    import threading
+    err = []
+
+    def work(k0):
+        try:
+            for k in range(k0, steps, len(ctxs)):
+                body(ctxs[k0], pairs)
+        except Exception as e:   # noqa: BLE001 -- re-raised below
+            err.append(e)
+    fence()
+    t0 = time.perf_counter()
+    if len(ctxs) == 1:
+        work(0)
+    else:
+        th = [threading.Thread(target=work, args=(k,)) for k in range(len(ctxs))]
+        [t.start() for t in th]
+        [t.join() for t in th]
+    fence()
+    dt = time.perf_counter() - t0
+    if err:
+        raise err[0]
+    return dt
+
+
+def step_candidates(ctx, pairs):
+    ctx.batch_upload(pairs)
+    ctx.batch_compute()
+    for which, th in SCANS:
+        ctx.batch_candidates_all(which, th)
+
+
+def quick_rates(ractip_amd, torch, device_index, pairs, steps, model=0):
+    """device-resident and end-to-end (upload -> compute -> 5 scans on the host, two contexts) rates of one more workload"""
+    ctxs = [ractip_amd.Context(device=device_index, model=model) for _ in range(2)]
+    try:
+        for c in ctxs:
+            c.batch_upload(pairs)
+            c.batch_compute()
+        fence = torch.cuda.synchronize
+        dt_res = timed_steps(ctxs[:1], pairs, steps, lambda c, p: c.batch_compute(), fence)
+        ms, nl = ctxs[0].batch_timings()
+        dt_e2e = timed_steps(ctxs, pairs, 2 * steps, step_candidates, fence)
+        names = ctxs[0].batch_kernels()
+        return {"pairs_per_step": len(pairs), "steps": steps,
+                "device_resident_pairs_per_s": len(pairs) * steps / dt_res, "ms_per_step_device_resident": dt_res / steps * 1e3,
+                "value_pairs_per_s": len(pairs) * 2 * steps / dt_e2e,
+                "phase_ms": {"mccaskill_inside": ms[0], "mccaskill_outside": ms[1], "duplex": ms[2]},
+                "kernels": [k[0] for k in names], "path": ctxs[0].last_path()}
+    finally:
+        for c in ctxs:
+            c.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--seqlen", "--n", dest="n", type=int, default=500,
-                    help="sequence length (BASELINE config 3: 500; config 4: 2000); use --seqlen under torch.distributed.run")
+                    help="sequence length of the synthetic pairs (BASELINE config 3: 500, config 4: 2000)")
     ap.add_argument("--batch", type=int, default=0, help="pairs per GPU per step (0 = auto)")
     ap.add_argument("--workload", default="pairs", choices=["pairs", "zscore"],
-                    help="pairs: synthetic random pairs of --seqlen (the headline metric); zscore: the DP stage of BASELINE "
-                         "config 5 -- OxyS vs fhlA, --zscore=12 --seed=1, --batch dinucleotide shuffles per GPU per step")
+                    help="pairs: synthetic random pairs of one length; zscore: BASELINE config 5, the DP stage of the z-score loop "
+                         "(src/ractip.cpp:1638-1657): 1000 dinucleotide shuffles of OxyS/fhlA per step")
+    ap.add_argument("--total", type=int, default=0,
+                    help="zscore workload: FIXED total number of shuffles split over the ranks (strong scaling, BASELINE config 5 "
+                         "as stated: 1000); 0 = --batch shuffles per rank (weak scaling)")
     ap.add_argument("--model", default="contrafold", choices=["contrafold", "vienna"],
-                    help="contrafold: the pinned --contrafold path (headline); vienna: the default-CLI path with --duplex "
-                         "(pf_fold bp + pf_unstru up at width 15 + pf_duplex hp, BL* energies, parity unpinned)")
+                    help="contrafold: the in-tree engines (parity pinned); vienna: the default CLI path (Vienna-BL, parity unpinned)")
     ap.add_argument("--hp", default=None, choices=["duplex", "cofold"],
-                    help="--model vienna only: hybridization matrix from pf_duplex (the --duplex branch) or from the two-molecule "
-                         "ensemble co_pf_fold(s1+s2), RactIP's default (default: cofold)")
+                    help="vienna only: hp from pf_duplex (the --duplex branch) or from the two-molecule ensemble (default branch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the extra n=2000 / z-score measurements of the default run")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only for "
                     "rehearsing the multi-rank path on a one-GPU box, where all ranks share cuda:0)")
     args = ap.parse_args()
@@ -184,37 +263,53 @@ def main():
             dist.init_process_group(args.backend)
 
     n = args.n
+    scaling = "weak"
     if args.workload == "zscore":
         # bundled sequences of the reference (data/OxyS.fa, data/fhlA.fa), shuffled exactly as ractip.cpp:1636-1643 does
         from ractip_amd import shard as _shard
         fa = [l.strip() for l in open(os.path.join(ROOT, "ractip_amd", "data", "config5_OxyS_fhlA.fa")) if not l.startswith(">")]
         oxys, fhla = fa[0], fa[1]
-        batch = args.batch or 1000
         n = max(len(oxys), len(fhla))
-        all_pairs = _shard.zscore_shuffles(oxys, fhla, 12, batch * world, 1)
+        if args.total:   # BASELINE config 5 as stated: a fixed number of shuffles over the ranks, contiguous iteration blocks
+            scaling = "strong"
+            all_pairs = _shard.zscore_shuffles(oxys, fhla, 12, args.total, 1)
+            lo, hi = _shard.shard_bounds(args.total, rank, world)
+            pairs = all_pairs[lo:hi]
+            batch = hi - lo
+        else:
+            batch = args.batch or 1000
+            all_pairs = _shard.zscore_shuffles(oxys, fhla, 12, batch * world, 1)
+            pairs = all_pairs[rank * batch:(rank + 1) * batch]
     else:
-        # measured on MI355X (r01_n): n=500: 6218 pairs/s at 256 pairs/step, 5976 at 128, 5182 at 64, 5995 at 512;
-        # n=2000: 271 at 32, 202 at 16; Vienna-BL n=500: 1007 at 128, 960 at 64
+        # measured on MI355X (r02): n=500: 7389 pairs/s device-resident at 256 pairs/step; n=2000: 308 at 32
         batch = args.batch or (256 if n <= 600 else (64 if n <= 1200 else 32))
         if args.model == "vienna" and not args.batch:
             batch = max(1, batch // 2) if n <= 1200 else batch   # n=2000: 48 pairs/s at 32, 42 at 16 (125 GB of tables)
         # every rank draws from ONE stream and keeps its own slice: distinct pairs per rank (weak scaling)
         all_pairs = random_pairs(batch * world, n, seed=12345)
-    pairs = all_pairs[rank * batch:(rank + 1) * batch]
+        pairs = all_pairs[rank * batch:(rank + 1) * batch]
+    total_per_step = len(all_pairs)
 
     vienna = args.model == "vienna"
-    ctx = ractip_amd.Context(device=device_index, model=ractip_amd.hot.RH_MODEL_VIENNA_BL if vienna else ractip_amd.hot.RH_MODEL_CONTRAFOLD)
+    model_id = ractip_amd.hot.RH_MODEL_VIENNA_BL if vienna else ractip_amd.hot.RH_MODEL_CONTRAFOLD
     cofold = vienna and (args.hp or "cofold") == "cofold"
-    if vienna:
-        ctx.set_hybrid(cofold)
-    ctx.batch_upload(pairs)  # sequences -> HBM, tables allocated: outside the timed region
+    # two contexts on one GPU: their steps alternate, so uploads / result copies of one overlap the kernels of the other.
+    # Ranks of a multi-GPU run keep one context: the gather is a collective and stays on the main thread.
+    n_ctx = 2 if (world == 1 and n <= 1200) else 1
+    ctxs = [ractip_amd.Context(device=device_index, model=model_id) for _ in range(n_ctx)]
+    for c in ctxs:
+        if vienna:
+            c.set_hybrid(cofold)
+        c.batch_upload(pairs)   # tables allocated, launch graphs captured: outside the timed region
+        c.batch_compute()
+    ctx = ctxs[0]
 
     from ractip_amd import shard
 
-    def step():
-        ctx.batch_compute()  # all DP kernels, blocks until the device is done
-        if dist is not None:  # the shard's only exchange: per-pair scalars to every rank (ractip.cpp:1655-1663)
-            shard.gather_in_order(ctx.batch_logz(), batch * world, dist,
+    def step(c, p):
+        step_candidates(c, p)   # host strings -> HBM, all DP kernels, the five threshold scans back on the host
+        if dist is not None:    # the shard's only exchange: per-pair scalars to every rank (ractip.cpp:1655-1663)
+            shard.gather_in_order(c.batch_logz(), total_per_step, dist,
                                   device=torch.device("cuda", device_index) if args.backend == "nccl" else None)
 
     def fence():
@@ -222,21 +317,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    ms_acc = np.zeros(4)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        ms, nl = ctx.batch_timings()
-        ms_acc += np.array(ms)
-    fence()
-    dt = time.perf_counter() - t0
+    for k in range(args.warmup):
+        step(ctxs[k % n_ctx], pairs)
+    dt = timed_steps(ctxs, pairs, args.steps, step, fence)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+
+    # device-resident rate (inputs in HBM, nothing copied back): one context, the same number of steps
+    ms_acc = np.zeros(4)
+    nl = [0, 0, 0]
+
+    def resident(c, p):
+        nonlocal nl
+        c.batch_compute()
+        ms, nl = c.batch_timings()
+        ms_acc[:] += np.array(ms)
+    dt_res = timed_steps(ctxs[:1], pairs, args.steps, resident, fence)
 
     # isolated phase timings (outside the timed region): the duplex sweeps, the McCaskill inside sweep and the outside sweep
     # run one after the other, each bracketed by HIP events on its own stream, with nothing else on the device --
@@ -251,7 +349,7 @@ def main():
     kernel_names = ctx.batch_kernels()
 
     if rank == 0:
-        total_pairs = batch * world * args.steps
+        total_pairs = total_per_step * args.steps
         # algorithmic bytes of rank 0's batch, split by kernel (ractip_amd/balg.py)
         # (random-pair workload: counted exactly on the first pairs and scaled -- the pairs are i.i.d. sequences of one length;
         #  the z-score workload is counted in full)
@@ -275,19 +373,7 @@ def main():
                                             ("mccaskill_outside_phase", b["mc_outside"], ms_mean[1], nl[1]),
                                             ("duplex_phase", b["duplex"], ms_mean[2], nl[2])):
             phases[key] = {"alg_GB_per_step": bytes_ / 1e9, "ms_per_step": float(ms_k), "launches": int(launches),
-                           "avg_launch_us": float(ms_k) * 1e3 / max(1, launches),
-                           "achieved_GBs": bytes_ / 1e9 / (ms_k / 1e3) if ms_k > 0 else None}
-        # roofline of the dominant sweep: the phase with the largest isolated device time.  Its launches are the
-        # per-diagonal kernel plus (fast path) the block-product kernel that takes the far k-terms of the same sums;
-        # algorithmic bytes per launch = B_alg of the sweep / its launches, duration = isolated sweep time / its launches
-        bk = {"inside": 0, "inside_far": 0, "outside": 0, "outside_far": 0, "duplex": 0}
-        far_on = kernel_names[0][2] > 0
-        for s1, s2 in counted:
-            pk = balg.pair_bytes_by_kernel(s1, s2, bs=16 if far_on else 0)
-            for k in bk:
-                bk[k] += pk[k] * scale
-        if cofold:
-            bk["duplex"] = b["duplex"]
+                           "avg_launch_us": float(ms_k) * 1e3 / max(1, launches)}
         kernels = {}
         for idx, (pname, bytes_) in enumerate((("mccaskill_inside_phase", b["mc_inside"]), ("mccaskill_outside_phase", b["mc_outside"]),
                                                ("duplex_phase", b["duplex"]))):
@@ -295,22 +381,25 @@ def main():
             launches = int(nl[idx])
             if not fine or launches == 0 or iso_ms[idx] <= 0:
                 continue
-            avg_us = iso_ms[idx] * 1e3 / launches
             kernels[fine] = {"phase": pname, "launches_per_step": launches, "of_which_block_product": n_far,
                              "block_product_kernel": far or None, "isolated_ms_per_step": float(iso_ms[idx]),
-                             "avg_launch_us": avg_us, "alg_bytes_per_launch": bytes_ / launches,
-                             "achieved_GBs": bytes_ / 1e9 / (iso_ms[idx] / 1e3),
-                             "alg_GB_fine_vs_block_product": [bk[("inside", "outside", "duplex")[idx]] / 1e9,
-                                                              bk.get(("inside_far", "outside_far", "none")[idx], 0) / 1e9]}
+                             "avg_launch_us": iso_ms[idx] * 1e3 / launches, "alg_bytes_per_launch": bytes_ / launches,
+                             # one FMA per two operand loads of the reference recurrences: FLOP = algorithmic bytes / 8
+                             "fp64_TFLOPs": bytes_ / 8.0 / (iso_ms[idx] / 1e3) / 1e12}
         dom = max(kernels, key=lambda k: kernels[k]["isolated_ms_per_step"])
-        # HBM-side traffic per launch of that sweep: rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, gfx950 correction),
-        # collected separately (profiles/pmc_traffic.json, bytes per dispatch by kernel name); null if not profiled
-        traffic = None
+        kd = kernels[dom]
+        # HBM-side traffic of that sweep: rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, gfx950 correction), collected by
+        # tools/profile_gpu.sh -> tools/pmc_traffic_json.py into profiles/pmc_traffic.json (bytes per dispatch by kernel
+        # name), stamped with the hash of the kernel sources: an entry measured on other kernels is not reported (null)
+        traffic, traffic_note = None, None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("%s_n%d_b%d" % (args.model, n, batch), {})
-            kd = kernels[dom]
+            if tj.get("source_hash") != source_hash():
+                traffic_note = "profiles/pmc_traffic.json has no entry measured on these kernel sources" if tj else "not profiled"
+                tj = {}
+
             def per_dispatch(name):
-                hits = [v for k2, v in tj.items() if name and name.split("<")[0] in k2 and ("mfma" in name) == ("mfma" in k2)]
+                hits = [v for k2, v in tj.items() if name and isinstance(v, float) and name.split("(")[0] in k2]
                 return hits[0] if hits else None
             tf, tb = per_dispatch(dom), per_dispatch(kd["block_product_kernel"])
             if tb is not None and (kd["block_product_kernel"] or "").endswith("_pk"):
@@ -319,11 +408,17 @@ def main():
                 nfine = kd["launches_per_step"] - kd["of_which_block_product"]
                 traffic = (tf * nfine + (tb or 0.0) * kd["of_which_block_product"]) / kd["launches_per_step"]
         except (OSError, ValueError):
-            pass
-        ach = kernels[dom]["achieved_GBs"]
+            traffic_note = "profiles/pmc_traffic.json unreadable"
+        launch_s = kd["avg_launch_us"] * 1e-6
+        alg_GBs = kd["alg_bytes_per_launch"] / 1e9 / launch_s
+        # `achieved` is what the HBM interface delivered (counter bytes per launch / launch duration) whenever the counters
+        # are known for these kernels: a fraction that can fail.  The algorithmic figure (SURVEY 8d's B_alg per launch /
+        # duration) exceeds the peak as soon as operands are reused on chip and is kept as information only.
+        ach = traffic / 1e9 / launch_s if traffic else alg_GBs
+        comp_step = compulsory_bytes(pairs, vienna, cofold)
         line = {
-            "metric": ("sequence-pairs/sec (incl. bp+hp+ap DP) at n=%d" % n) if args.workload == "pairs"
-                      else "z-score DP stage: shuffled pairs/sec (OxyS/fhlA, bp+hp+ap DP per shuffle)",
+            "metric": ("sequence-pairs/sec (incl. bp+hp+ap DP; host strings in, thresholded matrices out) at n=%d" % n) if args.workload == "pairs"
+                      else "z-score DP stage: shuffled pairs/sec (OxyS/fhlA, bp+hp+ap DP per shuffle; host strings in, thresholded matrices out)",
             "value": total_pairs / dt,
             "unit": "pairs/s",
             "n_gpus": world,
@@ -331,46 +426,71 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
+            "device_resident_pairs_per_s": len(pairs) * args.steps / dt_res,
+            "device_resident_ms_per_step": dt_res / args.steps * 1e3,
             "config": {"workload": ("synthetic random pairs n=%d/%d, std::mt19937(12345) stream (BASELINE config %s)"
                                     % (n, n, "3" if n == 500 else ("4" if n == 2000 else "-"))) if args.workload == "pairs"
                                    else "OxyS.fa (109) vs fhlA.fa (113), --zscore=12 --seed=1 dinucleotide shuffles (BASELINE config 5, DP stage)",
-                       "pairs_per_gpu_per_step": batch, "model": None,
+                       "pairs_per_gpu_per_step": batch, "total_pairs_per_step": total_per_step, "model": None,
+                       "step": "rh_batch_upload -> rh_batch_compute -> rh_batch_candidates_all x5 (thresholds 0.5/0.5/0.1/0.003/0.003)"
+                               + (", steps alternate between %d contexts / host threads" % n_ctx if n_ctx > 1 else "")
+                               + (", + all_gather of 3 doubles per pair" if world > 1 else ""),
                        "scoring": ("Vienna-BL (BL* tables, ViennaRNA-1.8 semantics, up width 15, hp from %s; parity unpinned)"
                                    % ("co_pf_fold(s1+s2)" if cofold else "pf_duplex")) if vienna
                                   else "CONTRAfold complementary (708 weights)"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "achieved_basis": "pmc counters (FETCH_SIZE x2 + WRITE_SIZE) per launch / HIP-event launch duration" if traffic
+                                           else "algorithmic bytes (no counter profile of these kernel sources): NOT a bound, may exceed 1",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
+                         "traffic_frac": (traffic / 1e9 / launch_s / HBM_PEAK_GBS) if traffic else None,
+                         "traffic_over_compulsory": (traffic * kd["launches_per_step"] / comp_step) if traffic else None,
+                         "alg_over_peak": alg_GBs / HBM_PEAK_GBS, "alg_GBs": alg_GBs,
+                         "fp64_frac": kd["fp64_TFLOPs"] / FP64_PEAK_TFLOPS,
                          "peak_copy_measured": copy_bandwidth_GBs(torch) if world == 1 else None,
-                         "frac": ach / HBM_PEAK_GBS if ach else None, "traffic": traffic,
-                         "alg_bytes_per_launch": kernels[dom]["alg_bytes_per_launch"],
-                         "avg_launch_us": kernels[dom]["avg_launch_us"],
+                         "alg_bytes_per_launch": kd["alg_bytes_per_launch"],
+                         "avg_launch_us": kd["avg_launch_us"],
                          "timing": "HIP events around the whole sweep on its own stream, sweeps run one after the other "
-                                   "(3 passes after the timed region); 'phases' below = the same events inside the timed region, "
+                                   "(3 passes after the timed region); 'phases' below = the same events inside the device-resident loop, "
                                    "where the duplex stream overlaps the McCaskill stream",
                          "kernels": kernels,
-                         "whole_path": {"alg_GB_per_pair": b["total"] / 1e9 / batch,
+                         "whole_path": {"alg_GB_per_pair": b["total"] / 1e9 / max(1, len(pairs)),
                                         # every DP table written once and read once (SURVEY 8d's "compulsory bytes")
-                                        "compulsory_GB_per_pair": compulsory_bytes(pairs, vienna, cofold) / 1e9 / batch,
-                                        "achieved_GBs": b["total"] / 1e9 / (ms_mean[3] / 1e3),
-                                        "frac": b["total"] / 1e9 / (ms_mean[3] / 1e3) / HBM_PEAK_GBS},
+                                        "compulsory_GB_per_pair": comp_step / 1e9 / max(1, len(pairs))},
                          "phases": phases},
         }
         if world == 1:
-            # PCIe-inclusive rates (never `value`): host strings in -> results on the host, for the record in DESIGN.md
-            t1 = time.perf_counter()
-            for _ in range(2):
-                ctx.batch_upload(pairs); ctx.batch_compute(); ctx.batch_results_all()
-            dense = 2 * batch / (time.perf_counter() - t1)
-            t1 = time.perf_counter()
-            for _ in range(2):
-                ctx.batch_upload(pairs); ctx.batch_compute()
-                for which, th in ((0, 0.5), (1, 0.5), (2, 0.1), (3, 0.003), (4, 0.003)):   # cmdline.c default thresholds
-                    ctx.batch_candidates_all(which, th)
-            sparse = 2 * batch / (time.perf_counter() - t1)
-            line["pcie_inclusive"] = {"dense_results_pairs_per_s": dense, "threshold_candidates_pairs_per_s": sparse}
+            # dense results instead of the thresholded lists: all five matrices into page-locked host buffers, two contexts
+            bufs = {}
+
+            def step_dense(c, p):
+                c.batch_upload(p)
+                c.batch_compute()
+                bufs[id(c)] = c.batch_results_all_into(bufs.get(id(c)))
+            for c in ctxs:
+                step_dense(c, pairs)
+            k_dense = max(2, min(args.steps, 6))
+            dt_dense = timed_steps(ctxs, pairs, k_dense, step_dense, fence)
+            line["pcie_inclusive"] = {"threshold_candidates_pairs_per_s": line["value"],
+                                      "dense_results_pairs_per_s": len(pairs) * k_dense / dt_dense,
+                                      "dense_GB_per_step": sum(a.nbytes for a in bufs[id(ctx)]) / 1e9}
+        for c in ctxs:
+            c.close()
+        ctxs = []
+        if world == 1 and not args.no_also and args.workload == "pairs" and n == 500 and not vienna:
+            # the other BASELINE configurations, bounded to a few seconds each: config 4 (n = 2000) and config 5 (z-score DP stage)
+            also = {}
+            try:
+                also["n2000"] = quick_rates(ractip_amd, torch, device_index, random_pairs(32, 2000, seed=12345), 3)
+                from ractip_amd import shard as _shard
+                fa = [l.strip() for l in open(os.path.join(ROOT, "ractip_amd", "data", "config5_OxyS_fhlA.fa")) if not l.startswith(">")]
+                also["zscore_1000_shuffles"] = quick_rates(ractip_amd, torch, device_index, _shard.zscore_shuffles(fa[0], fa[1], 12, 1000, 1), 10)
+            except Exception as e:   # noqa: BLE001 -- the headline line must still be printed
+                also["error"] = repr(e)
+            line["also"] = also
         if world == 1 and not args.no_cpu_baseline:
             if vienna:
                 line["cpu_baseline"] = cpu_baseline_vienna(all_pairs, budget_s=12.0 if n <= 600 else 1.0, cofold=cofold)
@@ -384,7 +504,8 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
+    for c in ctxs:
+        c.close()
 
 
 if __name__ == "__main__":

@@ -162,6 +162,13 @@ int rh_batch_candidates_all(rh_ctx* ctx, int which, float threshold, rh_cand* ou
 int rh_batch_layout(rh_ctx* ctx, size_t* tri_stride, int* up_ld, size_t* hp_stride, int* hp_ld);
 int rh_batch_results_all(rh_ctx* ctx, double* bp, double* up, double* hp, double* logz);
 
+/* Page-locked host memory for result buffers (hipHostMalloc): device-to-host copies into it run at the full DMA rate and,
+ * issued from two contexts, overlap the other context's kernels (the reference's result containers are plain std::vector,
+ * src/ractip.cpp:82-83; a host that wants the dense matrices at PCIe speed hands these buffers to rh_batch_results_all).
+ * rh_host_alloc returns NULL on failure; any context's device is fine. */
+void* rh_host_alloc(rh_ctx* ctx, size_t bytes);
+void rh_host_free(rh_ctx* ctx, void* p);
+
 /* Device time (ms, HIP events on the context's streams) spent by the last
  * rh_batch_compute in: [0] McCaskill inside sweep, [1] McCaskill outside sweep
  * (+posterior), [2] duplex sweeps, [3] whole compute.  Launch counts in n_launch[0..2]. */
@@ -177,6 +184,13 @@ int rh_batch_kernels(rh_ctx* ctx, const char* fine[3], const char* far[3], int n
  * rh_batch_timings returns each phase's device time with nothing else on the GPU (what a kernel trace reports per
  * kernel).  Results are unchanged.  Default: overlap on. */
 int rh_set_overlap(rh_ctx* ctx, int on);
+
+/* Which problems of the last rh_batch_compute left the double range on the scaled linear path and were recomputed by the
+ * log-space kernels (rh_last_path / rh_last_hybrid_path == 3): which = 0: sequence indices (2p = s1 of pair p), 1: pair
+ * indices of the duplex.  Only those problems are recomputed; every other problem keeps its linear-path result.  Writes at
+ * most `cap` indices, returns how many there are.  (The reference's log-space arithmetic, LogSpace.hpp:232-244, never
+ * leaves its range; this is how the fast path keeps that guarantee.) */
+int rh_batch_fallbacks(rh_ctx* ctx, int which, int* out, int cap);
 
 /* Device pointers of the last batch (for callers that keep results on the GPU):
  * bp tables [2*npairs][tri_stride] (sequence 2p = s1 of pair p, 2p+1 = s2),

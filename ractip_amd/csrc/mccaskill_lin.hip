@@ -327,10 +327,10 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) RH_WPE_IN void lin_inside_
                 for (int u = 0; u < UF; u++) {
                     const int mm = m + u * W, k = i + mm;
                     const bool ok = valid && mm <= hi && (k < kA || k >= kB);
-                    acc2 = fma(ok ? a[u] : 0.0, b[u], acc2);
+                    acc2 = fma(ok ? a[u] : 0.0, ok ? b[u] : 0.0, acc2);   // both operands: a masked term reads a clamped address, and 0 x (a stale Inf) is NaN
                     if (LA) {
                         const bool ok1 = valid1 && mm <= hi && mm >= 2 && (k < kA1 || k >= kB1);
-                        acc2n = fma(ok1 ? a[u] : 0.0, bn[u], acc2n);
+                        acc2n = fma(ok1 ? a[u] : 0.0, ok1 ? bn[u] : 0.0, acc2n);
                     }
                 }
             }

@@ -131,17 +131,15 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_inside_strip(McB
 #pragma unroll 1
         for (int jj = f5_lo; jj <= d0 + 1; jj++) {
             if (jj < 1 || jj > n) continue;
+            // fixed partition of the sum (256 threads, 4 partial sums) whatever W is: the bits of F5i do not depend on which
+            // kernel -- bootstrap, strip or tail -- computes an entry, i.e. not on the other sequences of the batch
             double acc = 0.0;
-            for (int k = threadIdx.x; k <= jj - 2; k += 64 * W) acc = fma(f5i[k], fca[(size_t)(jj - 2 - k) * ld + (k + 1)], acc);
+            if (threadIdx.x < 256)
+                for (int k = threadIdx.x; k <= jj - 2; k += 256) acc = fma(f5i[k], fca[(size_t)(jj - 2 - k) * ld + (k + 1)], acc);
             acc = wsum_s(acc);
             if (lane == 0) red[w] = acc;
             __syncthreads();
-            if (threadIdx.x == 0) {
-                double t = 0.0;
-#pragma unroll
-                for (int k = 0; k < W; k++) t += red[k];
-                f5i[jj] = f5i[jj - 1] * L->w_eu + t * L->w_ep2;
-            }
+            if (threadIdx.x == 0) f5i[jj] = f5i[jj - 1] * L->w_eu + (red[0] + red[1] + red[2] + red[3]) * L->w_ep2;
             __syncthreads();   // F5i[jj] is an operand of F5i[jj+1]
         }
         return;
@@ -548,17 +546,13 @@ __device__ __forceinline__ void f5o_range(const double* __restrict__ fca_tab, do
     for (int k = khi; k >= klo && k >= 1; k--) {
         if (k > n - 1) continue;
         const double* __restrict__ fca = fca_tab + (k + 1);
-        double acc = 0.0;
-        for (int jj = k + 2 + threadIdx.x; jj <= n; jj += 64 * W) acc = fma(f5o[jj], fca[(size_t)(jj - 2 - k) * ld], acc);
+        double acc = 0.0;   // fixed partition (256 threads, 4 partial sums) whatever W is: see the inside strip
+        if (threadIdx.x < 256)
+            for (int jj = k + 2 + threadIdx.x; jj <= n; jj += 256) acc = fma(f5o[jj], fca[(size_t)(jj - 2 - k) * ld], acc);
         acc = wsum_s(acc);
         if (lane == 0) red[w] = acc;
         __syncthreads();
-        if (threadIdx.x == 0) {
-            double t = 0.0;
-#pragma unroll
-            for (int q = 0; q < W; q++) t += red[q];
-            f5o[k] = f5o[k + 1] * L->w_eu + t * L->w_ep2;
-        }
+        if (threadIdx.x == 0) f5o[k] = f5o[k + 1] * L->w_eu + (red[0] + red[1] + red[2] + red[3]) * L->w_ep2;
         __syncthreads();   // F5o[k] is an operand of F5o[k-1]
     }
 }

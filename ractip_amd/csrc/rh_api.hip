@@ -306,6 +306,17 @@ struct rh_ctx {
     void* d_zpart = nullptr; size_t cap_zpart = 0;   // per-chunk partial sums of Z~ (+ pairable-cell counts behind them)
     int lz_chunks = 0;
     void* d_cand = nullptr;  size_t cap_cand = 0;
+    // compacted sub-batches of the per-problem log-space fallback
+    void* d_subseq = nullptr; size_t cap_subseq = 0;
+    void* d_subn = nullptr; size_t cap_subn = 0;
+    void* d_subbp = nullptr; size_t cap_subbp = 0;
+    void* d_subup = nullptr; size_t cap_subup = 0;
+    void* d_subdseq = nullptr; size_t cap_subdseq = 0;
+    void* d_subdn = nullptr; size_t cap_subdn = 0;
+    void* d_subdx = nullptr; size_t cap_subdx = 0;
+    bool tables_dirty = false;      // the last compute met values outside the double range: clear the tables before the next batch
+    std::vector<uint8_t> h_codes;   // host mirror of d_seq
+    std::vector<int> fallback_mc, fallback_dx;   // problems the last compute recomputed in log space (rh_batch_fallbacks)
     void* d_gaps = nullptr;  size_t cap_gaps = 0;
     void* d_allow = nullptr; size_t cap_allow = 0;   // structure-constraint masks [ns][ld*ld] bytes (Vienna-BL, optional)
     void* d_coallow = nullptr; size_t cap_coallow = 0;   // the same for the s1+s2 batch
@@ -465,6 +476,7 @@ int stage(rh_ctx* c, int ns, const char* const* seqs, const int* lens, bool with
     int rc;
     if ((rc = ensure(c, &c->d_seq, &c->cap_seq, codes.size(), false))) return rc;
     if ((rc = ensure(c, &c->d_n, &c->cap_n, sizeof(int) * ns, false))) return rc;
+    c->h_codes = codes;
     HIP_TRY(c, hipMemcpyAsync(c->d_seq, codes.data(), codes.size(), hipMemcpyHostToDevice, c->s_mc));
     HIP_TRY(c, hipMemcpyAsync(c->d_n, lens, sizeof(int) * ns, hipMemcpyHostToDevice, c->s_mc));
     HIP_TRY(c, hipStreamSynchronize(c->s_mc));  // host staging buffers die with this scope
@@ -511,6 +523,15 @@ int stage(rh_ctx* c, int ns, const char* const* seqs, const int* lens, bool with
             if ((rc = ensure(c, &c->d_allow, &c->cap_allow, M.size(), false))) return rc;
             HIP_TRY(c, hipMemcpy(c->d_allow, M.data(), M.size(), hipMemcpyHostToDevice));
             B.allow = (const uint8_t*)c->d_allow;
+        }
+        if (c->tables_dirty) {
+            // a problem of the previous batch overflowed: its tables hold Inf / NaN, which a later batch must never meet even in
+            // cells it masks (0 x Inf).  One clear per such batch; ordinary batches reuse the tables as they are.
+            HIP_TRY(c, hipMemsetAsync(c->d_mctab, 0, c->cap_mctab, c->s_mc));
+            if (c->d_pk) HIP_TRY(c, hipMemsetAsync(c->d_pk, 0, c->cap_pk, c->s_mc));
+            if (c->d_cotab) HIP_TRY(c, hipMemsetAsync(c->d_cotab, 0, c->cap_cotab, c->s_mc));
+            if (c->d_copk) HIP_TRY(c, hipMemsetAsync(c->d_copk, 0, c->cap_copk, c->s_mc));
+            c->tables_dirty = false;
         }
         B.seq = (const uint8_t*)c->d_seq; B.n = (const int*)c->d_n;
         B.tab = (double*)c->d_mctab;
@@ -614,9 +635,8 @@ int stage(rh_ctx* c, int ns, const char* const* seqs, const int* lens, bool with
 }
 
 // ---- McCaskill sweeps, log-space path (always valid)
-int launch_mc_log(rh_ctx* c, int pin)
+int launch_mc_log(rh_ctx* c, int pin, const McBatch& B, double* logz_out)
 {
-    const McBatch& B = c->mc;
     hipLaunchKernelGGL(mc_init, dim3((B.ns + 63) / 64), dim3(64), 0, c->s_mc, B);
     for (int d = 0; d <= B.nmax - 1; d++) {
         const int waves = std::max(B.nmax - 1 - d, 0) + 1;
@@ -629,10 +649,11 @@ int launch_mc_log(rh_ctx* c, int pin)
         KLAUNCH(c, 2, mc_outside_diag, pin ? dim3(B.ns, (waves + 3) / 4) : dim3((waves + 3) / 4, B.ns), dim3(256), c->s_mc, B, c->d_model, d, pin);
         c->n_launch[1]++;
     }
-    hipLaunchKernelGGL(log_finish, dim3((B.ns + 63) / 64), dim3(64), 0, c->s_mc, B, (double*)c->d_mclogz);
+    hipLaunchKernelGGL(log_finish, dim3((B.ns + 63) / 64), dim3(64), 0, c->s_mc, B, logz_out);
     hipLaunchKernelGGL(mc_unpaired, dim3((B.nmax + 3) / 4, B.ns), dim3(256), 0, c->s_mc, B);
     return RH_OK;
 }
+int launch_mc_log(rh_ctx* c, int pin) { return launch_mc_log(c, pin, c->mc, (double*)c->d_mclogz); }
 
 // ---- McCaskill sweeps + accessibility, Vienna-BL model (log space; mccaskill_vienna.hip)
 int launch_mc_vienna(rh_ctx* c, int pin)
@@ -1014,10 +1035,11 @@ int run_graphed(rh_ctx* c, GraphSlot& g, size_t key, hipStream_t stream, int* la
         HIP_TRY(c, hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
         const int rc = launch();
         hipError_t e = hipStreamEndCapture(stream, &graph);
-        if (rc) return rc;
-        if (e != hipSuccess) return fail(c, RH_ERR_HIP, "graph capture failed: %s", hipGetErrorString(e));
-        HIP_TRY(c, hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0));
-        HIP_TRY(c, hipGraphDestroy(graph));
+        if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }   // (the captured graph is not leaked on the error paths)
+        if (e != hipSuccess) { if (graph) (void)hipGraphDestroy(graph); return fail(c, RH_ERR_HIP, "graph capture failed: %s", hipGetErrorString(e)); }
+        e = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) { g.exec = nullptr; return fail(c, RH_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e)); }
         g.key = key;
         g.launches = *launch_counter - before;
         g.far = *far_counter - far_before;
@@ -1031,9 +1053,8 @@ int run_graphed(rh_ctx* c, GraphSlot& g, size_t key, hipStream_t stream, int* la
 }
 
 // ---- duplex sweeps, log-space path
-int launch_dx_log(rh_ctx* c)
+int launch_dx_log(rh_ctx* c, const DxBatch& D)
 {
-    const DxBatch& D = c->dx;
     const int smax = D.n1max + D.n2max;
     const int steps = smax / 2;
     const int waves = 2 * std::min(D.n1max, D.n2max);
@@ -1044,6 +1065,86 @@ int launch_dx_log(rh_ctx* c)
     hipLaunchKernelGGL(dx_logz, dim3(D.np), dim3(1024), 0, c->s_dx, D, c->d_model);
     const int cells = D.n1max * D.n2max;
     hipLaunchKernelGGL(dx_posterior, dim3((cells + 255) / 256, D.np), dim3(256), 0, c->s_dx, D);
+    return RH_OK;
+}
+int launch_dx_log(rh_ctx* c) { return launch_dx_log(c, c->dx); }
+
+// ---- per-problem fallback (CONTRAfold model): only the sequences / pairs whose scaled values left the double range are
+// recomputed by the log-space kernels, as a compacted sub-batch; everyone else keeps the linear-path result, bit for bit.
+// (The reference has no such cliff at all: its log-space arithmetic, LogSpace.hpp:232-244, is always valid.)
+int recompute_mc_subset_log(rh_ctx* c, const std::vector<int>& F)
+{
+    const McBatch& B = c->mc;
+    const int nsub = (int)F.size();
+    std::vector<uint8_t> codes((size_t)nsub * B.lds);
+    std::vector<int> lens(nsub);
+    int nmax = 0;
+    for (int k = 0; k < nsub; k++) {
+        std::memcpy(codes.data() + (size_t)k * B.lds, c->h_codes.data() + (size_t)F[k] * B.lds, B.lds);
+        lens[k] = c->n[F[k]];
+        nmax = std::max(nmax, lens[k]);
+    }
+    int rc;
+    const size_t up_per = (size_t)B.ld * c->max_w;
+    if ((rc = ensure(c, &c->d_subseq, &c->cap_subseq, codes.size(), false))) return rc;
+    if ((rc = ensure(c, &c->d_subn, &c->cap_subn, sizeof(int) * nsub, false))) return rc;
+    if ((rc = ensure(c, &c->d_subbp, &c->cap_subbp, sizeof(double) * B.tri_stride * nsub, false))) return rc;
+    if ((rc = ensure(c, &c->d_subup, &c->cap_subup, sizeof(double) * (up_per + 1) * nsub, false))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->d_subseq, codes.data(), codes.size(), hipMemcpyHostToDevice, c->s_mc));
+    HIP_TRY(c, hipMemcpyAsync(c->d_subn, lens.data(), sizeof(int) * nsub, hipMemcpyHostToDevice, c->s_mc));
+    HIP_TRY(c, hipMemsetAsync(c->d_subbp, 0, sizeof(double) * B.tri_stride * nsub, c->s_mc));
+    HIP_TRY(c, hipStreamSynchronize(c->s_mc));   // the host staging vectors die with this scope
+    McBatch S = B;                 // same ld / strides: the tables of the linear pass are dead and are reused
+    S.ns = nsub; S.nmax = nmax;
+    S.seq = (const uint8_t*)c->d_subseq; S.n = (const int*)c->d_subn;
+    S.f5i = (double*)c->d_f5; S.f5o = (double*)c->d_f5 + (size_t)B.ld * nsub;
+    S.bp = (double*)c->d_subbp; S.up = (double*)c->d_subup;
+    double* sub_logz = (double*)c->d_subup + up_per * nsub;
+    if ((rc = launch_mc_log(c, nsub % 8 == 0 ? 1 : 0, S, sub_logz))) return rc;
+    for (int k = 0; k < nsub; k++) {   // scatter to the flagged sequences' slots
+        HIP_TRY(c, hipMemcpyAsync((double*)c->d_bp + (size_t)F[k] * B.tri_stride, (double*)c->d_subbp + (size_t)k * B.tri_stride,
+                                  sizeof(double) * B.tri_stride, hipMemcpyDeviceToDevice, c->s_mc));
+        HIP_TRY(c, hipMemcpyAsync((double*)c->d_up + (size_t)F[k] * up_per, (double*)c->d_subup + (size_t)k * up_per, sizeof(double) * up_per,
+                                  hipMemcpyDeviceToDevice, c->s_mc));
+        HIP_TRY(c, hipMemcpyAsync((double*)c->d_mclogz + F[k], sub_logz + k, sizeof(double), hipMemcpyDeviceToDevice, c->s_mc));
+    }
+    return RH_OK;
+}
+
+int recompute_dx_subset_log(rh_ctx* c, const std::vector<int>& F)
+{
+    const DxBatch& D = c->dx;
+    const int nsub = (int)F.size();
+    std::vector<uint8_t> codes((size_t)2 * nsub * D.lds);
+    std::vector<int> lens(2 * (size_t)nsub);
+    int n1max = 0, n2max = 0;
+    for (int k = 0; k < nsub; k++)
+        for (int h = 0; h < 2; h++) {
+            std::memcpy(codes.data() + (size_t)(2 * k + h) * D.lds, c->h_codes.data() + (size_t)(2 * F[k] + h) * D.lds, D.lds);
+            lens[2 * k + h] = c->n[2 * F[k] + h];
+            (h ? n2max : n1max) = std::max(h ? n2max : n1max, lens[2 * k + h]);
+        }
+    int rc;
+    if ((rc = ensure(c, &c->d_subdseq, &c->cap_subdseq, codes.size(), false))) return rc;
+    if ((rc = ensure(c, &c->d_subdn, &c->cap_subdn, sizeof(int) * lens.size(), false))) return rc;
+    // own tables: the linear duplex image keeps zero pad columns between runs, which the log-space layout would overwrite
+    if ((rc = ensure(c, &c->d_subdx, &c->cap_subdx, sizeof(double) * (D.pair_stride + D.tab_stride + 1) * nsub, false))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->d_subdseq, codes.data(), codes.size(), hipMemcpyHostToDevice, c->s_dx));
+    HIP_TRY(c, hipMemcpyAsync(c->d_subdn, lens.data(), sizeof(int) * lens.size(), hipMemcpyHostToDevice, c->s_dx));
+    double* sub_hp = (double*)c->d_subdx + D.pair_stride * nsub;
+    double* sub_logz = sub_hp + D.tab_stride * nsub;
+    HIP_TRY(c, hipMemsetAsync(sub_hp, 0, sizeof(double) * D.tab_stride * nsub, c->s_dx));   // row 0 / column 0 stay zero
+    HIP_TRY(c, hipStreamSynchronize(c->s_dx));
+    DxBatch S = D;
+    S.np = nsub; S.n1max = n1max; S.n2max = n2max;
+    S.seq = (const uint8_t*)c->d_subdseq; S.n = (const int*)c->d_subdn;
+    S.tab = (double*)c->d_subdx; S.hp = sub_hp; S.logz = sub_logz;
+    if ((rc = launch_dx_log(c, S))) return rc;
+    for (int k = 0; k < nsub; k++) {
+        HIP_TRY(c, hipMemcpyAsync((double*)c->d_hp + (size_t)F[k] * D.tab_stride, sub_hp + (size_t)k * D.tab_stride, sizeof(double) * D.tab_stride,
+                                  hipMemcpyDeviceToDevice, c->s_dx));
+        HIP_TRY(c, hipMemcpyAsync((double*)c->d_logz + F[k], sub_logz + k, sizeof(double), hipMemcpyDeviceToDevice, c->s_dx));
+    }
     return RH_OK;
 }
 
@@ -1156,6 +1257,7 @@ int compute(rh_ctx* c)
     c->n_launch[0] = c->n_launch[1] = c->n_launch[2] = 0;
     c->n_far[0] = c->n_far[1] = c->n_far[2] = 0;
     c->last_path = 0;
+    c->fallback_mc.clear(); c->fallback_dx.clear();
     // sequence -> XCD affinity only when the batch spreads evenly over the 8 XCDs (speed only)
     const int pin = (c->has_mc && c->mc.ns % 8 == 0) ? 1 : 0;
     int rc;
@@ -1216,7 +1318,7 @@ int compute(rh_ctx* c)
                 HIP_TRY(c, hipMemcpyAsync(bad.data(), c->d_bad, sizeof(int) * c->mc.ns, hipMemcpyDeviceToHost, c->s_mc));
                 HIP_TRY(c, hipStreamSynchronize(c->s_mc));
                 for (int b : bad) log_path |= (b != 0);
-                if (log_path) c->last_path = 3;
+                if (log_path) { c->last_path = 3; c->tables_dirty = true; }
             }
         }
         if (log_path) {
@@ -1236,8 +1338,13 @@ int compute(rh_ctx* c)
             std::vector<int> bad(c->mc.ns);
             HIP_TRY(c, hipMemcpyAsync(bad.data(), c->d_bad, sizeof(int) * c->mc.ns, hipMemcpyDeviceToHost, c->s_mc));
             HIP_TRY(c, hipStreamSynchronize(c->s_mc));
-            for (int b : bad) need_log |= (b != 0);
-            if (need_log) c->last_path = 3;
+            for (int k = 0; k < c->mc.ns; k++) if (bad[k]) c->fallback_mc.push_back(k);
+            if (!c->fallback_mc.empty()) {
+                c->last_path = 3;
+                c->tables_dirty = true;
+                if (2 * c->fallback_mc.size() > (size_t)c->mc.ns) need_log = true;   // most of the batch: redo it whole
+                else if ((rc = recompute_mc_subset_log(c, c->fallback_mc))) return rc;
+            }
         }
     } else {
         HIP_TRY(c, hipEventRecord(c->ev[1], c->s_mc));
@@ -1258,6 +1365,7 @@ int compute(rh_ctx* c)
         bool redo = false;
         for (int b : bad) redo |= (b != 0);
         if (redo) {   // some pair left the double range: recompute the two-molecule sweeps in log space
+            c->tables_dirty = true;
             c->n_launch[2] = 0; c->n_far[2] = 0;
             HIP_TRY(c, hipEventRecord(c->ev[3], c->s_dx));
             HIP_TRY(c, hipMemsetAsync(c->d_cobp, 0, sizeof(double) * c->co.tri_stride * c->co.ns, c->s_dx));
@@ -1273,8 +1381,13 @@ int compute(rh_ctx* c)
             HIP_TRY(c, hipMemcpyAsync(bad.data(), c->d_dxbad, sizeof(int) * c->dx.np, hipMemcpyDeviceToHost, c->s_dx));
             HIP_TRY(c, hipStreamSynchronize(c->s_dx));
             bool redo = false;
-            for (int b : bad) redo |= (b != 0);
-            if (redo) {  // some pair left the double range: recompute the batch with the log-space kernels
+            for (int k = 0; k < c->dx.np; k++) if (bad[k]) { redo = true; c->fallback_dx.push_back(k); }
+            if (redo && c->model != RH_MODEL_VIENNA_BL && 2 * c->fallback_dx.size() <= (size_t)c->dx.np) {
+                // only the flagged pairs, as a compacted sub-batch with its own tables
+                if ((rc = recompute_dx_subset_log(c, c->fallback_dx))) return rc;
+                HIP_TRY(c, hipEventRecord(c->ev[4], c->s_dx));
+                c->last_dx_path = 3;
+            } else if (redo) {  // most pairs (or the Vienna-BL model): recompute the batch with the log-space kernels
                 c->n_launch[2] = 0;
                 HIP_TRY(c, hipEventRecord(c->ev[3], c->s_dx));
                 if ((rc = (c->model == RH_MODEL_VIENNA_BL ? launch_dx_vlog(c) : launch_dx_log(c)))) return rc;
@@ -1435,7 +1548,7 @@ void rh_destroy(rh_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    void* bufs[] = {c->d_seq, c->d_n, c->d_mctab, c->d_f5, c->d_bp, c->d_up, c->d_dxtab, c->d_hp, c->d_logz, c->d_scal, c->d_mclogz, c->d_bad, c->d_cnt, c->d_cand, c->d_dxbad, c->d_zbar, c->d_zpart, c->d_gaps, c->d_coseq, c->d_con, c->d_cotab, c->d_pk, c->d_copk, c->d_rowp, c->d_corowp, c->d_cof5, c->d_cobp, c->d_cobad, c->d_allow, c->d_coallow, c->d_vlin, c->d_vdxl, c->d_vdx, c->d_hplen, c->d_model, c->d_lin, c->d_dxlin, c->d_vienna, c->d_wT};
+    void* bufs[] = {c->d_seq, c->d_n, c->d_mctab, c->d_f5, c->d_bp, c->d_up, c->d_dxtab, c->d_hp, c->d_logz, c->d_scal, c->d_mclogz, c->d_bad, c->d_cnt, c->d_cand, c->d_dxbad, c->d_zbar, c->d_zpart, c->d_gaps, c->d_coseq, c->d_con, c->d_cotab, c->d_pk, c->d_copk, c->d_rowp, c->d_corowp, c->d_cof5, c->d_cobp, c->d_cobad, c->d_allow, c->d_coallow, c->d_vlin, c->d_vdxl, c->d_vdx, c->d_hplen, c->d_model, c->d_lin, c->d_dxlin, c->d_vienna, c->d_wT, c->d_subseq, c->d_subn, c->d_subbp, c->d_subup, c->d_subdseq, c->d_subdn, c->d_subdx};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (GraphSlot* g : {&c->g_in, &c->g_out, &c->g_dx}) if (g->exec) (void)hipGraphExecDestroy(g->exec);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -1687,6 +1800,22 @@ int rh_batch_results_all(rh_ctx* c, double* bp, double* up, double* hp, double* 
     return RH_OK;
 }
 
+void* rh_host_alloc(rh_ctx* c, size_t bytes)
+{
+    if (!c || bytes == 0) return nullptr;
+    void* p = nullptr;
+    if (hipSetDevice(c->device) != hipSuccess || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+        fail(c, RH_ERR_OOM, "hipHostMalloc of %zu bytes failed", bytes);
+        return nullptr;
+    }
+    return p;
+}
+
+void rh_host_free(rh_ctx* c, void* p)
+{
+    if (c && p) { (void)hipSetDevice(c->device); (void)hipHostFree(p); }
+}
+
 int rh_set_max_w(rh_ctx* c, int max_w)
 {
     if (!c) return RH_ERR_ARG;
@@ -1749,6 +1878,15 @@ int rh_batch_kernels(rh_ctx* c, const char* fine[3], const char* far[3], int n_f
         if (n_far) n_far[k] = c->n_far[k];
     }
     return RH_OK;
+}
+
+int rh_batch_fallbacks(rh_ctx* c, int which, int* out, int cap)
+{
+    if (!c || (which != 0 && which != 1)) return RH_ERR_ARG;
+    if (!c->computed) return fail(c, RH_ERR_ARG, "no computed batch");
+    const std::vector<int>& F = which ? c->fallback_dx : c->fallback_mc;
+    for (int k = 0; k < (int)F.size() && k < cap; k++) out[k] = F[k];
+    return (int)F.size();
 }
 
 int rh_set_overlap(rh_ctx* c, int on)

@@ -28,6 +28,8 @@ extern "C" {
 double** pr_duplex = nullptr;
 static int g_n1 = 0;
 static rh_ctx* g_ctx = nullptr;
+// the original keeps process-global state too (pr_duplex); the context is released when the process exits or the library is unloaded
+static void release_context() { if (g_ctx) { rh_destroy(g_ctx); g_ctx = nullptr; } }
 
 double pf_duplex(const char* s1, const char* s2)
 {
@@ -41,6 +43,7 @@ double pf_duplex(const char* s1, const char* s2)
             std::fprintf(stderr, "pf_duplex (ractip_amd): %s\n", rh_last_error(nullptr));
             std::abort();
         }
+        std::atexit(release_context);
     }
     std::vector<double> hp((size_t)(n1 + 1) * (n2 + 1), 0.0);
     double logz = 0.0;

@@ -1,10 +1,12 @@
 // prob_cli.cpp -- drives the C++ adapters exactly as RactIP::solve does
 // (/root/reference/src/ractip.cpp:536-548) and prints the float matrices it would
 // hand to the ILP, one value per line, for tests/test_gpu_host_adapter.py.
-//   prob_cli contrafold SEQ | rnafold SEQ MAX_W | contraduplex S1 S2 TH | rnaduplex S1 S2 | cofold S1 S2 | pfduplex S1 S2 | solve S1 S2 [S1 S2 ...]
+//   [RACTIP_DEVICES=0,1,..] prob_cli contrafold SEQ | rnafold SEQ MAX_W | contraduplex S1 S2 TH | rnaduplex S1 S2 | cofold S1 S2 | pfduplex S1 S2 | solve S1 S2 [S1 S2 ...]
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "ractip_prob.hpp"
 
@@ -47,7 +49,12 @@ int main(int argc, char** argv)
             free_pf_duplex();
             return 0;
         }
-        ProbabilityEngine en(0, mode == "contraduplex" ? (float)std::atof(argv[4]) : 0.1f);
+        // RACTIP_DEVICES=0,1,... : one context and host thread per listed device for the batched modes (the in-process shard)
+        std::vector<int> devices;
+        if (const char* e = std::getenv("RACTIP_DEVICES"))
+            for (const char* p = e; *p;) { devices.push_back(std::atoi(p)); while (*p && *p != ',') ++p; if (*p == ',') ++p; }
+        if (devices.empty()) devices.push_back(0);
+        ProbabilityEngine en(devices, mode == "contraduplex" ? (float)std::atof(argv[4]) : 0.1f);
         if (mode == "contrafold") {
             VF bp; VI off; VVF up;
             en.contrafold(argv[2], bp, off, up);
@@ -72,11 +79,11 @@ int main(int argc, char** argv)
             dump_hp(hp);
         } else if (mode == "rnaduplex") {
             VVF hp; en.rnaduplex(argv[2], argv[3], hp); dump_hp(hp);
-        } else if (mode == "solve_default") {   // solve_default MAX_W S1 S2 [S1 S2 ...]
+        } else if (mode == "solve_default" || mode == "solve_default_duplex") {   // solve_default[_duplex] MAX_W S1 S2 [S1 S2 ...]
             const unsigned mw = (unsigned)std::atoi(argv[2]);
             std::vector<std::pair<std::string, std::string>> pairs;
             for (int k = 3; k + 1 < argc; k += 2) pairs.emplace_back(argv[k], argv[k + 1]);
-            for (const PairProbabilities& r : en.solve_probabilities_default(pairs, mw)) {
+            for (const PairProbabilities& r : en.solve_probabilities_default(pairs, mw, mode == "solve_default_duplex")) {
                 std::printf("pair %.17g %.17g %.17g\n", r.logZ1, r.logZ2, r.logZd);
                 std::printf("bp %zu\n", r.bp1.size());
                 for (float v : r.bp1) std::printf("%.9g\n", v);

@@ -2,6 +2,7 @@
 #include "ractip_prob.hpp"
 
 #include <algorithm>
+#include <thread>
 
 #include "../../include/ractip_hot.h"
 
@@ -15,20 +16,47 @@ VI make_offsets(uint L)
 }
 
 ProbabilityEngine::ProbabilityEngine(int device, float th_hy, const char* param_file)
-    : ctx_(rh_create(device, RH_MODEL_CONTRAFOLD, param_file)), device_(device), th_hy_(th_hy)
+    : ProbabilityEngine(std::vector<int>(1, device), th_hy, param_file) {}
+
+ProbabilityEngine::ProbabilityEngine(const std::vector<int>& devices, float th_hy, const char* param_file)
+    : ctx_(nullptr), devices_(devices.empty() ? std::vector<int>(1, 0) : devices), device_(devices_[0]), th_hy_(th_hy)
 {
-    if (!ctx_) throw std::logic_error(std::string("ractip_amd: ") + rh_last_error(nullptr));
+    for (int d : devices_) {
+        rh_ctx* c = rh_create(d, RH_MODEL_CONTRAFOLD, param_file);
+        if (!c) {
+            const std::string why = rh_last_error(nullptr);
+            for (rh_ctx* k : ctxs_) rh_destroy(k);
+            throw std::logic_error("ractip_amd: " + why);
+        }
+        ctxs_.push_back(c);
+    }
+    ctx_ = ctxs_[0];
+    vctxs_.assign(devices_.size(), nullptr);
 }
 
-ProbabilityEngine::~ProbabilityEngine() { rh_destroy(ctx_); rh_destroy(vctx_); }
+ProbabilityEngine::~ProbabilityEngine()
+{
+    for (rh_ctx* c : ctxs_) rh_destroy(c);
+    for (rh_ctx* c : vctxs_) rh_destroy(c);
+}
 
 rh_ctx* ProbabilityEngine::vienna() const
 {
     if (!vctx_) {
-        vctx_ = rh_create(device_, RH_MODEL_VIENNA_BL, nullptr);
-        if (!vctx_) throw std::logic_error(std::string("ractip_amd: ") + rh_last_error(nullptr));
+        for (size_t k = 0; k < devices_.size(); ++k) {
+            if (!vctxs_[k]) vctxs_[k] = rh_create(devices_[k], RH_MODEL_VIENNA_BL, nullptr);
+            if (!vctxs_[k]) throw std::logic_error(std::string("ractip_amd: ") + rh_last_error(nullptr));
+        }
+        vctx_ = vctxs_[0];
     }
     return vctx_;
+}
+
+std::pair<int, int> ProbabilityEngine::shard_bounds(int num, int k, int parts)
+{
+    const int base = num / parts, extra = num % parts;
+    const int lo = k * base + std::min(k, extra);
+    return {lo, lo + base + (k < extra ? 1 : 0)};
 }
 
 void ProbabilityEngine::raise(const char* where) const
@@ -167,11 +195,15 @@ void ProbabilityEngine::contraduplex(const std::string& seq1, const std::string&
 
 void ProbabilityEngine::rnaduplex(const std::string& seq1, const std::string& seq2, VVF& hp) const
 {
+    // the --duplex branch (src/ractip.cpp:390-398): pf_duplex() with the BL* energies, i.e. the Vienna-BL context with hp from
+    // the duplex-only ensemble -- the same numbers the pf_duplex shim and solve_probabilities_default(duplex = true) return
     const uint n1 = seq1.size(), n2 = seq2.size();
     hp.assign(n1 + 1, VF(n2 + 1, 0.0f));  // hp.resize(s1.size()+1, VF(s2.size()+1)), :393
     if (n1 == 0 || n2 == 0) return;
+    rh_ctx* v = vienna();
     std::vector<double> d((size_t)(n1 + 1) * (n2 + 1));
-    if (rh_duplex(ctx_, seq1.c_str(), (int)n1, seq2.c_str(), (int)n2, d.data(), nullptr) != RH_OK) raise("rnaduplex");
+    if (rh_set_hybrid(v, RH_HYBRID_DUPLEX) != RH_OK || rh_duplex(v, seq1.c_str(), (int)n1, seq2.c_str(), (int)n2, d.data(), nullptr) != RH_OK)
+        throw std::logic_error(std::string("ractip_amd::rnaduplex: ") + rh_last_error(v));
     for (uint i = 1; i <= n1; ++i)
         for (uint j = 1; j <= n2; ++j) hp[i][j] = (float)d[(size_t)i * (n2 + 1) + j];  // :395-397, no threshold
 }
@@ -185,17 +217,47 @@ std::vector<PairProbabilities> ProbabilityEngine::solve_probabilities(
 std::vector<PairProbabilities> ProbabilityEngine::solve_probabilities_default(
     const std::vector<std::pair<std::string, std::string>>& pairs, uint max_w, bool duplex) const
 {
-    rh_ctx* v = vienna();
-    if (rh_set_max_w(v, (int)std::max(1u, max_w)) != RH_OK || rh_set_hybrid(v, duplex ? RH_HYBRID_DUPLEX : RH_HYBRID_COFOLD) != RH_OK)
-        throw std::logic_error(std::string("ractip_amd::solve_probabilities_default: ") + rh_last_error(v));
-    std::vector<PairProbabilities> out = batch(v, pairs, std::max(1u, max_w), !duplex);
-    rh_set_hybrid(v, RH_HYBRID_DUPLEX);
+    vienna();
+    for (rh_ctx* v : vctxs_)
+        if (rh_set_max_w(v, (int)std::max(1u, max_w)) != RH_OK || rh_set_hybrid(v, duplex ? RH_HYBRID_DUPLEX : RH_HYBRID_COFOLD) != RH_OK)
+            throw std::logic_error(std::string("ractip_amd::solve_probabilities_default: ") + rh_last_error(v));
+    std::vector<PairProbabilities> out = batch(vctx_, pairs, std::max(1u, max_w), !duplex);
+    for (rh_ctx* v : vctxs_) rh_set_hybrid(v, RH_HYBRID_DUPLEX);
     return out;
 }
 
+// contiguous blocks of the pairs, one per listed device, each on its own context and host thread; results in iteration order
 std::vector<PairProbabilities> ProbabilityEngine::batch(rh_ctx* ctx, const std::vector<std::pair<std::string, std::string>>& pairs,
                                                         uint max_w, bool threshold_hp) const
 {
+    const int np = (int)pairs.size();
+    const std::vector<rh_ctx*>& all = (ctx == ctx_) ? ctxs_ : vctxs_;
+    const int parts = std::min<int>((int)all.size(), std::max(1, np));
+    if (parts <= 1) return batch_one(ctx, pairs, 0, np, max_w, threshold_hp);
+    std::vector<std::vector<PairProbabilities>> part(parts);
+    std::vector<std::string> errors(parts);
+    std::vector<std::thread> workers;
+    for (int k = 0; k < parts; ++k)
+        workers.emplace_back([&, k] {
+            try {
+                const auto b = shard_bounds(np, k, parts);
+                part[k] = batch_one(all[k], pairs, b.first, b.second, max_w, threshold_hp);
+            } catch (const std::exception& e) { errors[k] = e.what(); }
+        });
+    for (std::thread& t : workers) t.join();
+    std::vector<PairProbabilities> out;
+    out.reserve(np);
+    for (int k = 0; k < parts; ++k) {
+        if (!errors[k].empty()) throw std::logic_error(errors[k]);
+        for (PairProbabilities& r : part[k]) out.push_back(std::move(r));
+    }
+    return out;
+}
+
+std::vector<PairProbabilities> ProbabilityEngine::batch_one(rh_ctx* ctx, const std::vector<std::pair<std::string, std::string>>& all_pairs,
+                                                            int lo, int hi, uint max_w, bool threshold_hp) const
+{
+    const std::vector<std::pair<std::string, std::string>> pairs(all_pairs.begin() + lo, all_pairs.begin() + hi);
     const int np = (int)pairs.size();
     std::vector<PairProbabilities> out(np);
     if (np == 0) return out;

@@ -37,6 +37,12 @@ class ProbabilityEngine {
 public:
     // th_hy: RactIP's hybridization threshold th_hy_ (contraduplex keeps hp >= th_hy, :237)
     explicit ProbabilityEngine(int device = 0, float th_hy = 0.1f, const char* param_file = nullptr);
+    // the z-score shard inside ONE process (src/ractip.cpp:1636-1663): one rh_ctx and one host thread per listed
+    // device.  The batched forms split their pairs into contiguous blocks, one per device, and return the results in
+    // iteration order, so the float accumulation of the caller (:1655-1663) sees the same sequence of values as on one
+    // GPU.  A device may be listed more than once (two contexts on one GPU: one's copies overlap the other's kernels).
+    // The single-problem members use the first device.
+    explicit ProbabilityEngine(const std::vector<int>& devices, float th_hy = 0.1f, const char* param_file = nullptr);
     ~ProbabilityEngine();
     ProbabilityEngine(const ProbabilityEngine&) = delete;
     ProbabilityEngine& operator=(const ProbabilityEngine&) = delete;
@@ -70,14 +76,22 @@ public:
                                                                uint max_w = 15, bool duplex = false) const;
 
     rh_ctx* raw() const { return ctx_; }
+    int device_count() const { return (int)devices_.size(); }
+    // [lo, hi) of `num` units owned by shard `k` of `parts`: contiguous, sizes differ by at most one (ractip_amd/shard.py)
+    static std::pair<int, int> shard_bounds(int num, int k, int parts);
 
 private:
     [[noreturn]] void raise(const char* where) const;
     rh_ctx* vienna() const;
     std::vector<PairProbabilities> batch(rh_ctx* ctx, const std::vector<std::pair<std::string, std::string>>& pairs, uint max_w,
                                          bool threshold_hp) const;
-    rh_ctx* ctx_;
-    mutable rh_ctx* vctx_ = nullptr;
+    std::vector<PairProbabilities> batch_one(rh_ctx* ctx, const std::vector<std::pair<std::string, std::string>>& pairs, int lo, int hi,
+                                             uint max_w, bool threshold_hp) const;
+    rh_ctx* ctx_;                          // first device's CONTRAfold context
+    mutable rh_ctx* vctx_ = nullptr;       // first device's Vienna-BL context (created on first use)
+    std::vector<int> devices_;
+    std::vector<rh_ctx*> ctxs_;            // one CONTRAfold context per listed device (ctxs_[0] == ctx_)
+    mutable std::vector<rh_ctx*> vctxs_;   // Vienna-BL contexts, same order
     int device_;
     float th_hy_;
 };

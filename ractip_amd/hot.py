@@ -19,6 +19,7 @@ EXPORTS = [
     "rh_batch_upload", "rh_batch_compute", "rh_batch_results", "rh_batch_candidates",
     "rh_batch_timings", "rh_batch_device_views", "rh_batch_logz", "rh_batch_candidates_all", "rh_batch_layout",
     "rh_batch_results_all", "rh_set_max_w", "rh_get_max_w", "rh_set_overlap", "rh_batch_kernels", "rh_set_hybrid", "rh_last_hybrid_path", "rh_fold_constrained", "rh_cofold_constrained",
+    "rh_host_alloc", "rh_host_free", "rh_batch_fallbacks",
 ]
 
 
@@ -83,6 +84,12 @@ def load_library():
     L.rh_batch_timings.argtypes = [vp, vp, vp]
     L.rh_batch_logz.argtypes = [vp, vp]
     L.rh_batch_device_views.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.rh_batch_fallbacks.argtypes = [vp, ci, vp, ci]
+    L.rh_batch_fallbacks.restype = ci
+    L.rh_host_alloc.restype = vp
+    L.rh_host_alloc.argtypes = [vp, ctypes.c_size_t]
+    L.rh_host_free.restype = None
+    L.rh_host_free.argtypes = [vp, vp]
     for f in ("rh_bpp", "rh_unpaired", "rh_fold", "rh_duplex", "rh_batch_upload", "rh_batch_compute", "rh_batch_results",
               "rh_batch_candidates", "rh_batch_timings", "rh_batch_device_views", "rh_batch_logz", "rh_batch_candidates_all",
               "rh_batch_layout", "rh_batch_results_all"):
@@ -111,6 +118,9 @@ class Context:
 
     def close(self):
         if getattr(self, "h", None):
+            for ptr in getattr(self, "_pinned", []):
+                self.L.rh_host_free(self.h, ptr)
+            self._pinned = []
             self.L.rh_destroy(self.h)
             self.h = None
 
@@ -254,6 +264,35 @@ class Context:
                 u1, u2 = u1.reshape(n1, w), u2.reshape(n2, w)
             out.append(dict(bp1=bp[2 * p][:tri_size(n1)], bp2=bp[2 * p + 1][:tri_size(n2)], up1=u1, up2=u2, hp=h, logZ=z[p]))
         return out
+
+    def pinned_empty(self, shape, dtype=np.float64):
+        """numpy array over page-locked host memory (rh_host_alloc); freed with the context."""
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        ptr = self.L.rh_host_alloc(self.h, max(nbytes, 8))
+        if not ptr:
+            raise RhError("rh_host_alloc failed: %s" % self.L.rh_last_error(self.h).decode())
+        self._pinned = getattr(self, "_pinned", []) + [ptr]
+        buf = (ctypes.c_char * max(nbytes, 8)).from_address(ptr)
+        return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def batch_results_all_into(self, bufs=None):
+        """Dense results of all pairs in the padded device layout (rh_batch_layout), three copies, no unpacking.  `bufs` =
+        (bp, up, hp, logz) arrays from a previous call are reused when the layout is unchanged; they are page-locked."""
+        ts, hs = ctypes.c_size_t(), ctypes.c_size_t()
+        uld, hld = ctypes.c_int(), ctypes.c_int()
+        self._check(self.L.rh_batch_layout(self.h, ctypes.byref(ts), ctypes.byref(uld), ctypes.byref(hs), ctypes.byref(hld)))
+        np_ = len(self._pairs)
+        shapes = ((2 * np_, ts.value), (2 * np_, uld.value), (np_, hs.value), (np_, 3))
+        if bufs is None or tuple(b.shape for b in bufs) != shapes:
+            bufs = tuple(self.pinned_empty(sh) for sh in shapes)
+        self._check(self.L.rh_batch_results_all(self.h, *[b.ctypes.data for b in bufs]))
+        return bufs
+
+    def batch_fallbacks(self, which=0):
+        """Indices of the sequences (which=0) / pairs (which=1) the last compute recomputed in log space."""
+        buf = (ctypes.c_int * max(1, 2 * len(self._pairs)))()
+        k = self._check(self.L.rh_batch_fallbacks(self.h, which, buf, len(buf)))
+        return [buf[t] for t in range(min(k, len(buf)))]
 
     def set_overlap(self, on):
         """False: phases run one after the other (isolated per-phase device times in batch_timings)."""

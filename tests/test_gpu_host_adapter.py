@@ -55,16 +55,47 @@ def test_contrafold_member(cli, oracle, golden):
     assert np.abs(up.astype(np.float32) - oracle.up_float(n, o["post"].astype(np.float32))).max() < 2e-6
 
 
-def test_contraduplex_threshold_and_rnaduplex(cli, oracle, golden):
+def test_contraduplex_threshold(cli, oracle, golden):
     s1, s2 = str(golden["mc/Tar/seq"]), str(golden["mc/Tarstar/seq"])
     ref = oracle.duplex(s1, s2)["post"]
-    hp, _ = take(run(cli, "rnaduplex", s1, s2), 0, "hp")
-    close32(hp, ref, "rnaduplex hp")
     th = 0.1
     hp_t, _ = take(run(cli, "contraduplex", s1, s2, str(th)), 0, "hp")
     expect = np.where(ref.astype(np.float32) >= np.float32(th), ref, 0.0)  # GetPosterior(th_hy_), ractip.cpp:237
     edge = np.abs(ref - th) < 1e-6
     close32(np.where(edge, 0, hp_t), np.where(edge, 0, expect), "contraduplex hp")
+
+
+def test_rnaduplex_is_the_vienna_bl_pf_duplex_on_every_entry_point(cli, golden):
+    """RactIP::rnaduplex --duplex (src/ractip.cpp:390-398) is pf_duplex() with the BL* energies.  The C++ member, the
+    source-compatible pf_duplex shim and the batched default path with duplex = true are three doors to the same
+    numbers (parity unpinned model: checked against its CPU restatement)."""
+    from _oracle import ViennaOracle
+    s1, s2 = str(golden["mc/Tar/seq"]), str(golden["mc/Tarstar/seq"])
+    ref = ViennaOracle().pf_duplex(s1, s2)["pr"]
+    hp, _ = take(run(cli, "rnaduplex", s1, s2), 0, "hp")
+    close32(hp, ref, "rnaduplex hp vs Vienna-BL pf_duplex")
+    shim, _ = take(run(cli, "pfduplex", s1, s2), 1, "hp")
+    close32(shim, ref, "pf_duplex shim")
+    assert np.abs(hp.astype(np.float32) - shim.astype(np.float32)).max() <= 1e-7
+    lines = run(cli, "solve_default_duplex", "3", s1, s2)
+    pos = 1
+    _, pos = take(lines, pos, "bp")
+    _, pos = take(lines, pos, "up")
+    hb, pos = take(lines, pos, "hp")
+    assert np.abs(hb.astype(np.float32) - hp.astype(np.float32)).max() <= 1e-7
+
+
+def test_in_process_shard_over_a_device_list(cli, golden):
+    """ProbabilityEngine over a device list (here the one GPU twice: two contexts, two host threads): contiguous blocks of
+    the pairs, results in iteration order -- identical output to the single-context run (src/ractip.cpp:1636-1663)."""
+    names = ["DIS", "Tar", "Tarstar", "R1inv", "R2inv"]
+    args = []
+    for k in range(5):
+        args += [str(golden["mc/%s/seq" % names[k]]), str(golden["mc/%s/seq" % names[(k + 2) % 5]])]
+    one = run(cli, "solve", *args)
+    two = run_env(cli, {"RACTIP_DEVICES": "0,0"}, "solve", *args)
+    three = run_env(cli, {"RACTIP_DEVICES": "0,0,0"}, "solve", *args)
+    assert one == two == three and sum(l.startswith("pair") for l in one) == 5
 
 
 def run_env(cli, env, *args):

@@ -174,6 +174,10 @@ def test_n2000_vs_golden(ctx, golden):
     hp = r["hp"].ravel()
     assert abs(hp.sum() - float(golden["dx2000/post_sum"])) < 1e-5
     assert_prob_close(hp[golden["dx2000/idx"]], golden["dx2000/val"], rel=REL, what="hp n=2000")
+    # the second sequence of the pair (oracle/gen_golden.py, GOLDEN_ONLY=2000b)
+    assert abs(r["logZ"][1] - float(golden["mc2000b/logZ"])) < 1e-7
+    assert abs(r["bp2"].sum() - float(golden["mc2000b/post_sum"])) < 1e-5
+    assert_prob_close(r["bp2"][golden["mc2000b/idx"]], golden["mc2000b/val"], rel=REL, what="bp2 n=2000")
 
 
 def test_linear_path_is_taken_and_falls_back_on_overflow(ctx, oracle):
@@ -191,6 +195,88 @@ def test_linear_path_is_taken_and_falls_back_on_overflow(ctx, oracle):
     o = oracle.inference(helix)
     assert abs(z - o["logZ"]) < 1e-7 * abs(o["logZ"])
     assert_prob_close(bp, o["post"], rel=REL, what="GC helix via fallback")
+
+
+def test_mixed_batch_only_the_flagged_problems_fall_back(ctx, oracle):
+    """One perfect GC helix among ordinary pairs: only that sequence (and the duplex of its pair) leaves the double range
+    and is recomputed in log space; every other problem keeps its linear-path bits (LogSpace.hpp:232-244 has no cliff)."""
+    if ctx.path_name != "auto":
+        pytest.skip("fallback logic belongs to the auto path")
+    pairs = random_pairs(6, 300, seed=4242)
+    ctx.batch_upload(pairs)
+    ctx.batch_compute()
+    assert ctx.last_path() == 1 and ctx.batch_fallbacks(0) == [] and ctx.batch_fallbacks(1) == []
+    base = [ctx.batch_results(p) for p in range(len(pairs))]
+    helix = "G" * 348 + "AAAA" + "C" * 348                      # log Z ~ 1.5 per nucleotide >> the scale exponent: e^966 scaled
+    mixed = list(pairs)
+    mixed[3] = (helix, pairs[3][1])
+    ctx.batch_upload(mixed)
+    ctx.batch_compute()
+    assert ctx.last_path() == 3 and ctx.batch_fallbacks(0) == [6]
+    for p in range(len(pairs)):
+        r = ctx.batch_results(p)
+        if p != 3:   # untouched problems: bit for bit what the all-ordinary batch gave
+            for k in ("bp1", "bp2", "up1", "up2", "hp", "logZ"):
+                assert np.array_equal(r[k], base[p][k]), (p, k)
+        else:
+            o1, od = oracle.inference(helix), oracle.duplex(helix, pairs[3][1])
+            assert abs(r["logZ"][0] - o1["logZ"]) < 1e-7 * abs(o1["logZ"])
+            assert_prob_close(r["bp1"], o1["post"], rel=REL, what="helix bp via per-problem fallback")
+            assert np.array_equal(r["bp2"], base[3]["bp2"])         # its partner stayed on the linear path
+            assert abs(r["logZ"][2] - od["logZ2"][0]) < 1e-7 * abs(od["logZ2"][0])
+            assert_prob_close(r["hp"], od["post"], rel=REL, what="helix duplex")
+    # a duplex that overflows while its sequences do not: two complementary 400-mers (log Z of the duplex ~ 2 per pair)
+    a = "GC" * 200
+    b = "GC" * 200
+    ctx.batch_upload(pairs[:3] + [(a, b)] + pairs[3:])
+    ctx.batch_compute()
+    if ctx.batch_fallbacks(1):
+        assert ctx.batch_fallbacks(1) == [3] and ctx.last_hybrid_path() == 3
+        od = oracle.duplex(a, b)
+        assert_prob_close(ctx.batch_results(3)["hp"], od["post"], rel=REL, what="overflowing duplex via per-pair fallback")
+        assert np.array_equal(ctx.batch_results(0)["hp"], base[0]["hp"])
+
+
+def test_real_and_gc_rich_sequences_stay_on_the_linear_path(ctx, golden):
+    """The scale exponent is tuned on random ACGU (log Z per nucleotide 0.11-0.13); the bundled RNAs sit at 0.13-0.23 and a
+    70 % GC sequence higher still: all of them must stay inside the double range on the fast path, up to n = 2000."""
+    if ctx.path_name != "auto":
+        pytest.skip("records the path the auto mode takes")
+    names = [str(n) for n in golden["mc_names"] if len(str(golden["mc/%s/seq" % n])) >= 30]
+    seqs = [str(golden["mc/%s/seq" % n]) for n in names]
+    ctx.batch_upload([(s, s) for s in seqs])
+    ctx.batch_compute()
+    assert ctx.last_path() == 1, ("bundled sequences fell back", [names[k // 2] for k in ctx.batch_fallbacks(0)])
+    rng = np.random.default_rng(7)
+    gc = "".join(rng.choice(list("GCAU"), 2000, p=[0.35, 0.35, 0.15, 0.15]))
+    ctx.batch_upload([(gc, gc[::-1])])
+    ctx.batch_compute()
+    z = ctx.batch_results(0)["logZ"]
+    assert ctx.last_path() == 1, "70 %% GC, n = 2000: log Z per nucleotide %.3f left the double range" % (z[0] / 2000)
+    assert 0.15 < z[0] / 2000 < 0.45
+
+
+def test_zscore_batch_of_1000_shuffles_sampled_against_the_oracle(ctx, oracle):
+    """BASELINE config 5, DP stage: the 1000 dinucleotide shuffles of OxyS / fhlA (--zscore=12 --seed=1, src/ractip.cpp:1636-1643)
+    in one device pass; 16 of them checked in full (bp1, bp2, hp, three log Z) against the CPU oracle."""
+    import os
+    from ractip_amd import shard
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fa = [l.strip() for l in open(os.path.join(root, "ractip_amd", "data", "config5_OxyS_fhlA.fa")) if not l.startswith(">")]
+    pairs = shard.zscore_shuffles(fa[0], fa[1], 12, 1000, 1)
+    ctx.batch_upload(pairs)
+    ctx.batch_compute()
+    logz = ctx.batch_logz()
+    assert logz.shape == (1000, 3) and np.all(np.isfinite(logz))
+    for p in list(range(0, 1000, 67)) + [999]:
+        s1, s2 = pairs[p]
+        r = ctx.batch_results(p)
+        o1, o2, od = oracle.inference(s1), oracle.inference(s2), oracle.duplex(s1, s2)
+        assert abs(r["logZ"][0] - o1["logZ"]) < 1e-9 and abs(r["logZ"][1] - o2["logZ"]) < 1e-9
+        assert abs(r["logZ"][2] - od["logZ2"][0]) < 1e-9 and np.array_equal(r["logZ"], logz[p])
+        assert_prob_close(r["bp1"], o1["post"], rel=REL, what="shuffle %d bp1" % p)
+        assert_prob_close(r["bp2"], o2["post"], rel=REL, what="shuffle %d bp2" % p)
+        assert_prob_close(r["hp"], od["post"], rel=REL, what="shuffle %d hp" % p)
 
 
 def test_threshold_candidates_match_reference_scans(ctx, oracle, golden):

@@ -36,20 +36,29 @@ def test_ip_model_is_class_ip():
     assert [round(ip.get_value(k)) for k in (a, b, c)] == [0, 1, 0]
 
 
-def test_readme_dis_dis_default_path(golden):
-    """The reference's recorded output is reproduced by the Vienna-BL restatement + programme once the accessibility
-    threshold is 0.01; at the default 0.003 the interaction is two pairs longer on either side because the restatement puts
-    P(letters 11..23 unpaired) = 0.0038, a hair above the threshold (0.14 kcal/mol): the one point where the unpinned
-    energy model (ViennaRNA-1.8 semantics instead of the unknown 2.x build behind the README) shows."""
+def test_readme_dis_dis_structure_needs_a_looser_accessibility_threshold(golden):
+    """The Vienna-BL restatement + programme reproduces the README structure (README.md:93-97) only with --acc-th 0.01."""
     from _oracle import ViennaOracle
     vo = ViennaOracle()
     s = str(golden["mc/DIS/seq"])
     f, co = vo.mccaskill(s, max_w=15), vo.cofold(s, s)
     r1, r2, _ = ilp.solve(s, s, f["post"], f["post"], co["hp"], f["up"], f["up"], ilp.Options(th_ac=0.01))
     assert r1 == README_DIS and r2 == README_DIS.replace("[", "]")
-    assert 0.003 < f["up"][10][12] < 0.01
-    r1, r2, _ = ilp.solve(s, s, f["post"], f["post"], co["hp"], f["up"], f["up"])
-    assert r1 == "((((.((((([[..[[[[[[.[[)))))...))))" and r2 == r1.replace("[", "]")
+    assert 0.003 < f["up"][10][12] < 0.01   # P(letters 11..23 unpaired) = 0.0038: 0.14 kcal/mol above the default threshold
+
+
+@pytest.mark.xfail(strict=True, reason="KNOWN GAP, parity unpinned: at RactIP's default thresholds the only output the reference "
+                   "records for its default path (README.md:91-97, `ractip DIS.fa DIS.fa`, unknown ViennaRNA 2.x build) is NOT "
+                   "reproduced -- the interaction comes out two pairs longer on each side.  The Vienna-BL model here has "
+                   "ViennaRNA-1.8 loop-energy semantics (the 1.8 branch of src/pf_duplex.c:209-433); CMakeLists.txt:28 builds the "
+                   "2.x branch.  This test turns green only when the default-flag output matches the README.")
+def test_readme_dis_dis_default_thresholds_match_the_reference_output(golden):
+    from _oracle import ViennaOracle
+    vo = ViennaOracle()
+    s = str(golden["mc/DIS/seq"])
+    f, co = vo.mccaskill(s, max_w=15), vo.cofold(s, s)
+    r1, r2, _ = ilp.solve(s, s, f["post"], f["post"], co["hp"], f["up"], f["up"])   # cmdline.c defaults: -a 0.7 -t 0.5, th_ac 0.003
+    assert r1 == README_DIS and r2 == README_DIS.replace("[", "]")
 
 
 def test_structures_from_reference_matrices_are_well_formed(golden):

@@ -23,6 +23,9 @@ except (OSError, ValueError):
     doc = {}
 doc["note"] = ("HBM-side bytes per DISPATCH by kernel from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, KB counters, gfx950 "
                "correction); key = <model>_n<seqlen>_b<pairs per step>; bench.py reports the dominant kernel's entry as roofline.traffic")
+sys.path.insert(0, root)
+import bench
+out["source_hash"] = bench.source_hash()   # bench.py reports an entry only for the kernel sources it was measured on
 doc[key] = out
 json.dump(doc, open(dst, "w"), indent=1)
 print(json.dumps(out, indent=1))
