@@ -110,8 +110,15 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_inside_strip(McB
     static_assert(KD % W == 0 && KD <= 8 && W % TS == 0 && KD % (W / TS) == 0 && (NM + 1) % W == 0, "8 terms per end and term set, 32/W staged rows per wavefront and region");
     __shared__ double lds[P::SZ];
     __shared__ double red[W];
-    const int sq = pin ? blockIdx.x : blockIdx.y;
-    const int slot = pin ? blockIdx.y : blockIdx.x;
+    // pin = 2 (batch size a multiple of 8): workgroups are dealt round-robin to the 8 XCDs in launch order, so sequence sq is
+    // pinned to XCD sq % 8 AND the groups of one sequence are consecutive on that XCD: neighbouring groups share 40 % of their
+    // staged columns, which then come out of that XCD's L2 instead of HBM.  (Placement only: any mapping gives the same result.)
+    int sq = pin ? blockIdx.x : blockIdx.y, slot = pin ? blockIdx.y : blockIdx.x;
+    if (pin == 2) {
+        const unsigned lin = blockIdx.x + blockIdx.y * gridDim.x, t = lin >> 3;
+        slot = (int)(t % gridDim.y);
+        sq = (int)(t / gridDim.y) * 8 + (int)(lin & 7);
+    }
     if (sq >= B.ns) return;
     const int n = B.n[sq];
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -577,8 +584,15 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_outside_strip(Mc
     static_assert(KD % W == 0 && KD <= 8 && W % TS == 0 && KD % (W / TS) == 0 && (NM + 1) % W == 0, "8 terms per end and term set, 32/W staged rows per wavefront and region");
     __shared__ double lds[P::SZ];
     __shared__ double red[W];
-    const int sq = pin ? blockIdx.x : blockIdx.y;
-    const int slot = pin ? blockIdx.y : blockIdx.x;
+    // pin = 2 (batch size a multiple of 8): workgroups are dealt round-robin to the 8 XCDs in launch order, so sequence sq is
+    // pinned to XCD sq % 8 AND the groups of one sequence are consecutive on that XCD: neighbouring groups share 40 % of their
+    // staged columns, which then come out of that XCD's L2 instead of HBM.  (Placement only: any mapping gives the same result.)
+    int sq = pin ? blockIdx.x : blockIdx.y, slot = pin ? blockIdx.y : blockIdx.x;
+    if (pin == 2) {
+        const unsigned lin = blockIdx.x + blockIdx.y * gridDim.x, t = lin >> 3;
+        slot = (int)(t % gridDim.y);
+        sq = (int)(t / gridDim.y) * 8 + (int)(lin & 7);
+    }
     if (sq >= B.ns) return;
     const int n = B.n[sq];
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;

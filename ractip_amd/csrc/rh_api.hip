@@ -266,6 +266,7 @@ struct rh_ctx {
     int strip = 3;                 // CONTRAfold linear path: KD = 8 diagonals per launch (mccaskill_strip.hip) with the banded near/far split;
                                    // RH_STRIP=0: the per-diagonal-pair kernels of mccaskill_lin.hip.  Bit 0 = inside sweep, bit 1 = outside sweep
     int strip_w = 8;               // wavefronts per strip workgroup (RH_STRIP_W = 4 | 8)
+    int strip_xcd = 1;             // groups of one sequence consecutive on one XCD (RH_STRIP_XCD=0: sequence-major launch order only)
     double* d_wT = nullptr;        // transposed, zero-padded single-branch weights wT[l1][t+1] of the strip kernels
     bool far_pk = true;            // ... on packed operand tiles (lin_pack_tiles + lin_far_*_pk); RH_FAR_PK=0: gather per product
     bool use_graphs = true;        // RH_NO_GRAPH=1 launches every kernel from the host instead
@@ -863,10 +864,10 @@ int launch_mc_lin(rh_ctx* c, int pin, int phase)
                 const int groups = (std::max(B.nmax - 1 - d0, 0) + GS - 1) / GS + 1;
                 if (c->strip_w == 4)
                     KLAUNCH(c, 0, (lin_inside_strip<KD, 4>), pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(256), c->s_mc, B, c->d_lin, c->d_wT, d0,
-                            d0 == 32 ? 32 : d0 - KD + 2, std::exp(-c->h_lin.s * d0), pin);
+                            d0 == 32 ? 32 : d0 - KD + 2, std::exp(-c->h_lin.s * d0), (pin && c->strip_xcd) ? 2 : pin);
                 else
                     KLAUNCH(c, 0, (lin_inside_strip<KD, 8>), pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(512), c->s_mc, B, c->d_lin, c->d_wT, d0,
-                            d0 == 32 ? 32 : d0 - KD + 2, std::exp(-c->h_lin.s * d0), pin);
+                            d0 == 32 ? 32 : d0 - KD + 2, std::exp(-c->h_lin.s * d0), (pin && c->strip_xcd) ? 2 : pin);
                 c->n_launch[0]++;
                 if ((d0 + KD) % BS == 0) {
                     const int D = (d0 + KD) / BS + 1;
@@ -938,10 +939,10 @@ int launch_mc_lin(rh_ctx* c, int pin, int phase)
                 const int groups = (std::max(B.nmax - 1 - (d0 - (KD - 1)), 0) + GS - 1) / GS + 1;
                 if (c->strip_w == 4)
                     KLAUNCH(c, 2, (lin_outside_strip<KD, 4>), pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(256), c->s_mc, B, c->d_lin, c->d_wT, d0,
-                            d0 - 6, d0 - 13, pin, bad);
+                            d0 - 6, d0 - 13, (pin && c->strip_xcd) ? 2 : pin, bad);
                 else
                     KLAUNCH(c, 2, (lin_outside_strip<KD, 8>), pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(512), c->s_mc, B, c->d_lin, c->d_wT, d0,
-                            d0 - 6, d0 - 13, pin, bad);
+                            d0 - 6, d0 - 13, (pin && c->strip_xcd) ? 2 : pin, bad);
                 c->n_launch[1]++;
             }
             hipLaunchKernelGGL(lin_finish, dim3((B.ns + 63) / 64), dim3(64), 0, c->s_mc, B, c->d_lin, (double*)c->d_mclogz, bad);
@@ -1240,7 +1241,7 @@ size_t shape_key(const rh_ctx* c, int which)
         for (size_t v : {(size_t)B.ns, (size_t)B.nmax, (size_t)B.ld, (size_t)B.lds, (size_t)B.tab, (size_t)B.seq, (size_t)B.n,
                          (size_t)B.f5i, (size_t)B.bp, (size_t)B.up, (size_t)c->d_bad, (size_t)c->d_mclogz, (size_t)c->lin_w, (size_t)c->lin_w_in,
                          (size_t)c->lin_bs, (size_t)B.tri_stride, (size_t)c->far_mfma, (size_t)c->max_w, (size_t)c->d_gaps,
-                         (size_t)c->d_hplen, (size_t)B.allow, (size_t)B.pk, (size_t)c->far_pk, (size_t)B.rowp, (size_t)c->lookahead, (size_t)c->strip, (size_t)c->d_wT, (size_t)c->strip_w})
+                         (size_t)c->d_hplen, (size_t)B.allow, (size_t)B.pk, (size_t)c->far_pk, (size_t)B.rowp, (size_t)c->lookahead, (size_t)c->strip, (size_t)c->d_wT, (size_t)c->strip_w, (size_t)c->strip_xcd})
             h = mix(h, v);
     } else {
         const DxLinBatch& X = c->dxl;
@@ -1495,6 +1496,7 @@ rh_ctx* rh_create(int device, int model, const char* param_file)
     if (const char* e = std::getenv("RH_LOOKAHEAD")) c->lookahead = std::atoi(e);
     if (const char* e = std::getenv("RH_STRIP")) c->strip = std::atoi(e);
     if (const char* e = std::getenv("RH_STRIP_W")) c->strip_w = std::atoi(e) == 4 ? 4 : 8;
+    if (const char* e = std::getenv("RH_STRIP_XCD")) c->strip_xcd = std::atoi(e);
     if (const char* e = std::getenv("RH_DX_W")) c->dx_w = std::atoi(e);
     if (const char* e = std::getenv("RH_DX_QUAD")) c->dx_quad = std::atoi(e) != 0;
     bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&c->s_mc, hipStreamNonBlocking) == hipSuccess &&

@@ -195,3 +195,34 @@ void build_vdx_lin(const ViennaDx& V, double s, VDxLin* D)
 }
 
 }  // namespace rh
+
+// Host-only inspection hook for tests/test_bl_cells.py (no GPU involved): the energy, in the file's 10 cal/mol units, that
+// the product's loader holds for one table cell after binding the flat BL* arrays -- so that the binding can be checked
+// against cells labelled independently from the reference's block comments (oracle/pin_bl_cells.py).
+// table: 0 = stack[i][j], 1 = int11[i][j][k][l], 2 = int21[i][j][k][l][m], 3 = int22[i][j][k][l][m][n].
+extern "C" int rh_debug_vienna_cell(const char* param_file, int table, int i, int j, int k, int l, int m, int n, double* energy)
+{
+    static rh::ViennaDx* V = nullptr;
+    static std::string loaded;
+    if (!param_file || !energy) return -1;
+    if (!V || loaded != param_file) {
+        delete V;
+        V = new rh::ViennaDx;
+        char err[256];
+        if (!rh::load_vienna_dx(param_file, V, err, sizeof err)) { delete V; V = nullptr; return -4; }
+        loaded = param_file;
+    }
+    const double kT = (37.0 + 273.15) * 1.98717;
+    if (i < 0 || i > 7 || j < 0 || j > 7) return -1;
+    const int tt = i * 8 + j;
+    double w;
+    switch (table) {
+        case 0: w = V->stack[tt]; break;
+        case 1: if (k < 0 || k > 4 || l < 0 || l > 4) return -1; w = V->int11[tt * 25 + k * 5 + l]; break;
+        case 2: if (k < 0 || k > 4 || l < 0 || l > 4 || m < 0 || m > 4) return -1; w = V->int21[tt * 125 + (k * 5 + l) * 5 + m]; break;
+        case 3: if (k < 0 || k > 4 || l < 0 || l > 4 || m < 0 || m > 4 || n < 0 || n > 4) return -1; w = V->int22[tt * 625 + ((k * 5 + l) * 5 + m) * 5 + n]; break;
+        default: return -1;
+    }
+    *energy = -w * kT / 10.0;
+    return 0;
+}
