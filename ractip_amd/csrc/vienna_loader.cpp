@@ -198,7 +198,7 @@ void build_vdx_lin(const ViennaDx& V, double s, VDxLin* D)
 
 // Host-only inspection hook for tests/test_bl_cells.py (no GPU involved): the energy, in the file's 10 cal/mol units, that
 // the product's loader holds for one table cell after binding the flat BL* arrays -- so that the binding can be checked
-// against cells labelled independently from the reference's block comments (oracle/pin_bl_cells.py).
+// against cells labelled independently from the reference's block comments (tests/golden/bl_star_cells.json).
 // table: 0 = stack[i][j], 1 = int11[i][j][k][l], 2 = int21[i][j][k][l][m], 3 = int22[i][j][k][l][m][n].
 extern "C" int rh_debug_vienna_cell(const char* param_file, int table, int i, int j, int k, int l, int m, int n, double* energy)
 {
