@@ -181,7 +181,7 @@ __device__ __forceinline__ d4 mfma_chunk(const double (*A)[17], const double (*B
 }
 
 // sum the 4 wavefronts' accumulators and store the tile (wave 0)
-__device__ __forceinline__ void reduce_store(double (*red)[256], d4 acc, double* __restrict__ T, int ld, int n, int i0, int j0)
+__device__ __forceinline__ void reduce_store(double (*red)[256], d4 acc, double* __restrict__ T, int ld, int n, int i0, int j0, bool rmw = false)
 {
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
@@ -192,7 +192,7 @@ __device__ __forceinline__ void reduce_store(double (*red)[256], d4 acc, double*
     for (int r = 0; r < 4; r++) {
         const double v = red[0][r * 64 + lane] + red[1][r * 64 + lane] + red[2][r * 64 + lane] + red[3][r * 64 + lane];
         const int i = i0 + (lane >> 4) + 4 * r, j = j0 + (lane & 15);
-        if (i >= 1 && i <= j && j <= n - 1) T[(size_t)(j - i) * ld + i] = v;
+        if (i >= 1 && i <= j && j <= n - 1) { double* t = T + (size_t)(j - i) * ld + i; *t = rmw ? *t + v : v; }   // rmw: on top of the 64-block products
     }
 }
 
@@ -299,10 +299,10 @@ __device__ __forceinline__ d4 mfma4(d4 a, d4 b, d4 acc)
 
 // acc += sum over K = k_lo + w, k_lo + w + 4, ... <= k_hi of frag(pa + ta(K)) x frag(pb + tb(K)); two steps in flight
 template <class TA, class TB>
-__device__ __forceinline__ d4 pk_loop(const double* __restrict__ pa, const double* __restrict__ pb, int k_lo, int k_hi, TA ta, TB tb)
+__device__ __forceinline__ d4 pk_loop(const double* __restrict__ pa, const double* __restrict__ pb, int k_lo, int k_hi, TA ta, TB tb,
+                                      d4 acc = d4{0.0, 0.0, 0.0, 0.0})
 {
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    d4 acc = {0.0, 0.0, 0.0, 0.0};
     int K = k_lo + w;
     for (; K + 4 <= k_hi; K += 8) {
         const d4 a0 = *(const d4*)(pa + ta(K) + lane * 4), b0 = *(const d4*)(pb + tb(K) + lane * 4);
@@ -317,7 +317,15 @@ __device__ __forceinline__ d4 pk_loop(const double* __restrict__ pa, const doubl
     return acc;
 }
 
-__global__ __launch_bounds__(256) void lin_far_inside_pk(McBatch B, int D)
+// Two-level block products (l2 != 0, long sequences).  With 16x16 tiles every operand tile is read once per product: 4 KB per 8 kFLOP,
+// which at n = 2000 is 250 GB per 32 pairs and the largest item of the step.  The bulk of every K range is therefore taken by
+// 64x64 MACRO tiles (4x4 tiles, lin_far2_*): a macro tile (I2,J2) sums K2 = I2+2 .. J2-2 (in 64-blocks) with each wavefront
+// owning a 32x32 quadrant -- 4 operand tiles feed 4 tile products, 16 KB per 64 tile products per workgroup, a quarter of the
+// traffic -- and the 16-tile kernels add only the remaining <= 2 x 9 blocks next to the tile's row / column block ON TOP of it
+// (read-modify-write).  All operand tiles of the macro range are complete before the first cell of the macro tile is due
+// (spans <= 64(J2-I2)-65 < 64(J2-I2)-63), so far2(D2) is launched with the tile kernel of block diagonal 4*D2-3 (inside) /
+// 4*D2+3 (outside), behind that launch's packing.
+__global__ __launch_bounds__(256) void lin_far_inside_pk(McBatch B, int D, int l2)
 {
     __shared__ double red[4][256];
     const int sq = blockIdx.y;
@@ -327,12 +335,16 @@ __global__ __launch_bounds__(256) void lin_far_inside_pk(McBatch B, int D)
     const int nb = B.nb;
     const double* __restrict__ pk = B.pk + (size_t)sq * kPkCopies * B.pk_stride;
     // FM2F(I,J) = sum_K FM1(I,K) x FM(K,J)
-    const d4 acc = pk_loop(pk + PK_FM1_A * B.pk_stride, pk + PK_FM_B * B.pk_stride, I + 2, J - 2,
-                           [=](int K) { return pk_tile(nb, I, K); }, [=](int K) { return pk_tile(nb, K, J); });
-    reduce_store(red, acc, B.tab + (size_t)sq * B.seq_stride + (size_t)LF_FM2F * B.tab_stride, B.ld, n, I * 16, J * 16);
+    const auto ta = [=](int K) { return pk_tile(nb, I, K); };
+    const auto tb = [=](int K) { return pk_tile(nb, K, J); };
+    const int I2 = I >> 2, J2 = J >> 2;
+    const bool two = l2 && J2 - I2 >= 4;   // K = 4(I2+2) .. 4(J2-1)-1 came from the macro tile
+    d4 acc = pk_loop(pk + PK_FM1_A * B.pk_stride, pk + PK_FM_B * B.pk_stride, I + 2, two ? 4 * (I2 + 2) - 1 : J - 2, ta, tb);
+    if (two) acc = pk_loop(pk + PK_FM1_A * B.pk_stride, pk + PK_FM_B * B.pk_stride, 4 * (J2 - 1), J - 2, ta, tb, acc);
+    reduce_store(red, acc, B.tab + (size_t)sq * B.seq_stride + (size_t)LF_FM2F * B.tab_stride, B.ld, n, I * 16, J * 16, two);
 }
 
-__global__ __launch_bounds__(256) void lin_far_outside_pk(McBatch B, int D)
+__global__ __launch_bounds__(256) void lin_far_outside_pk(McBatch B, int D, int l2)
 {
     __shared__ double red[4][256];
     const int sq = blockIdx.y;
@@ -342,14 +354,104 @@ __global__ __launch_bounds__(256) void lin_far_outside_pk(McBatch B, int D)
     const int nb = B.nb;
     const double* __restrict__ pk = B.pk + (size_t)sq * kPkCopies * B.pk_stride;
     double* __restrict__ tab = B.tab + (size_t)sq * B.seq_stride;
-    if (blockIdx.z == 0) {   // FMOF(I,J) = sum_{K<=I-2} FM1(K,I)^T x FM2o(K,J)
-        const d4 acc = pk_loop(pk + PK_FM1_B * B.pk_stride, pk + PK_FM2O_B * B.pk_stride, 0, I - 2,
+    const int I2 = I >> 2, J2 = J >> 2, last = (n - 1) / 16;
+    if (blockIdx.z == 0) {   // FMOF(I,J) = sum_{K<=I-2} FM1(K,I)^T x FM2o(K,J); K <= 4(I2-1)-1 came from the macro tile
+        const bool two = l2 && I2 >= 2;
+        const d4 acc = pk_loop(pk + PK_FM1_B * B.pk_stride, pk + PK_FM2O_B * B.pk_stride, two ? 4 * (I2 - 1) : 0, I - 2,
                                [=](int K) { return pk_tile(nb, K, I); }, [=](int K) { return pk_tile(nb, K, J); });
-        reduce_store(red, acc, tab + (size_t)LF_FMOF * B.tab_stride, B.ld, n, I * 16, J * 16);
-    } else {                 // FM1OF(I,J) = sum_{K>=J+2} FM2o(I,K) x FM(J,K)^T
-        const d4 acc = pk_loop(pk + PK_FM2O_A * B.pk_stride, pk + PK_FM_A * B.pk_stride, J + 2, (n - 1) / 16,
+        reduce_store(red, acc, tab + (size_t)LF_FMOF * B.tab_stride, B.ld, n, I * 16, J * 16, two);
+    } else {                 // FM1OF(I,J) = sum_{K>=J+2} FM2o(I,K) x FM(J,K)^T; K >= 4(J2+2) came from the macro tile
+        const bool two = l2 && 4 * (J2 + 2) <= last;
+        const d4 acc = pk_loop(pk + PK_FM2O_A * B.pk_stride, pk + PK_FM_A * B.pk_stride, J + 2, two ? 4 * (J2 + 2) - 1 : last,
                                [=](int K) { return pk_tile(nb, I, K); }, [=](int K) { return pk_tile(nb, J, K); });
-        reduce_store(red, acc, tab + (size_t)LF_FM1OF * B.tab_stride, B.ld, n, I * 16, J * 16);
+        reduce_store(red, acc, tab + (size_t)LF_FM1OF * B.tab_stride, B.ld, n, I * 16, J * 16, two);
+    }
+}
+
+// ---- 64x64 macro tiles: wavefront w owns the 32x32 quadrant (rows 2(w>>1).., columns 2(w&1)..) of 16-tiles
+struct Acc4 { d4 c[2][2]; };
+__device__ __forceinline__ void store_quadrant(const Acc4& A, double* __restrict__ T, int ld, int n, int I2, int J2)
+{
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            const int i0 = (4 * I2 + 2 * (w >> 1) + a) * 16, j0 = (4 * J2 + 2 * (w & 1) + b) * 16;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int i = i0 + (lane >> 4) + 4 * r, j = j0 + (lane & 15);
+                if (i >= 1 && i <= j && j <= n - 1) T[(size_t)(j - i) * ld + i] = A.c[a][b][r];
+            }
+        }
+}
+// acc(a,b) += sum_{K = k_lo}^{k_hi} frag(pa + ta(a,K)) x frag(pb + tb(K,b)); the loads of step K+1 are issued before the MFMAs of step K
+template <class TA, class TB>
+__device__ __forceinline__ void far2_loop(Acc4& A, const double* __restrict__ pa, const double* __restrict__ pb, int k_lo, int k_hi, TA ta, TB tb)
+{
+    const int lane = threadIdx.x & 63;
+    if (k_lo > k_hi) return;
+    d4 a0 = *(const d4*)(pa + ta(0, k_lo) + lane * 4), a1 = *(const d4*)(pa + ta(1, k_lo) + lane * 4);
+    d4 b0 = *(const d4*)(pb + tb(k_lo, 0) + lane * 4), b1 = *(const d4*)(pb + tb(k_lo, 1) + lane * 4);
+    for (int K = k_lo; K <= k_hi; K++) {
+        const int Kn = K < k_hi ? K + 1 : K;
+        const d4 na0 = *(const d4*)(pa + ta(0, Kn) + lane * 4), na1 = *(const d4*)(pa + ta(1, Kn) + lane * 4);
+        const d4 nb0 = *(const d4*)(pb + tb(Kn, 0) + lane * 4), nb1 = *(const d4*)(pb + tb(Kn, 1) + lane * 4);
+        A.c[0][0] = mfma4(a0, b0, A.c[0][0]);
+        A.c[0][1] = mfma4(a0, b1, A.c[0][1]);
+        A.c[1][0] = mfma4(a1, b0, A.c[1][0]);
+        A.c[1][1] = mfma4(a1, b1, A.c[1][1]);
+        a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+    }
+}
+
+// inside: FM2F(macro tile (I2, I2+D2)) = sum_{K = 4(I2+2)}^{4(J2-1)-1} FM1(I,K) x FM(K,J) over its 4x4 tiles; grid = (macro tiles, sequences)
+__global__ __launch_bounds__(256) void lin_far2_inside(McBatch B, int D2)
+{
+    const int sq = blockIdx.y;
+    const int n = B.n[sq];
+    const int I2 = blockIdx.x, J2 = I2 + D2;
+    if (J2 * 64 > n - 1) return;
+    const int nb = B.nb, w = threadIdx.x >> 6;
+    const int Ia = 4 * I2 + 2 * (w >> 1), Jb = 4 * J2 + 2 * (w & 1);
+    const double* __restrict__ pk = B.pk + (size_t)sq * kPkCopies * B.pk_stride;
+    Acc4 A;
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) A.c[a][b] = d4{0.0, 0.0, 0.0, 0.0};
+    far2_loop(A, pk + PK_FM1_A * B.pk_stride, pk + PK_FM_B * B.pk_stride, 4 * (I2 + 2), 4 * (J2 - 1) - 1,
+              [=](int a, int K) { return pk_tile(nb, Ia + a, K); }, [=](int K, int b) { return pk_tile(nb, K, Jb + b < nb ? Jb + b : nb - 1); });
+    store_quadrant(A, B.tab + (size_t)sq * B.seq_stride + (size_t)LF_FM2F * B.tab_stride, B.ld, n, I2, J2);
+}
+
+// outside: blockIdx.z = 0: FMOF(macro tile) = sum_{K <= 4(I2-1)-1} FM1(K,I)^T x FM2o(K,J);  1: FM1OF = sum_{K >= 4(J2+2)} FM2o(I,K) x FM(J,K)^T
+__global__ __launch_bounds__(256) void lin_far2_outside(McBatch B, int D2)
+{
+    const int sq = blockIdx.y;
+    const int n = B.n[sq];
+    const int I2 = blockIdx.x, J2 = I2 + D2;
+    if (J2 * 64 > n - 1) return;
+    const int nb = B.nb, w = threadIdx.x >> 6, last = (n - 1) / 16;
+    const int Ia = 4 * I2 + 2 * (w >> 1), Jb = 4 * J2 + 2 * (w & 1);
+    const double* __restrict__ pk = B.pk + (size_t)sq * kPkCopies * B.pk_stride;
+    double* __restrict__ tab = B.tab + (size_t)sq * B.seq_stride;
+    Acc4 A;
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) A.c[a][b] = d4{0.0, 0.0, 0.0, 0.0};
+    const auto cl = [=](int Q) { return Q < nb ? Q : nb - 1; };   // a tile column past the sequence is never stored: any address will do
+    if (blockIdx.z == 0) {
+        if (I2 < 2) return;   // nothing 64 or more to the left: the tile kernel writes these cells
+        far2_loop(A, pk + PK_FM1_B * B.pk_stride, pk + PK_FM2O_B * B.pk_stride, 0, 4 * (I2 - 1) - 1,
+                  [=](int a, int K) { return pk_tile(nb, K, Ia + a); }, [=](int K, int b) { return pk_tile(nb, K, cl(Jb + b)); });
+        store_quadrant(A, tab + (size_t)LF_FMOF * B.tab_stride, B.ld, n, I2, J2);
+    } else {
+        if (4 * (J2 + 2) > last) return;
+        far2_loop(A, pk + PK_FM2O_A * B.pk_stride, pk + PK_FM_A * B.pk_stride, 4 * (J2 + 2), last,
+                  [=](int a, int K) { return pk_tile(nb, Ia + a, K); }, [=](int K, int b) { return pk_tile(nb, cl(Jb + b), K); });
+        store_quadrant(A, tab + (size_t)LF_FM1OF * B.tab_stride, B.ld, n, I2, J2);
     }
 }
 

@@ -44,8 +44,10 @@ template <int KD, int W> __global__ void lin_inside_strip(McBatch B, const LinMo
 template <int KD, int W> __global__ void lin_outside_strip(McBatch B, const LinModel* __restrict__ L, const double* __restrict__ wT, int d0, int f5_hi, int f5_lo, int pin, int* __restrict__ bad);
 __global__ void lin_f5i_tail(McBatch B, const LinModel* __restrict__ L, int jlo);
 __global__ void lin_f5o_head(McBatch B, const LinModel* __restrict__ L, int khi, int klo);
-__global__ void lin_far_inside_pk(McBatch B, int D);
-__global__ void lin_far_outside_pk(McBatch B, int D);
+__global__ void lin_far_inside_pk(McBatch B, int D, int l2);
+__global__ void lin_far_outside_pk(McBatch B, int D, int l2);
+__global__ void lin_far2_inside(McBatch B, int D2);
+__global__ void lin_far2_outside(McBatch B, int D2);
 __global__ void lin_finish(McBatch B, const LinModel* __restrict__ L, double* __restrict__ logz, int* __restrict__ bad);
 template <int W> __global__ void dxl_sweep(DxLinBatch B, const DxLinModel* __restrict__ L, int step, int groups);
 __global__ void dxl_sweep4(DxLinBatch B, const DxLinModel* __restrict__ L, int step, int groups);
@@ -265,6 +267,8 @@ struct rh_ctx {
                                    // (MODE 1/2), 0 = one full launch per diagonal; RH_LOOKAHEAD
     int strip = 3;                 // CONTRAfold linear path: KD = 8 diagonals per launch (mccaskill_strip.hip) with the banded near/far split;
                                    // RH_STRIP=0: the per-diagonal-pair kernels of mccaskill_lin.hip.  Bit 0 = inside sweep, bit 1 = outside sweep
+    int far2 = -1;                 // two-level block products: -1 = by size (nmax >= 768), 0 / 1 forced (RH_FAR2)
+    int far2_next = -1;            // launch-sequence state of far_outside_step
     int strip_w = 8;               // wavefronts per strip workgroup (RH_STRIP_W = 4 | 8)
     int strip_xcd = 1;             // groups of one sequence consecutive on one XCD (RH_STRIP_XCD=0: sequence-major launch order only)
     double* d_wT = nullptr;        // transposed, zero-padded single-branch weights wT[l1][t+1] of the strip kernels
@@ -689,17 +693,26 @@ int launch_mc_vienna(rh_ctx* c, int pin)
 //   outside: far(D) uses FM2o tiles of block diagonals >= D+2 (final before fine diagonal (D+1)*16-1) and FM1/FM tiles of
 //            every block diagonal (the last two are packed when the outside phase starts)
 // returns the number of launches it counts: 1 (the pack launch rides with its product; bench.py adds its traffic to the product's)
+// two-level products (64x64 macro tiles under the 16x16 tile kernels, mccaskill_far.hip) pay from ~12 macro blocks per axis on
+static int far_two_level(const rh_ctx* c, const McBatch& B) { return c->far2 >= 0 ? c->far2 : (B.nmax >= 768 ? 1 : 0); }
+
 static int far_inside_step(rh_ctx* c, const McBatch& B, hipStream_t st, int D, int last_block, int banded = 0)
 {
     if (!c->far_pk) { KLAUNCH(c, 1, lin_far_inside_mfma, dim3(last_block - D + 1, B.ns), dim3(256), st, B, D); return 1; }
+    const int l2 = far_two_level(c, B);
     KLAUNCH(c, 1, lin_pack_tiles, dim3(B.nb - (D - 2), B.ns, 2), dim3(256), st, B, D - 2, 0, banded);
-    KLAUNCH(c, 1, lin_far_inside_pk, dim3(last_block - D + 1, B.ns), dim3(256), st, B, D);
+    if (l2 && (D + 3) % 4 == 0) {   // D = 4*D2-3: every operand tile of macro block diagonal D2 is packed now
+        const int D2 = (D + 3) / 4, last2 = (B.nmax - 1) / 64;
+        if (D2 >= 4 && D2 <= last2) KLAUNCH(c, 1, lin_far2_inside, dim3(last2 - D2 + 1, B.ns), dim3(256), st, B, D2);
+    }
+    KLAUNCH(c, 1, lin_far_inside_pk, dim3(last_block - D + 1, B.ns), dim3(256), st, B, D, l2);
     return 1;
 }
 // repack2: the inside sweep left block diagonal 2 packed in the other form (masked for the banded split / plain for the block split)
 static int far_outside_begin(rh_ctx* c, const McBatch& B, hipStream_t st, int last_block, int banded = 0, bool repack2 = false)
 {
     if (!c->far_pk) return 0;
+    c->far2_next = (B.nmax - 1) / 64;   // macro block diagonals whose 64-block products are still to be launched (descending)
     if (repack2 && last_block - 1 > 2) KLAUNCH(c, 3, lin_pack_tiles, dim3(B.nb - 2, B.ns, 2), dim3(256), st, B, 2, 0, banded);
     for (int Dblk = std::max(2, last_block - 1); Dblk <= last_block; Dblk++)
         KLAUNCH(c, 3, lin_pack_tiles, dim3(B.nb - Dblk, B.ns, 2), dim3(256), st, B, Dblk, 0, banded);
@@ -708,8 +721,14 @@ static int far_outside_begin(rh_ctx* c, const McBatch& B, hipStream_t st, int la
 static int far_outside_step(rh_ctx* c, const McBatch& B, hipStream_t st, int D, int last_block)
 {
     if (!c->far_pk) { KLAUNCH(c, 3, lin_far_outside_mfma, dim3(last_block - D + 1, B.ns, 2), dim3(256), st, B, D); return 1; }
+    const int l2 = far_two_level(c, B);
     if (D + 2 <= last_block) KLAUNCH(c, 3, lin_pack_tiles, dim3(B.nb - (D + 2), B.ns, 1), dim3(256), st, B, D + 2, 1, 0);
-    KLAUNCH(c, 3, lin_far_outside_pk, dim3(last_block - D + 1, B.ns, 2), dim3(256), st, B, D);
+    if (l2) {   // macro block diagonal D2 holds tile block diagonals 4*D2-3 .. 4*D2+3: its products go first, their FM2o tiles (block diagonals >= 4*D2+5) are packed
+        const int last2 = (B.nmax - 1) / 64;
+        for (; c->far2_next >= 0 && 4 * c->far2_next + 3 >= D; c->far2_next--)
+            KLAUNCH(c, 3, lin_far2_outside, dim3(last2 - c->far2_next + 1, B.ns, 2), dim3(256), st, B, c->far2_next);
+    }
+    KLAUNCH(c, 3, lin_far_outside_pk, dim3(last_block - D + 1, B.ns, 2), dim3(256), st, B, D, l2);
     return 1;
 }
 
@@ -1241,7 +1260,7 @@ size_t shape_key(const rh_ctx* c, int which)
         for (size_t v : {(size_t)B.ns, (size_t)B.nmax, (size_t)B.ld, (size_t)B.lds, (size_t)B.tab, (size_t)B.seq, (size_t)B.n,
                          (size_t)B.f5i, (size_t)B.bp, (size_t)B.up, (size_t)c->d_bad, (size_t)c->d_mclogz, (size_t)c->lin_w, (size_t)c->lin_w_in,
                          (size_t)c->lin_bs, (size_t)B.tri_stride, (size_t)c->far_mfma, (size_t)c->max_w, (size_t)c->d_gaps,
-                         (size_t)c->d_hplen, (size_t)B.allow, (size_t)B.pk, (size_t)c->far_pk, (size_t)B.rowp, (size_t)c->lookahead, (size_t)c->strip, (size_t)c->d_wT, (size_t)c->strip_w, (size_t)c->strip_xcd})
+                         (size_t)c->d_hplen, (size_t)B.allow, (size_t)B.pk, (size_t)c->far_pk, (size_t)B.rowp, (size_t)c->lookahead, (size_t)c->strip, (size_t)c->d_wT, (size_t)c->strip_w, (size_t)c->strip_xcd, (size_t)(c->far2 + 2)})
             h = mix(h, v);
     } else {
         const DxLinBatch& X = c->dxl;
@@ -1496,6 +1515,7 @@ rh_ctx* rh_create(int device, int model, const char* param_file)
     if (const char* e = std::getenv("RH_LOOKAHEAD")) c->lookahead = std::atoi(e);
     if (const char* e = std::getenv("RH_STRIP")) c->strip = std::atoi(e);
     if (const char* e = std::getenv("RH_STRIP_W")) c->strip_w = std::atoi(e) == 4 ? 4 : 8;
+    if (const char* e = std::getenv("RH_FAR2")) c->far2 = std::atoi(e);
     if (const char* e = std::getenv("RH_STRIP_XCD")) c->strip_xcd = std::atoi(e);
     if (const char* e = std::getenv("RH_DX_W")) c->dx_w = std::atoi(e);
     if (const char* e = std::getenv("RH_DX_QUAD")) c->dx_quad = std::atoi(e) != 0;

@@ -39,6 +39,11 @@ int main(int argc, char** argv)
     try {
         if (argc < 3) throw std::logic_error("usage");
         const std::string mode = argv[1];
+        if (mode == "bounds") {   // bounds NUM PARTS: the contiguous blocks of the in-process shard (no GPU needed)
+            const int num = std::atoi(argv[2]), parts = argc > 3 ? std::atoi(argv[3]) : 1;
+            for (int k = 0; k < parts; k++) { const auto b = ProbabilityEngine::shard_bounds(num, k, parts); std::printf("%d %d\n", b.first, b.second); }
+            return 0;
+        }
         if (mode == "pfduplex") {
             const double z = pf_duplex(argv[2], argv[3]);
             const size_t n1 = std::strlen(argv[2]), n2 = std::strlen(argv[3]);
