@@ -104,6 +104,7 @@ struct DxLinBatch {
     double pw_in[2];     // (lam*e^eu)^(sd-2) * lam^2 for the two inside diagonals of this launch
     double pw_out[2];    // (lam*e^eu)^(L1+L2-sd) * lam^2 for the two outside diagonals
     double pw4[4];       // dxl_sweep4: (lam*e^eu)^(4*step+k) * lam^2, k = 0..3 (the same for both directions)
+    double pw8[8];       // dxl_strip8: (lam*e^eu)^(8*step+k) * lam^2, k = 0..7
 };
 
 }  // namespace rh

@@ -414,6 +414,171 @@ __global__ __launch_bounds__(256) RH_WPE_DX void dxl_sweep4(DxLinBatch B, const 
     }
 }
 
+// ---------------------------------------------------------------------------------
+// Eight anti-diagonals per launch (the strip form of the McCaskill sweeps, mccaskill_strip.hip, for the duplex).  Launch `step`
+// covers X_k = A + k*fwd, k = 0..7 (inside: A = 2+8*step, fwd = +1; outside: A = Smax-8*step, fwd = -1).  X_k reads rows
+// X_k - fwd*(2+t), t = 0..28, at columns a + dir*(1..t+1):
+//   * the 30 rows A - fwd*r, r = 1..30, are final before the launch and are staged ONCE in LDS (100 columns); on row r the window
+//     of X_k has length r+k-1, all starting at the same column, so one running sum over the row serves all eight diagonals;
+//     the 8 wavefronts deal the rows round-robin and meet through partial sums in LDS (over the dead staging area);
+//   * X_k also reads the strip's own rows k' <= k-2 (kept in LDS, raw and decorated): four time slots, two diagonals each
+//     (wavefronts 2s, 2s+1), an LDS-only barrier in between;
+//   * X_k reaches k-1-k' columns into row k': the valid lanes shrink by up to 6 from the `dir` side, groups advance by 58 columns
+//     and the overlap is recomputed.  Every column 0..n1max+1 of the 8 rows is written (0 where there is no cell).
+__device__ __forceinline__ void lds_barrier_dx() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int WV>
+__device__ __forceinline__ void win_pass8(const double* seg0, const double* __restrict__ lam_pow, bool outside, int sdA, int smax, double acc[8])
+{
+    // rows r = 1 + WV + 8q of wavefront WV; seg0[q*104 + c]: inside column a-36+c (window element l = 1.. at index 36-l), outside
+    // column a+1+c (element l at index l-1)
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int r = 1 + WV + 8 * q;            // compile-time after unrolling
+        if (r > 30) continue;
+        const int row = outside ? sdA + r : sdA - r;
+        if (row >= 2 && row <= smax) {
+            lds_vptr vs = (lds_vptr)(seg0 + q * 104);
+            const int len_max = r + 6 < 29 ? r + 6 : 29;      // longest window any of the 8 diagonals takes from this row
+            double run = 0.0;
+#pragma unroll
+            for (int l = 1; l <= len_max; l++) {
+                run += outside ? vs[l - 1] : vs[36 - l];
+                const int k = l - r + 1, t = l - 1;            // the window of length l belongs to X_k, t = r+k-2 = l-1
+                if (k >= 0 && k < 8 && t >= 3 && t <= 28) acc[k] = fma(lam_pow[t + 2], run, acc[k]);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(512) void dxl_strip8(DxLinBatch B, const DxLinModel* __restrict__ L, int step)
+{
+    constexpr int KD = 8, GS = 58, PAD = 8, CS = 80;
+    __shared__ double seg[8][4][104];        // staged rows; afterwards: partial sums [8 wavefronts][8 diagonals][64]
+    __shared__ double srow[2][KD][CS];        // the strip's own rows: raw, decorated; lane l at index l+PAD
+    const int pr = blockIdx.y;
+    const int L1 = B.n[2 * pr], L2 = B.n[2 * pr + 1];
+    const bool outside = blockIdx.z != 0;
+    const int smax = L1 + L2;
+    const int dir = outside ? 1 : -1, fwd = -dir;
+    const int sdA = outside ? smax - KD * step : 2 + KD * step;
+    if (outside ? sdA < 2 : sdA > smax) return;                 // none of the eight diagonals exists
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    // own lanes: inside (sources at smaller columns) lanes 6..63, outside lanes 0..57
+    const int a0 = outside ? (int)blockIdx.x * GS : (int)blockIdx.x * GS - 6;
+    const int a = a0 + lane;
+    const bool own = outside ? (lane < GS || a0 + GS > B.n1max + 1) : (lane >= 6 || blockIdx.x == 0);
+    const int lda = B.lda;
+    const size_t ts = B.tab_stride;
+    double* __restrict__ tab = B.tab + (size_t)pr * B.pair_stride;
+    const uint8_t* __restrict__ s1 = B.seq + (size_t)(2 * pr) * B.lds;
+    const uint8_t* __restrict__ s2 = B.seq + (size_t)(2 * pr + 1) * B.lds;
+    const double* __restrict__ rawt = tab + (outside ? DL_OUT : DL_IN) * ts + kDxPad;
+    const double* __restrict__ dect = tab + (outside ? DL_OUTX : DL_INX) * ts + kDxPad;
+
+    {   // does this group hold a cell [max(1, sd-L2), min(L1, sd-1)] of any of the eight diagonals?  If not: clear its columns and leave
+        bool has = false;
+#pragma unroll
+        for (int k = 0; k < KD; k++) {
+            const int sd = sdA + k * fwd;
+            has = has || (sd >= 2 && sd <= smax && !(a0 + 63 < (sd - L2 > 1 ? sd - L2 : 1) || a0 > (sd - 1 < L1 ? sd - 1 : L1)));
+        }
+        if (!has) {
+            if (own && a >= 0 && a <= B.n1max + 1) {
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const int r = w + 8 * q, tbl = r >> 3, sd = sdA + (r & 7) * fwd;
+                    if (sd >= 2 && sd <= smax) tab[(tbl ? (outside ? DL_OUTX : DL_INX) : (outside ? DL_OUT : DL_IN)) * ts + (size_t)sd * lda + kDxPad + a] = 0.0;
+                }
+            }
+            return;
+        }
+    }
+    // ---- operands of X_w that come from rows of earlier launches (rows 2, 3, 4 before it while those lie outside the strip)
+    const int sdw = sdA + w * fwd;
+    const bool mine = sdw >= 2 && sdw <= smax;
+    bool pairable = false;
+    DxCellOps o = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (a >= 0 && a <= B.n1max + 1)
+        o = dx_cell_ops(lda, L, rawt, dect, s1, s2, outside, sdw, a, L1, L2, smax, (w < 2 ? 1 : 0) | (w < 3 ? 2 : 0) | (w < 4 ? 4 : 0), &pairable);
+
+    // ---- stage the 30 window rows (columns outside the padded row read as 0: the pads hold zeros, what lies beyond is another row)
+    {
+        const int c0 = outside ? a0 + 1 : a0 - 36;
+        const int cl = c0 + lane, ch = c0 + 64 + lane;           // 104 columns: 64 + 40
+        const bool okl = cl >= -kDxPad && cl <= B.n1max + 1 + kDxPad, okh = lane < 40 && ch >= -kDxPad && ch <= B.n1max + 1 + kDxPad;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int r = 1 + w + 8 * q;
+            const int row = outside ? sdA + r : sdA - r;
+            if (r <= 30 && row >= 2 && row <= smax) {            // wave-uniform
+                const double* __restrict__ rp = dect + (size_t)row * lda;
+                seg[w][q][lane] = okl ? rp[cl] : 0.0;
+                if (lane < 40) seg[w][q][64 + lane] = okh ? rp[ch] : 0.0;
+            }
+        }
+    }
+    for (int k = threadIdx.x; k < 2 * KD * CS; k += 512) (&srow[0][0][0])[k] = 0.0;
+    double acc[KD];
+#pragma unroll
+    for (int k = 0; k < KD; k++) acc[k] = 0.0;
+    switch (w) {   // (each wavefront reads only the rows it staged itself: no barrier needed before the pass)
+#define X(V) case V: win_pass8<V>(&seg[w][0][lane], L->lam_pow, outside, sdA, smax, acc); break;
+        X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+#undef X
+    }
+    __syncthreads();
+    // partial sums meet over the dead staging area, [8 wavefronts][4 diagonals][64] at a time: diagonals 0..3 (read by their owners,
+    // wavefronts 0..3), then diagonals 4..7
+    double* const part = &seg[0][0][0];
+    // ---- chain: slot s finishes X_2s and X_2s+1 (wavefronts 2s, 2s+1)
+    double g = 0.0;
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) part[(w * 4 + k) * 64 + lane] = acc[half * 4 + k];
+        lds_barrier_dx();
+        if ((w >> 2) == half) {
+#pragma unroll
+            for (int q = 0; q < 8; q++) g += part[(q * 4 + (w & 3)) * 64 + lane];
+        }
+        lds_barrier_dx();
+    }
+    auto finish = [&](int k) {
+        // own-row sources: row k' <= k-2 at columns a + dir*(1..t+1), t = k-2-k'
+        double v = 0.0, vx = 0.0;
+        if (mine && pairable) {
+            const int li = PAD + lane;
+            if (k >= 2) o.o_st = srow[0][k - 2][li + dir];
+            if (k >= 3) { o.o_01 = srow[1][k - 3][li + dir]; o.o_10 = srow[1][k - 3][li + 2 * dir]; }
+            if (k >= 4) { o.o_02 = srow[1][k - 4][li + dir]; o.o_11 = srow[1][k - 4][li + 2 * dir]; o.o_20 = srow[1][k - 4][li + 3 * dir]; }
+            for (int kp = 0; kp + 5 <= k; kp++) {
+                const int t = k - 2 - kp;                          // 3 <= t <= 5
+                double run = 0.0;
+                for (int l = 1; l <= t + 1; l++) run += srow[1][kp][li + dir * l];
+                g = fma(L->lam_pow[t + 2], run, g);
+            }
+            dx_cell_value(L, o, outside, B.pw8[k], g, &v, &vx);
+        }
+        srow[0][k][PAD + lane] = v;
+        srow[1][k][PAD + lane] = vx;
+    };
+#pragma unroll
+    for (int sl = 0; sl < 4; sl++) {
+        if ((w >> 1) == sl) finish(w);
+        lds_barrier_dx();
+    }
+    // ---- the 2 x 8 rows go to HBM: row (table, k) by wavefront; every column of the row is rewritten
+    if (own && a >= 0 && a <= B.n1max + 1) {
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int r = w + 8 * q, tbl = r >> 3, k = r & 7, sd = sdA + k * fwd;
+            if (sd >= 2 && sd <= smax)
+                tab[(tbl ? (outside ? DL_OUTX : DL_INX) : (outside ? DL_OUT : DL_IN)) * ts + (size_t)sd * lda + kDxPad + a] = srow[tbl][k][PAD + lane];
+        }
+    }
+}
+
 // Z~ = sum IN~[a,b] * close~(a,b)                                                (DuplexEngine.ipp:1066-1073)
 // two stages, both in a fixed summation order (results do not depend on scheduling): kLzRows anti-diagonals per
 // workgroup, read along the rows of the table (coalesced), then one thread per pair adds the chunks in order.

@@ -51,6 +51,7 @@ __global__ void lin_far2_outside(McBatch B, int D2);
 __global__ void lin_finish(McBatch B, const LinModel* __restrict__ L, double* __restrict__ logz, int* __restrict__ bad);
 template <int W> __global__ void dxl_sweep(DxLinBatch B, const DxLinModel* __restrict__ L, int step, int groups);
 __global__ void dxl_sweep4(DxLinBatch B, const DxLinModel* __restrict__ L, int step, int groups);
+__global__ void dxl_strip8(DxLinBatch B, const DxLinModel* __restrict__ L, int step);
 __global__ void dxvl_sweep4(DxLinBatch B, const VLinModel* __restrict__ L, const VDxLin* __restrict__ D, int step);
 __global__ void dxvl_logz_part(DxLinBatch B, const VLinModel* __restrict__ L, const VDxLin* __restrict__ D, double* __restrict__ zpart,
                                int* __restrict__ cpart, int nchunk);
@@ -259,6 +260,7 @@ struct rh_ctx {
     DxLinModel h_dxlin;
     DxLinBatch dxl = {};
     size_t dxl_layout = 0;         // (lda, rows) signature of the zero-padded table image currently in HBM
+    int dx_strip = 1;              // linear duplex: eight anti-diagonals per launch (dxl_strip8); RH_DX_STRIP=0: four (dxl_sweep4)
     bool dx_quad = true;           // linear duplex: four anti-diagonals per launch (dxl_sweep4, 4 wavefronts per group); RH_DX_QUAD=0: two (dxl_sweep<W>)
     int dx_w = 4;                  // wavefronts per 64-cell group of the linear duplex kernel
     int last_dx_path = 0;
@@ -1177,6 +1179,14 @@ int launch_dx_lin(rh_ctx* c)
     const int steps = smax / 2;
     const int groups = (X.n1max + 2 + 63) / 64;
     const double leu = c->h_dxlin.lam_eu, l2 = c->h_dxlin.lam_pow[2];
+    if (W == 4 && c->dx_quad && c->dx_strip) {   // eight anti-diagonals per launch (dxl_strip8)
+        const int groups8 = (X.n1max + 2 + 57) / 58;
+        for (int t = 0; 8 * t < smax - 1; t++) {
+            for (int k = 0; k < 8; k++) X.pw8[k] = std::pow(leu, 8.0 * t + k) * l2;
+            KLAUNCH(c, 4, dxl_strip8, dim3(groups8, X.np, 2), dim3(512), c->s_dx, X, c->d_dxlin, t);
+            c->n_launch[2]++;
+        }
+    } else
     if (W == 4 && c->dx_quad) {   // four anti-diagonals per launch (dxl_sweep4)
         const int groups4 = (X.n1max + 2 + 61) / 62;
         for (int t = 0; 4 * t < smax - 1; t++) {
@@ -1265,7 +1275,7 @@ size_t shape_key(const rh_ctx* c, int which)
     } else {
         const DxLinBatch& X = c->dxl;
         for (size_t v : {(size_t)X.np, (size_t)X.n1max, (size_t)X.n2max, (size_t)X.lda, (size_t)X.ldd, (size_t)X.tab, (size_t)X.hp,
-                         (size_t)X.seq, (size_t)X.n, (size_t)c->d_zbar, (size_t)c->d_logz, (size_t)c->d_dxbad, (size_t)c->dx_w, (size_t)c->d_zpart, (size_t)c->dx_quad})
+                         (size_t)X.seq, (size_t)X.n, (size_t)c->d_zbar, (size_t)c->d_logz, (size_t)c->d_dxbad, (size_t)c->dx_w, (size_t)c->d_zpart, (size_t)c->dx_quad, (size_t)c->dx_strip})
             h = mix(h, v);
     }
     return h;
@@ -1519,6 +1529,7 @@ rh_ctx* rh_create(int device, int model, const char* param_file)
     if (const char* e = std::getenv("RH_STRIP_XCD")) c->strip_xcd = std::atoi(e);
     if (const char* e = std::getenv("RH_DX_W")) c->dx_w = std::atoi(e);
     if (const char* e = std::getenv("RH_DX_QUAD")) c->dx_quad = std::atoi(e) != 0;
+    if (const char* e = std::getenv("RH_DX_STRIP")) c->dx_strip = std::atoi(e);
     bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&c->s_mc, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&c->s_dx, hipStreamNonBlocking) == hipSuccess &&
               hipMalloc((void**)&c->d_model, sizeof(ScoreModel)) == hipSuccess &&
@@ -1888,7 +1899,7 @@ int rh_batch_kernels(rh_ctx* c, const char* fine[3], const char* far[3], int n_f
     names[1] = ostrip ? (c->strip_w == 4 ? "lin_outside_strip<8, 4>" : "lin_outside_strip<8, 8>") : !c->has_mc ? "" : lin ? ((pairs && (c->lin_w == 4 || c->lin_w == 8)) ? "lin_outside_pair<" + w + ", " + targs + ">" : pre + "outside_diag<" + (vienna ? "8" : w) + ", " + targs + ">")
                                      : vienna ? "mcv_outside_diag" : "mc_outside_diag";
     names[2] = !c->has_dx ? "" : vienna ? (c->hybrid == RH_HYBRID_COFOLD ? (c->last_dx_path == 1 ? "vlin_inside_diag<8, 16, true> + vlin_outside_diag<8, 16, true> (s1+s2)"
-                                                                                         : "mcv_inside_diag + mcv_outside_diag (s1+s2)") : (c->last_dx_path == 1 ? "dxvl_sweep4" : "dxv_sweep_diag")) : c->last_dx_path == 1 ? ((c->dx_quad && c->dx_w != 2 && c->dx_w != 8) ? std::string("dxl_sweep4") : "dxl_sweep<" + std::to_string(c->dx_w == 2 || c->dx_w == 8 ? c->dx_w : 4) + ">") : "dx_sweep_diag";
+                                                                                         : "mcv_inside_diag + mcv_outside_diag (s1+s2)") : (c->last_dx_path == 1 ? "dxvl_sweep4" : "dxv_sweep_diag")) : c->last_dx_path == 1 ? ((c->dx_quad && c->dx_w != 2 && c->dx_w != 8) ? std::string(c->dx_strip ? "dxl_strip8" : "dxl_sweep4") : "dxl_sweep<" + std::to_string(c->dx_w == 2 || c->dx_w == 8 ? c->dx_w : 4) + ">") : "dx_sweep_diag";
     const bool mfma = c->far_mfma && c->lin_bs != 0 && c->lin_bs != 32;
     const std::string fsuf = c->far_pk ? "_pk" : "_mfma";
     names[3] = (c->has_mc && lin && c->n_far[0]) ? (mfma ? "lin_far_inside" + fsuf : "lin_far_inside<" + bs + ">") : "";

@@ -641,14 +641,16 @@ def test_errors_are_reported_not_swallowed(ctx):
 
 
 def test_sweep_organisations_agree(hotlib, oracle, monkeypatch):
-    """The fused two-diagonal sweeps (default), the look-ahead pair of launches, the one-diagonal-per-launch kernels, the
+    """The strips of eight diagonals with the banded near/far split (default), the fused two-diagonal sweeps with the block-aligned
+    split, the look-ahead pair of launches, the one-diagonal-per-launch kernels, strips with four wavefronts per group, strips for
+    one sweep only (mixed masked / plain block-diagonal-2 tiles), two-level block products forced on, the
     block products with / without packed operand tiles and the duplex sweep with four / two anti-diagonals per launch are
     the same arithmetic up to summation order: every variant against
     the CPU oracle at 1e-6 and against the default at 1e-10, on lengths around the 63/64-column group edges and the
     16-letter blocks."""
     import ractip_amd
     rng = np.random.RandomState(5)
-    seqs = [rnd(rng, n) for n in (62, 63, 64, 65, 127, 128, 129, 190, 331)]
+    seqs = [rnd(rng, n) for n in (62, 63, 64, 65, 127, 128, 129, 190, 331, 40, 57, 58, 71, 115)]
     pairs = [(seqs[0], seqs[3]), (seqs[4], seqs[1]), (seqs[7], seqs[8])]
 
     def run(env):
@@ -671,8 +673,9 @@ def test_sweep_organisations_agree(hotlib, oracle, monkeypatch):
         o = oracle.inference(s)
         assert abs(z - o["logZ"]) < 1e-9
         assert_prob_close(bp, o["post"], rel=REL, what="default n=%d" % len(s))
-    for env in ({"RH_LOOKAHEAD": "1"}, {"RH_LOOKAHEAD": "0"}, {"RH_FAR_PK": "0"}, {"RH_LOOKAHEAD": "0", "RH_LIN_W": "8"}, {"RH_LIN_W": "8"},
-                {"RH_DX_W": "8"}, {"RH_DX_QUAD": "0"}):
+    for env in ({"RH_STRIP": "0"}, {"RH_STRIP": "1"}, {"RH_STRIP": "2"}, {"RH_STRIP_W": "4"}, {"RH_STRIP_XCD": "0"}, {"RH_FAR2": "1"},
+                {"RH_STRIP": "0", "RH_FAR2": "1"}, {"RH_STRIP": "0", "RH_LOOKAHEAD": "1"}, {"RH_STRIP": "0", "RH_LOOKAHEAD": "0"}, {"RH_FAR_PK": "0"},
+                {"RH_STRIP": "0", "RH_LOOKAHEAD": "0", "RH_LIN_W": "8"}, {"RH_STRIP": "0", "RH_LIN_W": "8"}, {"RH_DX_W": "8"}, {"RH_DX_QUAD": "0"}):
         got, got_pairs = run(env)
         for (bp, z), (bp0, z0), s in zip(got, base, seqs):
             assert abs(z - z0) < 1e-10, (env, len(s))

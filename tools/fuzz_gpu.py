@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Differential fuzzing on the GPU box: random inputs through the C ABI against the CPU oracles, both models, both
 arithmetic paths, ragged batches, cuts at every offset of the 64-cell groups / 16-letter blocks, random constraints.
-  python tools/fuzz_gpu.py [seconds] [seed] [length scale]"""
+  python tools/fuzz_gpu.py [seconds] [seed] [length scale] [cf]      (cf: CONTRAfold pair batches only)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -12,6 +12,7 @@ from _oracle import Oracle, ViennaOracle, assert_prob_close
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 SCALE = int(sys.argv[3]) if len(sys.argv) > 3 else 1   # multiplies the length ranges (3: up to 540 letters, many block-product tiles)
+ONLY_CF = len(sys.argv) > 4 and sys.argv[4] == "cf"
 cf, vo = Oracle(), ViennaOracle()
 V = ractip_amd.hot.RH_MODEL_VIENNA_BL
 ctxs = {("cf", m): ractip_amd.Context(device=0) for m in (0, 1)}
@@ -37,13 +38,17 @@ def rand_constraint(s):
 
 t0, cases = time.time(), 0
 while time.time() - t0 < budget:
-    kind = rng.randint(5)
+    kind = 0 if ONLY_CF else rng.randint(5)
     m = rng.randint(2)
     gc = rng.choice([0.3, 0.5, 0.7])
     if kind == 0:      # CONTRAfold ragged pair batch
         pairs = [(rnd(rng.randint(1, 180 * SCALE), gc), rnd(rng.randint(1, 180 * SCALE), gc)) for _ in range(rng.randint(1, 5))]
         c = ctxs[("cf", m)]
         c.batch_upload(pairs); c.batch_compute()
+        if m == 0:   # ordinary sequences must stay on the linear path: a fallback here would hide a kernel bug behind the log-space result
+            assert c.last_path() == 1, ("silent McCaskill fallback", c.batch_fallbacks(0), pairs)
+            # (the duplex of a ~1000-nt 70 % GC sequence can legitimately leave the double range at its fixed scale: per-pair fallback)
+            assert c.last_hybrid_path() == 1 or gc > 0.6, ("silent duplex fallback", c.batch_fallbacks(1), pairs)
         for p, (s1, s2) in enumerate(pairs):
             r = c.batch_results(p)
             o1, o2, od = cf.inference(s1), cf.inference(s2), cf.duplex(s1, s2)
