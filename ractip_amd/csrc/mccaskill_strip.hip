@@ -69,9 +69,24 @@ extern "C" int rh_debug_stamps(unsigned long long* out, int reset)
     if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)) != hipSuccess) return -1; }
     return 0;
 }
+#define RH_NOSTAMP(k) do { } while (0)
+#define RH_NOSTAMP_BEGIN() do { } while (0)
+#if RH_STAMPS == 2   // -DRH_STAMPS=2: the outside kernel's phases, -DRH_STAMPS=1: the inside kernel's
+#define RH_STAMPO(k) RH_STAMP(k)
+#define RH_STAMPO_BEGIN() RH_STAMP_BEGIN()
+#define RH_STAMPI(k) RH_NOSTAMP(k)
+#define RH_STAMPI_BEGIN() RH_NOSTAMP_BEGIN()
 #else
-#define RH_STAMP(k) do { } while (0)
-#define RH_STAMP_BEGIN() do { } while (0)
+#define RH_STAMPI(k) RH_STAMP(k)
+#define RH_STAMPI_BEGIN() RH_STAMP_BEGIN()
+#define RH_STAMPO(k) RH_NOSTAMP(k)
+#define RH_STAMPO_BEGIN() RH_NOSTAMP_BEGIN()
+#endif
+#else
+#define RH_STAMPI(k) do { } while (0)
+#define RH_STAMPI_BEGIN() do { } while (0)
+#define RH_STAMPO(k) do { } while (0)
+#define RH_STAMPO_BEGIN() do { } while (0)
 #endif
 
 enum StripTable { S_FC = 0, S_FCX, S_FCA, S_FM1, S_FM, S_FCO, S_FCOX, S_FM2O, S_FMO, S_FM1O, S_FM2F, S_FMOF, S_FM1OF };
@@ -158,7 +173,7 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_inside_strip(McB
         if (lin >= 256 && lin < 512) for (int q = 0; q < RH_STAGGER; q++) __builtin_amdgcn_s_sleep(127);
     }
 #endif
-    RH_STAMP_BEGIN();
+    RH_STAMPI_BEGIN();
     const int i0 = 1 + slot * GS;
     const int i = i0 + lane;
     const int ic = i < ld ? i : ld - 1;
@@ -301,9 +316,9 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_inside_strip(McB
     }
     for (int k = threadIdx.x; k < (P::RA - NM) * CA; k += 64 * W) LA[NM * CA + k] = 0.0;
     for (int k = threadIdx.x; k < (P::RD - NM) * CD; k += 64 * W) LDm[NM * CD + k] = 0.0;
-    RH_STAMP(0);
+    RH_STAMPI(0);
     __syncthreads();
-    RH_STAMP(1);
+    RH_STAMPI(1);
 
     // ---- pre-phase: the terms whose operands were final before the launch, all KD diagonals
     double acc2[KH], accg[KH];
@@ -340,11 +355,11 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_inside_strip(McB
             for (int k = 0; k < KH; k++) { va[k] = na[k]; vb[k] = nb[k]; }
         }
     }
-    RH_STAMP(2);
+    RH_STAMPI(2);
     double f1[KD - 1];   // FM1[m][i], m = 1..KD-1: low-end operands of the chain's own-row terms (latency hides behind the filter)
 #pragma unroll
     for (int m = 1; m < KD; m++) { const double v = fm1[(unsigned)(m * ld) + (unsigned)i]; f1[m - 1] = i <= n - 1 - m ? v : 0.0; }
-    RH_STAMP(3);
+    RH_STAMPI(3);
     // single-branch filter: staged row rho is table row d0-1-rho = d-2-t with t = rho-1+k for diagonal d0+k; tap l1 reads column
     // i+1+l1 of it.  One LDS read feeds all KD diagonals.  The weight of (row rho, diagonal k, tap l1) is wT[l1][rho+k] (zero where
     // the shape does not exist), so for one tap the 8 rows x 8 diagonals of this wavefront are 36 consecutive entries of the
@@ -394,9 +409,9 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_inside_strip(McB
         p_c10[sl] = L->w10 * r_b10[sl];
         p_c11[sl] = L->w11 * r_11[sl];
     }
-    RH_STAMP(4);
+    RH_STAMPI(4);
     __syncthreads();   // every wavefront is done with the staged rows: the region behind the first KD fixed rows is reused
-    RH_STAMP(5);
+    RH_STAMPI(5);
     double* const PART = lds + P::OFF_PART;
     double* const SFM = lds + P::OFF_S;
     double* const SFM1 = SFM + KD * CS;
@@ -465,7 +480,7 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_inside_strip(McB
         const double fcxv = fc * p_cbx[SL], fcav = fc * p_cba[SL];
         SFM[K * CS + lane] = fmv; SFM1[K * CS + lane] = fm1v; SFCX[K * CS + lane] = fcxv; SFC[K * CS + lane] = fc; SFCA[K * CS + lane] = fcav;
     };
-    RH_STAMP(6);
+    RH_STAMPI(6);
     // time slot T: wavefront T % W finishes step T (fin: the two terms of row T-1 + the epilogue); every later step K > T, on
     // its own wavefront, adds the terms of row T-1, which the previous slot completed
 #define RH_SLOT(T)                                                                                  \
@@ -480,7 +495,7 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_inside_strip(McB
     }
     RH_SLOT(0) RH_SLOT(1) RH_SLOT(2) RH_SLOT(3) RH_SLOT(4) RH_SLOT(5) RH_SLOT(6) RH_SLOT(7)
 #undef RH_SLOT
-    RH_STAMP(7);
+    RH_STAMPI(7);
     lds_barrier();
     // ---- the strip's rows go to HBM now, off the chain: row r = (table, diagonal) by wavefront r % W, columns of this group only
     if (lane < GS) {
@@ -491,7 +506,7 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_inside_strip(McB
             if (i <= n - 1 - d) tab[slot_of[tb] * ts + (size_t)d * ld + i] = SFM[r * CS + lane];
         }
     }
-    RH_STAMP(8);
+    RH_STAMPI(8);
 }
 
 // F5i[jj], jj = jlo .. n, once every row of FCA is final (after the last strip)
@@ -618,7 +633,7 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_outside_strip(Mc
         if (lin >= 256 && lin < 512) for (int q = 0; q < RH_STAGGER; q++) __builtin_amdgcn_s_sleep(127);
     }
 #endif
-    RH_STAMP_BEGIN();
+    RH_STAMPO_BEGIN();
     const int i0 = 1 + slot * GS - (KD - 1);               // lane l <-> column i0+l; lanes >= KD-1 are this group's own columns
     const int i = i0 + lane;
     double* const LDm = lds;                               // fixed FM rows e = 1..
@@ -772,9 +787,9 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_outside_strip(Mc
     }
     for (int k = threadIdx.x; k < KD * CA; k += 64 * W) LA[k] = 0.0;
     for (int k = threadIdx.x; k < (P::RD - NM) * CD; k += 64 * W) LDm[NM * CD + k] = 0.0;
-    RH_STAMP(0);
+    RH_STAMPO(0);
     __syncthreads();
-    RH_STAMP(1);
+    RH_STAMPO(1);
 
     // ---- pre-phase: the terms whose operands were final before the launch, this wavefront's KH diagonals k = kb ..
     double accm[KH], acc1[KH], accg[KH];
@@ -808,11 +823,11 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_outside_strip(Mc
             for (int k = 0; k < KH; k++) { va[k] = na[k]; vb[k] = nb[k]; }
         }
     }
-    RH_STAMP(2);
+    RH_STAMPO(2);
     double f1e[KD - 1];   // FM1[e][i-e], e = 1..KD-1: operands of the chain's own-row FMo terms
 #pragma unroll
     for (int e = 1; e < KD; e++) { const double v = fm1[(unsigned)(e * ld + i - e)]; f1e[e - 1] = (i - e >= 1 && i <= n - 1) ? v : 0.0; }
-    RH_STAMP(3);
+    RH_STAMPO(3);
     // enclosing single-branch loops: staged row rho is table row d0+1+rho = d+2+t with t = rho-1+k for diagonal d0-k; tap l1 reads column
     // i-1-l1 of it (index lane+31-l1).  Weights as in the inside strip: wT[l1][rho+k].
     {
@@ -859,9 +874,9 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_outside_strip(Mc
         p_c10[sl] = L->w10 * r_b10[sl];
         p_c11[sl] = L->w11 * r_11[sl];
     }
-    RH_STAMP(4);
+    RH_STAMPO(4);
     __syncthreads();   // every wavefront is done with the staged rows
-    RH_STAMP(5);
+    RH_STAMPO(5);
     double* const PART = lds + P::OFF_PART;
     double* const SFM2O = lds + P::OFF_S;
     double* const SFMO = SFM2O + KD * CS;
@@ -944,7 +959,7 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_outside_strip(Mc
         SFCO[K * CS + PADL + lane] = fco; SFCOX[K * CS + PADL + lane] = fco * p_tjbx[SL];
         PART[(K * 3) * 64 + lane] = p;   // row (term set 0, diagonal K): consumed by pre<K> before this point
     };
-    RH_STAMP(6);
+    RH_STAMPO(6);
     // time slot T: wavefront T % W finishes step T (fin: the two terms of row T-1 + the epilogue); every later step K > T, on
     // its own wavefront, adds the terms of row T-1, which the previous slot completed
 #define RH_SLOT(T)                                                                                  \
@@ -959,7 +974,7 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_outside_strip(Mc
     }
     RH_SLOT(0) RH_SLOT(1) RH_SLOT(2) RH_SLOT(3) RH_SLOT(4) RH_SLOT(5) RH_SLOT(6) RH_SLOT(7)
 #undef RH_SLOT
-    RH_STAMP(7);
+    RH_STAMPO(7);
     lds_barrier();
     // ---- the strip's rows go to HBM now, off the chain
     if (lane >= KD - 1 && i >= 1) {
@@ -976,7 +991,7 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_outside_strip(Mc
         if (c >= KD - 1 && ii >= 1 && d >= 0 && ii <= n - 1 - d)
             B.bp[(size_t)sq * B.tri_stride + tri_off_s(n, ii) + (ii + d + 1)] = PART[(k * 3) * 64 + c];
     }
-    RH_STAMP(8);
+    RH_STAMPO(8);
 }
 
 template __global__ void lin_inside_strip<8, 4>(McBatch, const LinModel*, const double*, int, int, double, int);

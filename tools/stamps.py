@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""tools/stamps.py [bench args]: per-phase cycle totals of the strip kernels (library built by
-`python tools/build_variant.py stamps -DRH_STAMPS`); prints average cycles per workgroup and phase."""
+"""tools/stamps.py [n [pairs]]: per-phase s_memtime totals of one strip kernel (library built by
+`python tools/build_variant.py stamps -DRH_STAMPS=1` for the inside kernel, `=2` for the outside kernel); prints the
+average ticks per workgroup between consecutive RH_STAMP sites (mccaskill_strip.hip), wavefront 0 of each workgroup."""
 import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -21,8 +22,10 @@ lib.rh_debug_stamps(buf, 1)
 ctx.batch_compute()
 lib.rh_debug_stamps(buf, 1)
 wg = max(1, buf[15])
-names = ["stage loads+lds writes", "barrier", "fm2 pre-phase", "chain operand loads", "filter", "barrier", "partials+barrier", "chain", "", "", "", "", "", "", ""]
 print("workgroups:", wg)
-for k in range(15):
+order = [0, 1, 2, 3, 9, 10, 11, 4, 5, 6, 7, 8, 12, 13, 14]
+tot = sum(buf[k] for k in range(15)) / wg
+for k in order:
     if buf[k]:
-        print("%-28s %10.0f cycles/workgroup (100 MHz ticks x ?)" % (names[k], buf[k] / wg))
+        print("stamp %2d  %10.0f ticks/workgroup  %5.1f %%" % (k, buf[k] / wg, 100.0 * buf[k] / wg / tot))
+print("total     %10.0f" % tot)
