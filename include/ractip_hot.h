@@ -48,6 +48,25 @@ typedef struct rh_ctx rh_ctx;
  * Replaces the per-call engine construction of src/ractip.cpp:199-206, 229-234.
  * Returns NULL on failure; rh_last_error(NULL) then describes why. */
 rh_ctx* rh_create(int device, int model, const char* param_file);
+/* RH_MODEL_VIENNA_BL with the energy tables installed the way RactIP::run installs them (src/ractip.cpp:1563-1567):
+ *   library defaults  ->  copy_boltzmann_parameters() unless --no-bl-param (use_bl_param)  ->  read_parameter_file(param_file).
+ * defaults_file (or NULL): a ViennaRNA parameter file standing for the tables compiled into the user's RNAlib -- ViennaRNA is
+ * not part of the reference, so its built-in Turner tables are not in this library; tables no source provides are ZERO.
+ * param_file (or NULL): the -P file, ViennaRNA "## RNAfold parameter file" (1.x or v2.0 layout) or the flat dump format of
+ * ractip_amd/data/vienna_bl_star.params.  rh_create(dev, RH_MODEL_VIENNA_BL, f) = rh_create_vienna(dev, NULL, 1, f, 0).
+ * semantics: how the loop energies are evaluated --
+ *   RH_VIENNA_SEM_18: ViennaRNA-1.8 LoopEnergy + dangle sums, the 1.8 branch of src/pf_duplex.c:209-433 (all kernels);
+ *   RH_VIENNA_SEM_20: ViennaRNA-2.x E_IntLoop / E_ExtLoop / E_MLstem / E_Hairpin, the HAVE_VIENNA20 branch the reference's
+ *     CMake selects (src/pf_duplex.c:128-206; CMakeLists.txt:28): mismatch_interior_1n / _23, mismatch_exterior / _multi,
+ *     tri/tetra/hexaloop energies replacing the hairpin energy.  Log-space kernels only (rh_set_mode(LINEAR) is refused);
+ *   RH_VIENNA_SEM_AUTO: 2.x if defaults_file or param_file is a v2.0 parameter file, else 1.8.
+ * PARITY UNPINNED in both semantics. */
+#define RH_VIENNA_SEM_AUTO 0
+#define RH_VIENNA_SEM_18 1
+#define RH_VIENNA_SEM_20 2
+rh_ctx* rh_create_vienna(int device, const char* defaults_file, int use_bl_param, const char* param_file, int semantics);
+/* RH_VIENNA_SEM_18 / RH_VIENNA_SEM_20 of a RH_MODEL_VIENNA_BL context, 0 for the CONTRAfold model */
+int rh_vienna_semantics(const rh_ctx* ctx);
 void rh_destroy(rh_ctx* ctx);
 const char* rh_last_error(const rh_ctx* ctx);
 

@@ -1,6 +1,8 @@
-// duplex_vienna.hip -- pf_duplex forward/backward/posterior with BL*/ViennaRNA-1.8 loop energies (PARITY UNPINNED,
-// see vienna_model.h).  Recurrences: /root/reference/src/pf_duplex.c:304-345 (fw), 347-394 (bk, push form -> pulled
-// here), 264-277 (pr_duplex); loop budget MAXLOOP = 30 as in that file (the CONTRAfold DuplexEngine uses 28).
+// duplex_vienna.hip -- pf_duplex forward/backward/posterior with Vienna loop energies in either semantics of vienna_model.h
+// (PARITY UNPINNED): ViennaRNA-1.8 LoopEnergy + dangles, /root/reference/src/pf_duplex.c:304-345 (fw), 347-394 (bk, push form ->
+// pulled here), 264-277 (pr_duplex), or ViennaRNA-2.x E_IntLoop / E_ExtLoop, the same recurrences at :128-166, 168-206, 88-103.
+// The loader folds the difference into the tables (dxE, loop kinds 3 / 4), the kernels do not branch on it.
+// Loop budget MAXLOOP = 30 as in that file (the CONTRAfold DuplexEngine uses 28).
 // Same organisation as duplex.hip: two anti-diagonals per launch, inside and outside in the same launch, one
 // wavefront per pairable cell, log space.  Generic interior loops and long bulges read tables that already carry
 // the source cell's own energy terms (mismatchI resp. TerminalAU); the seven small loop shapes with joint tables
@@ -63,7 +65,7 @@ __global__ __launch_bounds__(256) void dxv_sweep_diag(DxBatch B, const ViennaDx*
     Lse acc = lse_empty();
     if (!outside) {
         if (lane == 0)   // pf_duplex.c:321-326
-            lse_add(acc, V->duplex_init + (i > 1 ? V->dangle5[type * 5 + xm] : 0.0) + (j < L2 ? V->dangle3[type * 5 + yp] : 0.0) + tau_here);
+            lse_add(acc, V->duplex_init + V->dxE[type * 36 + (i > 1 ? xm : 5) * 6 + (j < L2 ? yp : 5)]);
         double xs[kMcShapeIters];
 #pragma unroll
         for (int u = 0; u < kMcShapeIters; u++) {
@@ -77,7 +79,10 @@ __global__ __launch_bounds__(256) void dxv_sweep_diag(DxBatch B, const ViennaDx*
                 else if (kind == 2) xs[u] = tab[V_INTAU * ts + kl] + sh.score + tau_here;
                 else {
                     const int t2 = V->ptype[s1[k] * 5 + s2[l]];
-                    if (t2) xs[u] = tab[V_IN * ts + kl] + vienna_small_loop(V, sh.l1, sh.l2, t2, rt, s1[k + 1], s2[l - 1], xm, yp);
+                    if (t2 && kind >= 3) {   // 2.x E_IntLoop: 1xn loops score mismatch1nI, 2x3 loops mismatch23I (pf_duplex.c:153)
+                        const double* __restrict__ mm = kind == 3 ? V->mm1nI : V->mm23I;
+                        xs[u] = tab[V_IN * ts + kl] + sh.score + mm[t2 * 25 + s1[k + 1] * 5 + s2[l - 1]] + mm[rt * 25 + yp * 5 + xm];
+                    } else if (t2) xs[u] = tab[V_IN * ts + kl] + vienna_small_loop(V, sh.l1, sh.l2, t2, rt, s1[k + 1], s2[l - 1], xm, yp);
                 }
             }
         }
@@ -86,7 +91,7 @@ __global__ __launch_bounds__(256) void dxv_sweep_diag(DxBatch B, const ViennaDx*
         if (lane == 0) { tab[V_IN * ts + ij] = v; tab[V_INMM * ts + ij] = v + mm_up; tab[V_INTAU * ts + ij] = v + tau_here; }
     } else {
         if (lane == 0)   // pf_duplex.c:361-365 (close term)
-            lse_add(acc, (i < L1 ? V->dangle3[rt * 5 + xp] : 0.0) + (j > 1 ? V->dangle5[rt * 5 + ym] : 0.0) + tau_here);
+            lse_add(acc, V->dxE[rt * 36 + (j > 1 ? ym : 5) * 6 + (i < L1 ? xp : 5)]);
         double xs[kMcShapeIters];
 #pragma unroll
         for (int u = 0; u < kMcShapeIters; u++) {
@@ -100,7 +105,10 @@ __global__ __launch_bounds__(256) void dxv_sweep_diag(DxBatch B, const ViennaDx*
                 else if (kind == 2) xs[u] = tab[V_OUTTAU * ts + kl] + sh.score + tau_here;
                 else {
                     const int t2 = V->ptype[s1[ii] * 5 + s2[jj]];
-                    if (t2) xs[u] = tab[V_OUT * ts + kl] + vienna_small_loop(V, sh.l1, sh.l2, type, V->rtype[t2], xp, ym, s1[ii - 1], s2[jj + 1]);
+                    if (t2 && kind >= 3) {
+                        const double* __restrict__ mm = kind == 3 ? V->mm1nI : V->mm23I;
+                        xs[u] = tab[V_OUT * ts + kl] + sh.score + mm[type * 25 + xp * 5 + ym] + mm[V->rtype[t2] * 25 + s2[jj + 1] * 5 + s1[ii - 1]];
+                    } else if (t2) xs[u] = tab[V_OUT * ts + kl] + vienna_small_loop(V, sh.l1, sh.l2, type, V->rtype[t2], xp, ym, s1[ii - 1], s2[jj + 1]);
                 }
             }
         }
@@ -125,8 +133,7 @@ __global__ __launch_bounds__(1024) void dxv_logz(DxBatch B, const ViennaDx* __re
         const int type = V->ptype[s1[i] * 5 + s2[j]];
         if (!type) continue;
         const int rt = V->rtype[type];
-        lse_add(acc, in[(size_t)i * B.ldd + j] + (i < L1 ? V->dangle3[rt * 5 + s1[i + 1]] : 0.0) + (j > 1 ? V->dangle5[rt * 5 + s2[j - 1]] : 0.0) +
-                         (type > 2 ? V->tau : 0.0));
+        lse_add(acc, in[(size_t)i * B.ldd + j] + V->dxE[rt * 36 + (j > 1 ? s2[j - 1] : 5) * 6 + (i < L1 ? s1[i + 1] : 5)]);
     }
     const double M1 = wave_max(acc.m);
     const double S1 = wave_sum(acc.s * exp(acc.m - M1));

@@ -1,5 +1,6 @@
-// mccaskill_vienna.hip -- McCaskill inside / outside / posterior and region accessibility with the BL* energy tables
-// in the pf_fold / pf_unstru semantics of ViennaRNA 1.8 (PARITY UNPINNED, see vienna_model.h and DESIGN.md).
+// mccaskill_vienna.hip -- McCaskill inside / outside / posterior and region accessibility with the Vienna energy tables
+// in the pf_fold / pf_unstru semantics of ViennaRNA 1.8 or, with the tables built for it (stemE / stemM, loop kinds 3 / 4,
+// tri / hexaloops: vienna_model.h), of ViennaRNA 2.x with dangles = 2 (PARITY UNPINNED, see vienna_model.h and DESIGN.md).
 //
 // What it replaces: the third-party calls of RactIP::rnafold, /root/reference/src/ractip.cpp:288-304, 351-367
 // (pf_fold + export_bppm -> bp) and :370-375 (pf_unstru -> up[i][w] = H+I+M+E = P(i..i+w unpaired)).
@@ -59,14 +60,16 @@ __device__ __forceinline__ int shape_index(int l1, int l2) { return l1 * 31 - l1
 __device__ __forceinline__ double hairpin_w(const ViennaDx* V, const uint8_t* s, int a, int u, int type)
 {
     double e = u <= 30 ? V->hairpin[u] : V->hairpin30 - V->lxc * log(u / 30.0);
-    if (u == 3) return e + (type > 2 ? V->tau : 0.0);
-    if (u == 4) {
+    if (u == 3 || u == 4 || u == 6) {   // tabulated loops: the table holds a bonus (1.8) or the difference to the plain energy (2.x)
         int code = 0;
         bool ok = true;
-#pragma unroll
-        for (int k = 0; k < 6; k++) { const int c = s[a + k]; ok = ok && c != 0; code = code * 4 + (c - 1); }
-        if (ok) e += V->tetra[code];
+        for (int k = 0; k < u + 2; k++) { const int c = s[a + k]; ok = ok && c != 0; code = code * 4 + (c - 1); }
+        if (ok && u == 3) e += V->tri[code];
+        if (ok && u == 4) e += V->tetra[code];
+        if (ok && u == 6)
+            for (int k = 0; k < V->nhexa; k++) if (V->hexa_code[k] == code) e += V->hexa[k];
     }
+    if (u == 3) return e + (type > 2 ? V->tau : 0.0);
     return e + V->mmH[type * 25 + s[a + 1] * 5 + s[a + u]];
 }
 
@@ -79,6 +82,8 @@ __device__ __forceinline__ double loop_w(const ViennaDx* V, int l1, int l2, int 
     const int rti = V->rtype[ti];
     if (kind == 1) return V->shape[idx].score + V->mmI[to * 25 + a1 * 5 + b1] + V->mmI[rti * 25 + q1 * 5 + p1];
     if (kind == 2) return V->shape[idx].score + (to > 2 ? V->tau : 0.0) + (ti > 2 ? V->tau : 0.0);
+    if (kind == 3) return V->shape[idx].score + V->mm1nI[to * 25 + a1 * 5 + b1] + V->mm1nI[rti * 25 + q1 * 5 + p1];
+    if (kind == 4) return V->shape[idx].score + V->mm23I[to * 25 + a1 * 5 + b1] + V->mm23I[rti * 25 + q1 * 5 + p1];
     return vienna_small_loop(V, l1, l2, to, rti, a1, b1, p1, q1);
 }
 
@@ -173,7 +178,8 @@ __global__ __launch_bounds__(256) void mcv_inside_diag(McBatch B, const ViennaDx
     if (inner) {
         // a multiloop element may not touch the missing gap: a branch checks the gaps on both of its sides, an
         // unpaired letter the two gaps next to it
-        if (gap_ok(cut, i) && gap_ok(cut, j)) op_fca = tab[VM_FCA * ts + (size_t)(i + 1) * ld + (j - 1)];
+        if (gap_ok(cut, i) && gap_ok(cut, j))   // the branch (i+1, j) as a multiloop stem: its neighbours s[i], s[j+1] both exist
+            op_fca = tab[VM_FC * ts + (size_t)(i + 1) * ld + (j - 1)] + V->stemM[V->ptype[s_ip1 * 5 + s_j] * 25 + s_i * 5 + s_jp1];
         if (gap_ok(cut, i) && gap_ok(cut, i + 1)) op_fm1 = tab[VM_FM1 * ts + (size_t)(i + 1) * ld + j];
         if (gap_ok(cut, j - 1) && gap_ok(cut, j)) op_fms = tab[VM_FMST * ts + (size_t)(j - 1) * ld + i];
     }
@@ -197,7 +203,10 @@ __global__ __launch_bounds__(256) void mcv_inside_diag(McBatch B, const ViennaDx
                 else {
                     const int t2 = V->ptype[s[p] * 5 + s[q]];
                     if (kind == 2) x[u] = tab[VM_FC * ts + at] + sh.score + tau_here + (t2 > 2 ? V->tau : 0.0);
-                    else x[u] = tab[VM_FC * ts + at] + vienna_small_loop(V, sh.l1, sh.l2, type, V->rtype[t2], s_ip1, s_j, s[p - 1], s[q + 1]);
+                    else if (kind >= 3) {   // 2.x: 1xn / 2x3 loops have their own mismatch tables
+                        const double* __restrict__ mm = kind == 3 ? V->mm1nI : V->mm23I;
+                        x[u] = tab[VM_FC * ts + at] + sh.score + mm[type * 25 + s_ip1 * 5 + s_j] + mm[V->rtype[t2] * 25 + s[q + 1] * 5 + s[p - 1]];
+                    } else x[u] = tab[VM_FC * ts + at] + vienna_small_loop(V, sh.l1, sh.l2, type, V->rtype[t2], s_ip1, s_j, s[p - 1], s[q + 1]);
                 }
             }
         }
@@ -207,7 +216,7 @@ __global__ __launch_bounds__(256) void mcv_inside_diag(McBatch B, const ViennaDx
         if (!nick_in) lse_add(acc_c, hairpin_w(V, s, i, d, type));
         else   // the loop that holds the missing gap: two exterior-loop halves and the pair's own dangles
             lse_add(acc_c, B.xs[(size_t)sq * ld + i + 1] + B.xp[(size_t)sq * ld + j] +
-                               V->d3x[rt * 5 + (gap_ok(cut, i) ? s_ip1 : 0)] + V->d5x[rt * 5 + (gap_ok(cut, j) ? s_j : 0)]);
+                               V->stemE[rt * 25 + (gap_ok(cut, j) ? s_j : 0) * 5 + (gap_ok(cut, i) ? s_ip1 : 0)]);
     }
 
     // ---- FM2[i,j] = (+)_{i<k<j} FM1[i,k] + FM[k,j]
@@ -218,7 +227,7 @@ __global__ __launch_bounds__(256) void mcv_inside_diag(McBatch B, const ViennaDx
     double fm2, fc;
     lse_wave_finish2(acc_2, acc_c, fm2, fc);
     // multiloop closed by (i,j+1): expMLclosing * expMLintern[tt] * expdangle3[tt][S[i+1]] * expdangle5[tt][S[j]]
-    fc = pairable ? lse2(fc, fm2 + V->ml_close + V->d3x[rt * 5 + s_ip1] + V->d5x[rt * 5 + s_j]) : kNeg;
+    fc = pairable ? lse2(fc, fm2 + V->ml_close + V->stemM[rt * 25 + s_j * 5 + s_ip1]) : kNeg;
 
     double fm1 = kNeg, fms = kNeg, fm = kNeg;
     if (inner) {
@@ -231,7 +240,7 @@ __global__ __launch_bounds__(256) void mcv_inside_diag(McBatch B, const ViennaDx
         const size_t ij = (size_t)i * ld + j, ji = (size_t)j * ld + i;
         // as the enclosed pair of a generic loop: mismatchI[rtype][S[q+1]][S[p-1]]; as a stem: dangles on both sides
         const double dec_x = V->mmI[rt * 25 + s_jp2 * 5 + s_im1];
-        const double dec_a = V->d5x[type * 5 + (gap_ok(cut, i - 1) ? s_im1 : 0)] + V->d3x[type * 5 + (gap_ok(cut, j + 1) ? s_jp2 : 0)];
+        const double dec_a = V->stemE[type * 25 + (gap_ok(cut, i - 1) ? s_im1 : 0) * 5 + (gap_ok(cut, j + 1) ? s_jp2 : 0)];
         tab[VM_FC * ts + ij] = fc;
         tab[VM_FCX * ts + ij] = pairable ? fc + dec_x : kNeg;
         const double fca = pairable ? fc + dec_a : kNeg;
@@ -278,7 +287,7 @@ __global__ __launch_bounds__(256) void mcv_outside_diag(McBatch B, const ViennaD
             const int t = V->ptype[s[i] * 5 + s[b + 1]];
             if (!t || b + 1 - i < 4) continue;
             const int rt = V->rtype[t];
-            lse_add(acc, fcot[i] + xs[i + 1] + V->d3x[rt * 5 + (gap_ok(cut, i) ? s[i + 1] : 0)] + V->d5x[rt * 5 + (gap_ok(cut, b) ? s[b] : 0)]);
+            lse_add(acc, fcot[i] + xs[i + 1] + V->stemE[rt * 25 + (gap_ok(cut, b) ? s[b] : 0) * 5 + (gap_ok(cut, i) ? s[i + 1] : 0)]);
         }
         lse_stream2<4>(acc, xpo + 1, tab + VM_FCA * ts + (size_t)(b + 1) * ld, b + 1, n, lane);
         if (lane == 0) lse_add(acc, xpo[b + 1]);
@@ -298,7 +307,7 @@ __global__ __launch_bounds__(256) void mcv_outside_diag(McBatch B, const ViennaD
             const int t = V->ptype[s[a - 1] * 5 + s[j + 1]];
             if (!t || j + 1 - (a - 1) < 4) continue;
             const int rt = V->rtype[t];
-            lse_add(acc, fco[j] + xp[j] + V->d3x[rt * 5 + (gap_ok(cut, a - 1) ? s[a] : 0)] + V->d5x[rt * 5 + (gap_ok(cut, j) ? s[j] : 0)]);
+            lse_add(acc, fco[j] + xp[j] + V->stemE[rt * 25 + (gap_ok(cut, j) ? s[j] : 0) * 5 + (gap_ok(cut, a - 1) ? s[a] : 0)]);
         }
         if (a >= 3) lse_stream2<4>(acc, xso, tab + VM_FCAT * ts + (size_t)(a - 2) * ld, 1, a - 1, lane);   // a' = 1..a-2
         if (lane == 0) lse_add(acc, xso[a - 1]);
@@ -344,7 +353,7 @@ __global__ __launch_bounds__(256) void mcv_outside_diag(McBatch B, const ViennaD
 
     // ---- enclosing loops: outer pair (i-1-l1, j+2+l2) [letters], gap cell (i-1-l1, j+1+l2)
     Lse acc_c = lse_empty();
-    const double dec_a = V->d5x[type * 5 + (gap_ok(cut, i - 1) ? s_im1 : 0)] + V->d3x[type * 5 + (gap_ok(cut, j + 1) ? s_jp2 : 0)];
+    const double dec_a = V->stemE[type * 25 + (gap_ok(cut, i - 1) ? s_im1 : 0) * 5 + (gap_ok(cut, j + 1) ? s_jp2 : 0)];
     if (pairable) {
         const double dec_in = V->mmI[rt * 25 + s_jp2 * 5 + s_im1];
         const int l1max = i - 2, l2max = n - 2 - j;
@@ -362,7 +371,10 @@ __global__ __launch_bounds__(256) void mcv_outside_diag(McBatch B, const ViennaD
                     else {
                         const int to = V->ptype[s[io] * 5 + s[jo + 1]];
                         if (kind == 2) x[u] = tab[VM_FCO * ts + at] + sh.score + tau_here + (to > 2 ? V->tau : 0.0);
-                        else x[u] = tab[VM_FCO * ts + at] + vienna_small_loop(V, sh.l1, sh.l2, to, rt, s[io + 1], s[jo], s_im1, s_jp2);
+                        else if (kind >= 3) {
+                            const double* __restrict__ mm = kind == 3 ? V->mm1nI : V->mm23I;
+                            x[u] = tab[VM_FCO * ts + at] + sh.score + mm[to * 25 + s[io + 1] * 5 + s[jo]] + mm[rt * 25 + s_jp2 * 5 + s_im1];
+                        } else x[u] = tab[VM_FCO * ts + at] + vienna_small_loop(V, sh.l1, sh.l2, to, rt, s[io + 1], s[jo], s_im1, s_jp2);
                     }
                 }
             }
@@ -370,7 +382,7 @@ __global__ __launch_bounds__(256) void mcv_outside_diag(McBatch B, const ViennaD
         }
         if (lane == 0) {
             lse_add(acc_c, op_f5o + op_f5i + dec_a);            // stem of the exterior loop
-            lse_add(acc_c, op_fm1o_up + V->mli + dec_a);        // branch of a multiloop
+            lse_add(acc_c, op_fm1o_up + V->mli + V->stemM[type * 25 + s_im1 * 5 + s_jp2]);   // branch of a multiloop (both neighbours exist)
             lse_add(acc_c, op_x + dec_a);
         }
     }
@@ -391,7 +403,7 @@ __global__ __launch_bounds__(256) void mcv_outside_diag(McBatch B, const ViennaD
         fm1o = lse2(fm1o, fmso);              // FMS[i,j] -> FM1[i,j]
     }
     if (!pairable) fco = kNeg;
-    const double viafc = pairable ? fco + V->ml_close + V->d3x[rt * 5 + s_ip1] + V->d5x[rt * 5 + s_j] : kNeg;
+    const double viafc = pairable ? fco + V->ml_close + V->stemM[rt * 25 + s_j * 5 + s_ip1] : kNeg;
     const double fm2o = lse2(fmo, viafc);
 
     if (lane == 0) {

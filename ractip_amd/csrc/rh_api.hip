@@ -251,6 +251,7 @@ struct rh_ctx {
     LinModel* d_lin = nullptr;
     LinModel h_lin;
     ViennaDx* d_vienna = nullptr;  // RH_MODEL_VIENNA_BL only
+    int vienna_sem = 0;            // kViennaSem18 / kViennaSem20 (0: CONTRAfold model)
     VLinModel* d_vlin = nullptr;   // the same model in scaled linear space
     VLinModel* h_vlin = nullptr;
     VLinModel* d_vdxl = nullptr;   // the same tables at the duplex scale (duplex_vlin.hip)
@@ -1472,7 +1473,16 @@ int fetch_hp(rh_ctx* c, int p, double* out, double* logz)
 
 extern "C" {
 
-rh_ctx* rh_create(int device, int model, const char* param_file)
+static rh_ctx* create_ctx(int device, int model, const char* param_file, const char* defaults_file, int use_bl, int semantics);
+
+rh_ctx* rh_create(int device, int model, const char* param_file) { return create_ctx(device, model, param_file, nullptr, 1, 0); }
+rh_ctx* rh_create_vienna(int device, const char* defaults_file, int use_bl_param, const char* param_file, int semantics)
+{
+    return create_ctx(device, RH_MODEL_VIENNA_BL, param_file, defaults_file, use_bl_param, semantics);
+}
+int rh_vienna_semantics(const rh_ctx* c) { return c ? c->vienna_sem : RH_ERR_ARG; }
+
+static rh_ctx* create_ctx(int device, int model, const char* param_file, const char* defaults_file, int use_bl, int semantics)
 {
     if (model != RH_MODEL_CONTRAFOLD && model != RH_MODEL_VIENNA_BL) {
         fail(nullptr, RH_ERR_UNSUPPORTED, "unknown model %d", model);
@@ -1499,9 +1509,9 @@ rh_ctx* rh_create(int device, int model, const char* param_file)
             return nullptr;
         }
     } else {
-        const std::string path = param_file ? std::string(param_file) : default_param_path() + "vienna_bl_star.params";
+        const std::string bl = default_param_path() + "vienna_bl_star.params";
         host_vienna = new ViennaDx;
-        if (!load_vienna_dx(path.c_str(), host_vienna, err, sizeof err)) {
+        if (!load_vienna_dx_ex(defaults_file, use_bl != 0, bl.c_str(), param_file, semantics, host_vienna, err, sizeof err)) {
             delete host_vienna;
             fail(nullptr, RH_ERR_PARAM, "%s", err);
             return nullptr;
@@ -1511,6 +1521,8 @@ rh_ctx* rh_create(int device, int model, const char* param_file)
     rh_ctx* c = new rh_ctx;
     c->device = device; c->model = model;
     c->max_w = model == RH_MODEL_VIENNA_BL ? 15 : 1;   // RactIP's default --max-w (src/cmdline.c:151-186) / contrafold's width 1
+    c->vienna_sem = host_vienna ? host_vienna->semantics : 0;
+    if (c->vienna_sem == kViennaSem20) c->mode = RH_MODE_LOG;   // the scaled linear kernels hold the 1.8 semantics only
     // scale exponent of the linear fast path: log Z per nucleotide of typical sequences under this model
     // (random ACGU: 0.107..0.129 for n = 200..2000); deviations only cost dynamic range, never accuracy
     build_lin_model(host_model, 0.12, &c->h_lin);
@@ -1874,6 +1886,11 @@ int rh_set_mode(rh_ctx* c, int mode)
 {
     if (!c) return RH_ERR_ARG;
     if (mode < RH_MODE_AUTO || mode > RH_MODE_LINEAR) return fail(c, RH_ERR_ARG, "unknown mode %d", mode);
+    if (c->vienna_sem == kViennaSem20) {   // ViennaRNA-2.x semantics: log-space kernels only (AUTO means LOG)
+        if (mode == RH_MODE_LINEAR) return fail(c, RH_ERR_UNSUPPORTED, "RH_VIENNA_SEM_20 runs on the log-space kernels only");
+        c->mode = RH_MODE_LOG;
+        return RH_OK;
+    }
     c->mode = mode;
     return RH_OK;
 }

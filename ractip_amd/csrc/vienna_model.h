@@ -1,4 +1,8 @@
-// vienna_model.h -- BL*/ViennaRNA-1.8-semantics loop energies for the duplex sweeps (PARITY UNPINNED).
+// vienna_model.h -- Vienna loop energies for the duplex and McCaskill sweeps (PARITY UNPINNED), in two semantics:
+//   kViennaSem18: ViennaRNA-1.8 LoopEnergy()/dangles, what the 1.8 branch of pf_duplex.c:209-433 calls (BL* default);
+//   kViennaSem20: ViennaRNA-2.x E_IntLoop / E_ExtLoop / E_MLstem / E_Hairpin (pf_duplex.c:128-206 is written against them):
+//                 mismatch1nI for 1xn loops, mismatch23I for 2x3 loops, mismatchExt / mismatchM instead of dangle sums where
+//                 both neighbours exist, tri/tetra/hexaloop energies that REPLACE the hairpin energy.  Log-space kernels only.
 //
 // Energy tables: /root/reference/src/boltzmann_param.c (BL* values, shipped as data in
 // ractip_amd/data/vienna_bl_star.params); energy function: the ViennaRNA-1.8 LoopEnergy() that the 1.8 branch of
@@ -23,7 +27,8 @@ struct ViennaDx {
     double duplex_init;      // DuplexInit (410, ViennaRNA-1.8 constant)
     double pad_[2];
     Shape shape[kMcShapes];  // row-major (l1,l2), l1+l2 <= 30 (MAXLOOP); score = length-dependent part
-    int kind[kMcShapes];     // 0 = explicit small loop, 1 = generic interior loop, 2 = bulge of length >= 2
+    int kind[kMcShapes];     // 0 = explicit small loop, 1 = generic interior loop, 2 = bulge of length >= 2;
+                             // kViennaSem20 only: 3 = 1xn loop (n >= 3, mismatch1nI), 4 = 2x3 loop (mismatch23I)
     int ptype[25];           // pair type of two nucleotide codes (A,C,G,U = 1..4, other 0): CG=1 GC=2 GU=3 UG=4 AU=5 UA=6
     int rtype[8];
     // ---- McCaskill part: pf_fold semantics of ViennaRNA-1.8 part_func.c (what src/ractip.cpp:288-304, 351-375 calls)
@@ -34,7 +39,23 @@ struct ViennaDx {
     double d5x[8 * 5], d3x[8 * 5];   // smoothed stem dangles; TerminalAU folded into d3x, code 0 = no neighbour
     double ml_close;         // -(ML_closing + ML_intern)
     double mli, mlb;         // -ML_intern, -ML_base
+    // ---- both semantics through the same lookups (built by build_vienna_dx):
+    int semantics;           // kViennaSem18 / kViennaSem20
+    int nhexa;               // entries of hexa_code / hexa
+    double mm1nI[8 * 25], mm23I[8 * 25];   // kViennaSem20: mismatch1nI / mismatch23I[t][a][b] (zero under kViennaSem18: no shape of kind 3 / 4)
+    // exterior-loop term of a duplex end, pf_duplex.c:146,158,185,200 (2.x E_ExtLoop) / :321-326,337-340 (1.8 dangles):
+    // [t*36 + a*6 + b], a = 5' neighbour letter, b = 3' neighbour letter, 5 = there is none; TerminalAU included
+    double dxE[8 * 36];
+    // stem of an exterior loop / of a multiloop in pf_fold: [t*25 + a*5 + b], a = 5' neighbour, b = 3' neighbour, 0 = none (or unknown
+    // letter); TerminalAU included, MLintern not.  1.8: smoothed dangle5 + dangle3 for both; 2.x: mismatchExt / mismatchM where both exist
+    double stemE[8 * 25], stemM[8 * 25];
+    double tri[1024];        // triloop term by 5-letter code (closing pair + 3 loop letters), added to the plain hairpin energy
+    int hexa_code[40];       // hexaloops by 8-letter code, base 4
+    double hexa[40];
+    // special hairpins: under kViennaSem20 the tabulated energy replaces the whole hairpin energy; tetra / tri / hexa hold the
+    // DIFFERENCE to the plain energy of that very loop (fixed by the letters of the code), so the kernels add them in both semantics
 };
+constexpr int kViennaSem18 = 1, kViennaSem20 = 2;
 
 // LoopEnergy for the seven shapes with joint tables (stack, 1-bulges, int11, int21, int22): type = pair type of the
 // pair that closes the loop seen from outside, type_2 = rtype of the other pair; si1/sj1 = the unpaired letters next
@@ -50,6 +71,13 @@ __host__ __device__ inline double vienna_small_loop(const ViennaDx* V, int l1, i
     return V->int22[tt * 625 + ((si1 * 5 + sp1) * 5 + sq1) * 5 + sj1];
 }
 
+// param_file: the flat BL* dump (ractip_amd/data/vienna_bl_star.params), or a ViennaRNA parameter file ("## RNAfold parameter
+// file", 1.x or v2.0 layout); semantics 0 = by the file (v2.0 file -> kViennaSem20, anything else kViennaSem18).
+// defaults_file (may be null): a parameter file read FIRST, i.e. the library's built-in tables that RactIP leaves in place where
+// neither copy_boltzmann_parameters() nor read_parameter_file() writes (src/ractip.cpp:1563-1567); use_bl: install the bundled
+// BL* tables between the two, as RactIP::run does by default.  Tables no source provides stay 0.
+bool load_vienna_dx_ex(const char* defaults_file, bool use_bl, const char* bl_path, const char* param_file, int semantics, ViennaDx* out,
+                       char* err, int errlen);
 bool load_vienna_dx(const char* path, ViennaDx* out, char* err, int errlen);
 
 // ---- the same model in SCALED LINEAR space (mccaskill_vlin.hip): every DP quantity of span d is stored as Q*lam^d

@@ -12,8 +12,12 @@
 // Scoring: RH_MODEL_VIENNA_BL -- the BL* tables that RactIP installs by default
 // (src/boltzmann_param.c, copy_boltzmann_parameters at src/ractip.cpp:1566-1567) evaluated with
 // ViennaRNA-1.8 loop-energy semantics, i.e. the 1.8 branch of src/pf_duplex.c:209-433.  PARITY UNPINNED:
-// ViennaRNA itself is a third-party dependency that is absent and unversioned, and the
-// 2.x branch that the reference's CMake selects needs tables the repository does not hold.
+// ViennaRNA itself is a third-party dependency that is absent and unversioned.
+// The HAVE_VIENNA20 branch (src/pf_duplex.c:128-206, E_ExtLoop / E_IntLoop) needs tables only RNAlib holds; whoever has them
+// selects it through the environment, which stands for the process-global parameter state of the original:
+//   RACTIP_AMD_VIENNA_DEFAULTS = ViennaRNA parameter file with the library's built-in tables (e.g. rna_turner2004.par)
+//   RACTIP_AMD_VIENNA_PARAMS   = the -P file (read_parameter_file, src/ractip.cpp:1567)
+//   RACTIP_AMD_NO_BL_PARAM=1   = --no-bl-param            RACTIP_AMD_VIENNA_SEMANTICS = 1 (1.8) | 2 (2.x); default by the files
 // RACTIP_AMD_DUPLEX_MODEL=contrafold selects the CONTRAfold duplex scores instead (what
 // RactIP::contraduplex computes, src/ractip.cpp:225-245).
 #include <cstdio>
@@ -38,7 +42,13 @@ double pf_duplex(const char* s1, const char* s2)
         const char* dev = std::getenv("RACTIP_AMD_DEVICE");
         const char* mdl = std::getenv("RACTIP_AMD_DUPLEX_MODEL");
         const int model = (mdl && !std::strcmp(mdl, "contrafold")) ? RH_MODEL_CONTRAFOLD : RH_MODEL_VIENNA_BL;
-        g_ctx = rh_create(dev ? std::atoi(dev) : 0, model, nullptr);
+        const char* dflt = std::getenv("RACTIP_AMD_VIENNA_DEFAULTS");
+        const char* par = std::getenv("RACTIP_AMD_VIENNA_PARAMS");
+        const char* nobl = std::getenv("RACTIP_AMD_NO_BL_PARAM");
+        const char* sem = std::getenv("RACTIP_AMD_VIENNA_SEMANTICS");
+        g_ctx = model == RH_MODEL_VIENNA_BL
+                    ? rh_create_vienna(dev ? std::atoi(dev) : 0, dflt, !(nobl && std::atoi(nobl)), par, sem ? std::atoi(sem) : 0)
+                    : rh_create(dev ? std::atoi(dev) : 0, model, nullptr);
         if (!g_ctx) {  // the original aborts inside ViennaRNA's space() on failure; do the same, loudly
             std::fprintf(stderr, "pf_duplex (ractip_amd): %s\n", rh_last_error(nullptr));
             std::abort();

@@ -60,6 +60,14 @@ int main(int argc, char** argv)
             for (const char* p = e; *p;) { devices.push_back(std::atoi(p)); while (*p && *p != ',') ++p; if (*p == ',') ++p; }
         if (devices.empty()) devices.push_back(0);
         ProbabilityEngine en(devices, mode == "contraduplex" ? (float)std::atof(argv[4]) : 0.1f);
+        {   // RactIP's -P / --no-bl-param (src/ractip.cpp:1563-1567), through the environment the pf_duplex shim reads too
+            const char* dflt = std::getenv("RACTIP_AMD_VIENNA_DEFAULTS");
+            const char* par = std::getenv("RACTIP_AMD_VIENNA_PARAMS");
+            const char* nobl = std::getenv("RACTIP_AMD_NO_BL_PARAM");
+            const char* sem = std::getenv("RACTIP_AMD_VIENNA_SEMANTICS");
+            if (dflt || par || nobl || sem)
+                en.set_vienna_parameters(dflt ? dflt : "", !(nobl && std::atoi(nobl)), par ? par : "", sem ? std::atoi(sem) : 0);
+        }
         if (mode == "contrafold") {
             VF bp; VI off; VVF up;
             en.contrafold(argv[2], bp, off, up);

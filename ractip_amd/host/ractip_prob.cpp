@@ -44,12 +44,21 @@ rh_ctx* ProbabilityEngine::vienna() const
 {
     if (!vctx_) {
         for (size_t k = 0; k < devices_.size(); ++k) {
-            if (!vctxs_[k]) vctxs_[k] = rh_create(devices_[k], RH_MODEL_VIENNA_BL, nullptr);
+            if (!vctxs_[k])
+                vctxs_[k] = rh_create_vienna(devices_[k], v_defaults_.empty() ? nullptr : v_defaults_.c_str(), v_use_bl_ ? 1 : 0,
+                                             v_param_.empty() ? nullptr : v_param_.c_str(), v_semantics_);
             if (!vctxs_[k]) throw std::logic_error(std::string("ractip_amd: ") + rh_last_error(nullptr));
         }
         vctx_ = vctxs_[0];
     }
     return vctx_;
+}
+
+void ProbabilityEngine::set_vienna_parameters(const std::string& defaults_file, bool use_bl_param, const std::string& param_file, int semantics)
+{
+    v_defaults_ = defaults_file; v_use_bl_ = use_bl_param; v_param_ = param_file; v_semantics_ = semantics;
+    for (rh_ctx*& c : vctxs_) { if (c) rh_destroy(c); c = nullptr; }
+    vctx_ = nullptr;
 }
 
 std::pair<int, int> ProbabilityEngine::shard_bounds(int num, int k, int parts)

@@ -75,6 +75,13 @@ public:
     std::vector<PairProbabilities> solve_probabilities_default(const std::vector<std::pair<std::string, std::string>>& pairs,
                                                                uint max_w = 15, bool duplex = false) const;
 
+    // the Vienna energy tables as RactIP::run installs them (:1563-1567): copy_boltzmann_parameters() unless use_bl_param_ is
+    // off, then read_parameter_file(param_file_).  defaults_file stands for the tables built into the user's RNAlib (a ViennaRNA
+    // parameter file; ViennaRNA is no part of the reference, so this library has none of its own); semantics: 0 = by the files
+    // (a v2.0 file selects the 2.x loop energies of the HAVE_VIENNA20 build), 1 = ViennaRNA-1.8, 2 = ViennaRNA-2.x (include/
+    // ractip_hot.h, rh_create_vienna).  Takes effect for the Vienna-model members; existing Vienna contexts are rebuilt.
+    void set_vienna_parameters(const std::string& defaults_file, bool use_bl_param, const std::string& param_file, int semantics = 0);
+
     rh_ctx* raw() const { return ctx_; }
     int device_count() const { return (int)devices_.size(); }
     // [lo, hi) of `num` units owned by shard `k` of `parts`: contiguous, sizes differ by at most one (ractip_amd/shard.py)
@@ -94,6 +101,9 @@ private:
     mutable std::vector<rh_ctx*> vctxs_;   // Vienna-BL contexts, same order
     int device_;
     float th_hy_;
+    std::string v_defaults_, v_param_;     // set_vienna_parameters
+    bool v_use_bl_ = true;
+    int v_semantics_ = 0;
 };
 
 // offset[i] = i*(2(L+1)-i-1)/2, size L+1  (src/ractip.cpp:254-257; InferenceEngine.ipp:316)

@@ -19,7 +19,7 @@ EXPORTS = [
     "rh_batch_upload", "rh_batch_compute", "rh_batch_results", "rh_batch_candidates",
     "rh_batch_timings", "rh_batch_device_views", "rh_batch_logz", "rh_batch_candidates_all", "rh_batch_layout",
     "rh_batch_results_all", "rh_set_max_w", "rh_get_max_w", "rh_set_overlap", "rh_batch_kernels", "rh_set_hybrid", "rh_last_hybrid_path", "rh_fold_constrained", "rh_cofold_constrained",
-    "rh_host_alloc", "rh_host_free", "rh_batch_fallbacks",
+    "rh_host_alloc", "rh_host_free", "rh_batch_fallbacks", "rh_create_vienna", "rh_vienna_semantics",
 ]
 
 
@@ -45,6 +45,9 @@ def load_library():
     L = ctypes.CDLL(LIB_PATH)
     vp, cp, ci, dp = ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double)
     L.rh_create.restype = vp
+    L.rh_create_vienna.restype = vp
+    L.rh_create_vienna.argtypes = [ci, cp, ci, cp, ci]
+    L.rh_vienna_semantics.argtypes = [vp]
     L.rh_create.argtypes = [ci, ci, cp]
     L.rh_destroy.restype = None
     L.rh_destroy.argtypes = [vp]
@@ -109,12 +112,25 @@ def tri_offset(n, i):
 class Context:
     """One rh_ctx: one GPU, one host thread."""
 
-    def __init__(self, device=0, model=RH_MODEL_CONTRAFOLD, param_file=None):
+    def __init__(self, device=0, model=RH_MODEL_CONTRAFOLD, param_file=None, vienna=None):
+        """vienna = dict(defaults_file=None, use_bl_param=True, semantics=0): rh_create_vienna (Vienna model only) -- the
+        tables as RactIP::run installs them (library defaults -> BL* -> -P file) and the 1.8 / 2.x loop-energy semantics."""
         self.L = load_library()
-        self.h = self.L.rh_create(device, model, param_file.encode() if param_file else None)
+        enc = lambda x: x.encode() if x else None
+        if vienna is not None:
+            if model != RH_MODEL_VIENNA_BL:
+                raise RhError("vienna= applies to RH_MODEL_VIENNA_BL")
+            self.h = self.L.rh_create_vienna(device, enc(vienna.get("defaults_file")), 1 if vienna.get("use_bl_param", True) else 0,
+                                             enc(param_file), int(vienna.get("semantics", 0)))
+        else:
+            self.h = self.L.rh_create(device, model, enc(param_file))
         if not self.h:
             raise RhError("rh_create failed: %s" % self.L.rh_last_error(None).decode())
         self._pairs = []
+
+    def vienna_semantics(self):
+        """1 = ViennaRNA-1.8 loop energies, 2 = ViennaRNA-2.x (0: CONTRAfold model)."""
+        return self.L.rh_vienna_semantics(self.h)
 
     def close(self):
         if getattr(self, "h", None):

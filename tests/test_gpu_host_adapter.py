@@ -85,6 +85,26 @@ def test_rnaduplex_is_the_vienna_bl_pf_duplex_on_every_entry_point(cli, golden):
     assert np.abs(hb.astype(np.float32) - hp.astype(np.float32)).max() <= 1e-7
 
 
+def test_vienna_2x_semantics_through_the_member_and_the_shim(cli, tmp_path):
+    """the HAVE_VIENNA20 branch of pf_duplex (src/pf_duplex.c:128-206) for whoever has the tables: -P file in the v2.0 layout,
+    --no-bl-param; the member and the source-compatible shim read the same environment (PARITY UNPINNED, oracle/vienna2x.py)"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import vienna2x as v2
+    T = v2.random_tables(31)
+    par = str(tmp_path / "synthetic.par")
+    v2.write_par_v20(par, T)
+    s1, s2 = "GGAUCGAAGGCUAGCAUCG", "CGAUGCUUGCCUAGAUCC"
+    _, _, pr = v2.pf_duplex(T, s1, s2)
+    env = {"RACTIP_AMD_VIENNA_PARAMS": par, "RACTIP_AMD_NO_BL_PARAM": "1"}
+    hp, _ = take(run_env(cli, env, "rnaduplex", s1, s2), 0, "hp")
+    close32(hp, pr, "rnaduplex under 2.x semantics")
+    shim, _ = take(run_env(cli, env, "pfduplex", s1, s2), 1, "hp")
+    close32(shim, pr, "pf_duplex shim under 2.x semantics")
+    hp18, _ = take(run_env(cli, dict(env, RACTIP_AMD_VIENNA_SEMANTICS="1"), "rnaduplex", s1, s2), 0, "hp")
+    assert np.abs(hp18 - hp).max() > 1e-4      # the same tables under the 1.8 loop energies give another matrix
+
+
 def test_in_process_shard_over_a_device_list(cli, golden):
     """ProbabilityEngine over a device list (here the one GPU twice: two contexts, two host threads): contiguous blocks of
     the pairs, results in iteration order -- identical output to the single-context run (src/ractip.cpp:1636-1663)."""
