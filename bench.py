@@ -484,7 +484,7 @@ def main():
             # the other BASELINE configurations, bounded to a few seconds each: config 4 (n = 2000) and config 5 (z-score DP stage)
             also = {}
             try:
-                also["n2000"] = quick_rates(ractip_amd, torch, device_index, random_pairs(32, 2000, seed=12345), 3)
+                also["n2000"] = quick_rates(ractip_amd, torch, device_index, random_pairs(64, 2000, seed=12345), 3)   # 64 pairs: ~60 GB of tables per context
                 from ractip_amd import shard as _shard
                 fa = [l.strip() for l in open(os.path.join(ROOT, "ractip_amd", "data", "config5_OxyS_fhlA.fa")) if not l.startswith(">")]
                 also["zscore_1000_shuffles"] = quick_rates(ractip_amd, torch, device_index, _shard.zscore_shuffles(fa[0], fa[1], 12, 1000, 1), 10)

@@ -66,6 +66,9 @@ struct McBatch {
     double* pk;
     size_t pk_stride;    // doubles per copy = nb*(nb+1)/2 * 256
     int nb;              // 16-blocks per axis = (nmax-1)/16 + 1
+    // two-molecule batch, scaled linear kernels: the one-strand cells of the inside tables were copied from the single-molecule
+    // folds of the same upload (vlin_co_seed), so the inside sweep computes only the groups that touch both strands
+    int seeded;
 };
 constexpr int kPkCopies = 6;
 

@@ -224,6 +224,26 @@ __global__ void vlin_init(McBatch B, int* __restrict__ bad)
     }
 }
 
+// two-molecule batch B (pair p = s1+s2, cut after s1) next to the single-molecule batch S of the same upload (sequences 2p, 2p+1),
+// both in scaled linear space with the same lam: a cell whose letters all lie on one strand has the value it has in that
+// molecule folded alone -- the same recurrences over the same letters, and at a strand end the neighbour letter is "none" in
+// both (FCX differs at the strand ends, where it looks across the gap, but only loops whose side crosses the gap read it there,
+// and those are excluded).  One launch copies the seven inside tables of both triangles.
+__global__ __launch_bounds__(256) void vlin_co_seed(McBatch B, McBatch S)
+{
+    const int p = blockIdx.y, d = blockIdx.x;
+    const int n = B.n[p], n1 = B.cut[p];
+    const int tabs[7] = {VL_FC, VL_FCX, VL_FCB, VL_FCA, VL_FM1, VL_FMS, VL_FM};
+    double* __restrict__ dst = B.tab + (size_t)p * B.seq_stride + (size_t)d * B.ld;
+    for (int strand = 0; strand < 2; strand++) {
+        const int cells = (strand ? n - n1 : n1) - 1 - d, off = strand ? n1 : 0;
+        if (cells < 1) continue;
+        const double* __restrict__ src = S.tab + (size_t)(2 * p + strand) * S.seq_stride + (size_t)d * S.ld;
+        for (int t = 0; t < 7; t++)
+            for (int i = 1 + threadIdx.x; i <= cells; i += 256) dst[tabs[t] * B.tab_stride + off + i] = src[tabs[t] * S.tab_stride + i];
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // inside, diagonal d.  hp_d = lam^d * hairpin length weight of a loop of d unpaired letters.
 // MODE 0: one full launch per diagonal.  MODE 1 / 2 = look-ahead pair (as lin_inside_diag MODE 1 / 2 of mccaskill_lin.hip):
@@ -294,6 +314,10 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) __attribute__((amdgpu_wave
         return;
     }
 
+    if (CUT && B.seeded && cut > 0) {   // cells whose letters all lie on one strand hold the values of that molecule folded alone (vlin_co_seed)
+        const int i0 = 1 + slot * 64, dd = MODE == 1 ? d + 1 : d;   // MODE 1 also feeds diagonal d+1; its MODE 2 launch tests the same dd
+        if (i0 + 63 + dd + 1 <= cut || i0 > cut) return;
+    }
     const int i = 1 + slot * 64 + lane, j = i + d;
     const bool valid = i <= ncell;
     int s_im1 = 0, s_i = 0, s_ip1 = 0, s_j = 0, s_jp1 = 0, s_jp2 = 0;
@@ -642,6 +666,10 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) __attribute__((amdgpu_wave
     }
 
     const int i0 = 1 + slot * 64;
+    // two-molecule form: only the joint pair matrix of letters on DIFFERENT strands is wanted (src/ractip.cpp:451-454), and the
+    // outside value of a span that covers the missing gap depends on spans that cover it too.  A group whose cells all lie on
+    // one strand (letters i..j+1 <= cut, or i > cut; for MODE 1 on both diagonals) is therefore not computed at all: nothing reads it.
+    if (CUT && cut > 0 && (i0 + 63 + d + 1 <= cut || i0 > cut)) return;
     const int i = i0 + lane, j = i + d;
     const bool valid = i <= ncell;
     int s_im1 = 0, s_i = 0, s_ip1 = 0, s_j = 0, s_jp1 = 0, s_jp2 = 0;
@@ -919,9 +947,11 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) __attribute__((amdgpu_wave
     tab[VL_FM1O * ts + at] = fm1o;
     tab[VL_FM2O * ts + at] = fm2o;
     double p = d >= kMinHairpin ? fco * o_fc / o_z : 0.0;
-    if (!(p == p) || p > 1e300) { atomicOr(&bad[sq], 1); p = 0.0; }
+    // (two-molecule form: one-strand cells of a mixed group were computed from spans that were skipped; their values are never read)
+    const bool wanted = !(CUT && cut > 0) || (i <= cut && j + 1 > cut);
+    if (!(p == p) || p > 1e300) { if (wanted) atomicOr(&bad[sq], 1); p = 0.0; }
     p = p > 1.0 ? 1.0 : (p < 0.0 ? 0.0 : p);
-    B.bp[(size_t)sq * B.tri_stride + tri_off_vl(n, i) + (j + 1)] = p;
+    B.bp[(size_t)sq * B.tri_stride + tri_off_vl(n, i) + (j + 1)] = wanted ? p : 0.0;
 }
 
 // logZ = log F5i~[n] + s*n; flags a sequence whose scaled values left the double range

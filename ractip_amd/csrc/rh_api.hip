@@ -78,6 +78,7 @@ __global__ void mcv_acc_gaps(McBatch B, const ViennaDx* __restrict__ V, double* 
 __global__ void mcv_acc_final(McBatch B, const ViennaDx* __restrict__ V, const double* __restrict__ gaps, int max_w);
 __global__ void mcv_finish(McBatch B, double* __restrict__ logz);
 __global__ void vlin_init(McBatch B, int* __restrict__ bad);
+__global__ void vlin_co_seed(McBatch B, McBatch S);
 template <int W, int BS, bool CUT, int MODE> __global__ void vlin_inside_diag(McBatch B, const VLinModel* __restrict__ L, int d, double hp_d, int pin);
 template <int W, int BS, bool CUT, int MODE> __global__ void vlin_outside_diag(McBatch B, const VLinModel* __restrict__ L, int d, int pin, int* __restrict__ bad);
 __global__ void vlin_finish(McBatch B, const VLinModel* __restrict__ L, double* __restrict__ logz, int* __restrict__ bad);
@@ -261,6 +262,7 @@ struct rh_ctx {
     DxLinModel h_dxlin;
     DxLinBatch dxl = {};
     size_t dxl_layout = 0;         // (lda, rows) signature of the zero-padded table image currently in HBM
+    int co_seed = 1;               // Vienna-BL, hp from the two-molecule ensemble: copy the one-strand cells from the single folds (RH_CO_SEED=0: sweep them again)
     int dx_strip = 1;              // linear duplex: eight anti-diagonals per launch (dxl_strip8); RH_DX_STRIP=0: four (dxl_sweep4)
     bool dx_quad = true;           // linear duplex: four anti-diagonals per launch (dxl_sweep4, 4 wavefronts per group); RH_DX_QUAD=0: two (dxl_sweep<W>)
     int dx_w = 4;                  // wavefronts per 64-cell group of the linear duplex kernel
@@ -751,6 +753,7 @@ int launch_mc_vlin(rh_ctx* c, int pin, int phase, bool co)
     const int last_block = BS > 0 ? (B.nmax - 1) / BS : 0;
     if (phase == 0) {
         hipLaunchKernelGGL(vlin_init, dim3((B.ns + 63) / 64), dim3(64), 0, st, B, bad);
+        if (co && B.seeded) hipLaunchKernelGGL(vlin_co_seed, dim3(c->mc.nmax, B.ns), dim3(256), 0, st, B, c->mc);
         for (int d = 0; d <= B.nmax - 1; d++) {
             const int groups = (std::max(B.nmax - 1 - d, 0) + 63) / 64 + extra;
             const double hp_d = c->h_hplen[d];
@@ -1264,7 +1267,7 @@ size_t shape_key(const rh_ctx* c, int which)
         for (size_t v : {(size_t)B.ns, (size_t)B.nmax, (size_t)B.ld, (size_t)B.lds, (size_t)B.tab, (size_t)B.seq, (size_t)B.n, (size_t)B.f5i,
                          (size_t)B.bp, (size_t)c->d_cobad, (size_t)c->lin_bs, (size_t)B.tri_stride, (size_t)c->dx.hp, (size_t)c->dx.logz,
                          (size_t)c->dx.ldd, (size_t)c->dx.tab_stride, (size_t)c->dx.n1max, (size_t)c->dx.n2max, (size_t)B.allow, (size_t)B.pk,
-                         (size_t)c->far_pk, (size_t)B.rowp, (size_t)c->lookahead})
+                         (size_t)c->far_pk, (size_t)B.rowp, (size_t)c->lookahead, (size_t)B.seeded, (size_t)c->mc.tab, (size_t)c->mc.ld})
             h = mix(h, v);
     } else if (which <= 1) {
         const McBatch& B = c->mc;
@@ -1294,17 +1297,25 @@ int compute(rh_ctx* c)
     int rc;
     // duplex first on its own stream: it is independent of the McCaskill sweeps and overlaps them
     HIP_TRY(c, hipEventRecord(c->ev[3], c->s_dx));
-    bool dx_lin_launched = false, co_lin_launched = false;
+    bool dx_lin_launched = false, co_lin_launched = false, co_seed_bad = false, out_from_ev5 = false;
+    // two-molecule sweeps in linear space next to the single-molecule folds of the same pairs (no structure constraints): the cells
+    // on one strand are copied from those folds (vlin_co_seed), so the sweeps over s1+s2 start when their inside tables are final
+    const bool co_seed = c->has_dx && c->has_mc && c->model == RH_MODEL_VIENNA_BL && c->hybrid == RH_HYBRID_COFOLD && c->mode != RH_MODE_LOG &&
+                         c->co_seed && !c->mc.allow && !c->co.allow && c->mc.ns == 2 * c->co.ns;
+    c->co.seeded = co_seed ? 1 : 0;
+    auto launch_co_lin = [&]() -> int {   // scaled linear sweeps over s1+s2; out-of-range values send the batch to the log-space kernels
+        const int cpin = c->co.ns % 8 == 0 ? 1 : 0;
+        const bool far = c->lin_bs != 0;
+        return run_graphed(c, c->g_dx, shape_key(c, 3), c->s_dx, &c->n_launch[2], &c->n_far[2], [&] {
+            int r = far ? launch_mc_vlin<16>(c, cpin, 0, true) : launch_mc_vlin<0>(c, cpin, 0, true);
+            return r ? r : (far ? launch_mc_vlin<16>(c, cpin, 1, true) : launch_mc_vlin<0>(c, cpin, 1, true));
+        });
+    };
     if (c->has_dx && c->model == RH_MODEL_VIENNA_BL && c->hybrid == RH_HYBRID_COFOLD) {
         HIP_TRY(c, hipMemsetAsync(c->d_cobp, 0, sizeof(double) * c->co.tri_stride * c->co.ns, c->s_dx));
         bool co_log = c->mode == RH_MODE_LOG;
-        if (!co_log) {   // scaled linear sweeps over s1+s2; out-of-range values send the batch to the log-space kernels
-            const int cpin = c->co.ns % 8 == 0 ? 1 : 0;
-            const bool far = c->lin_bs != 0;
-            if ((rc = run_graphed(c, c->g_dx, shape_key(c, 3), c->s_dx, &c->n_launch[2], &c->n_far[2], [&] {
-                    int r = far ? launch_mc_vlin<16>(c, cpin, 0, true) : launch_mc_vlin<0>(c, cpin, 0, true);
-                    return r ? r : (far ? launch_mc_vlin<16>(c, cpin, 1, true) : launch_mc_vlin<0>(c, cpin, 1, true));
-                }))) return rc;
+        if (!co_log && !co_seed) {
+            if ((rc = launch_co_lin())) return rc;
             c->last_dx_path = 1;
             co_lin_launched = true;   // its overflow flags are read after the McCaskill stream has been fed (the two overlap)
         }
@@ -1341,6 +1352,17 @@ int compute(rh_ctx* c)
             if ((rc = run_graphed(c, c->g_in, shape_key(c, 0), c->s_mc, &c->n_launch[0], &c->n_far[0],
                                   [&] { return far ? launch_mc_vlin<16>(c, pin, 0, false) : launch_mc_vlin<0>(c, pin, 0, false); }))) return rc;
             HIP_TRY(c, hipEventRecord(c->ev[1], c->s_mc));
+            if (co_seed) {   // the inside tables of both molecules are final behind ev[1]
+                HIP_TRY(c, hipStreamWaitEvent(c->s_dx, c->ev[1], 0));
+                HIP_TRY(c, hipEventRecord(c->ev[3], c->s_dx));
+                if ((rc = launch_co_lin())) return rc;
+                HIP_TRY(c, hipEventRecord(c->ev[4], c->s_dx));
+                c->last_dx_path = 1;
+                co_lin_launched = true;
+                if (!c->overlap) HIP_TRY(c, hipStreamSynchronize(c->s_dx));   // isolated phase timings: nothing else on the device
+            }
+            HIP_TRY(c, hipEventRecord(c->ev[5], c->s_mc));   // start of the outside phase (= ev[1] unless the seeded sweeps ran in between)
+            out_from_ev5 = true;
             if ((rc = run_graphed(c, c->g_out, shape_key(c, 1), c->s_mc, &c->n_launch[1], &c->n_far[1],
                                   [&] { return far ? launch_mc_vlin<16>(c, pin, 1, false) : launch_mc_vlin<0>(c, pin, 1, false); }))) return rc;
             c->last_path = 1;
@@ -1349,10 +1371,11 @@ int compute(rh_ctx* c)
                 HIP_TRY(c, hipMemcpyAsync(bad.data(), c->d_bad, sizeof(int) * c->mc.ns, hipMemcpyDeviceToHost, c->s_mc));
                 HIP_TRY(c, hipStreamSynchronize(c->s_mc));
                 for (int b : bad) log_path |= (b != 0);
-                if (log_path) { c->last_path = 3; c->tables_dirty = true; }
+                if (log_path) { c->last_path = 3; c->tables_dirty = true; co_seed_bad = co_seed; }
             }
         }
         if (log_path) {
+            out_from_ev5 = false;
             c->n_launch[0] = c->n_launch[1] = 0;
             c->n_far[0] = c->n_far[1] = 0;
             HIP_TRY(c, hipEventRecord(c->ev[0], c->s_mc));
@@ -1393,7 +1416,7 @@ int compute(rh_ctx* c)
         std::vector<int> bad(c->co.ns);
         HIP_TRY(c, hipMemcpyAsync(bad.data(), c->d_cobad, sizeof(int) * c->co.ns, hipMemcpyDeviceToHost, c->s_dx));
         HIP_TRY(c, hipStreamSynchronize(c->s_dx));
-        bool redo = false;
+        bool redo = co_seed_bad;   // a molecule left the double range on its own: what was copied from its fold is not usable
         for (int b : bad) redo |= (b != 0);
         if (redo) {   // some pair left the double range: recompute the two-molecule sweeps in log space
             c->tables_dirty = true;
@@ -1432,7 +1455,7 @@ int compute(rh_ctx* c)
     HIP_TRY(c, hipStreamSynchronize(c->s_dx));
     float t01 = 0, t12 = 0, t34 = 0, t02 = 0;
     HIP_TRY(c, hipEventElapsedTime(&t01, c->ev[0], c->ev[1]));
-    HIP_TRY(c, hipEventElapsedTime(&t12, c->ev[1], c->ev[2]));
+    HIP_TRY(c, hipEventElapsedTime(&t12, c->ev[out_from_ev5 && !c->overlap ? 5 : 1], c->ev[2]));
     HIP_TRY(c, hipEventElapsedTime(&t02, c->ev[0], c->ev[2]));
     HIP_TRY(c, hipEventElapsedTime(&t34, c->ev[3], c->ev[4]));
     c->ms[0] = t01; c->ms[1] = t12; c->ms[2] = t34; c->ms[3] = std::max(t02, t34);
@@ -1539,6 +1562,7 @@ static rh_ctx* create_ctx(int device, int model, const char* param_file, const c
     if (const char* e = std::getenv("RH_STRIP_W")) c->strip_w = std::atoi(e) == 4 ? 4 : 8;
     if (const char* e = std::getenv("RH_FAR2")) c->far2 = std::atoi(e);
     if (const char* e = std::getenv("RH_STRIP_XCD")) c->strip_xcd = std::atoi(e);
+    if (const char* e = std::getenv("RH_CO_SEED")) c->co_seed = std::atoi(e);
     if (const char* e = std::getenv("RH_DX_W")) c->dx_w = std::atoi(e);
     if (const char* e = std::getenv("RH_DX_QUAD")) c->dx_quad = std::atoi(e) != 0;
     if (const char* e = std::getenv("RH_DX_STRIP")) c->dx_strip = std::atoi(e);
