@@ -325,6 +325,17 @@ __device__ __forceinline__ d4 pk_loop(const double* __restrict__ pa, const doubl
 // (read-modify-write).  All operand tiles of the macro range are complete before the first cell of the macro tile is due
 // (spans <= 64(J2-I2)-65 < 64(J2-I2)-63), so far2(D2) is launched with the tile kernel of block diagonal 4*D2-3 (inside) /
 // 4*D2+3 (outside), behind that launch's packing.
+
+// two-molecule batch (B.cut): a target tile whose cells all lie on one strand (letters i..j+1 <= cut, or i > cut) is never read --
+// outside: those spans do not enter the joint pair matrix; inside: only when the one-strand cells were copied from the
+// single-molecule folds (B.seeded).  lo_i = first start position, hi_j = last end position of the tile.
+__device__ __forceinline__ bool one_strand_tile(const McBatch& B, int sq, bool inside, int lo_i, int hi_j)
+{
+    if (!B.cut || (inside && !B.seeded)) return false;
+    const int cut = B.cut[sq];
+    return cut > 0 && (hi_j + 1 <= cut || lo_i > cut);
+}
+
 __global__ __launch_bounds__(256) void lin_far_inside_pk(McBatch B, int D, int l2)
 {
     __shared__ double red[4][256];
@@ -332,6 +343,7 @@ __global__ __launch_bounds__(256) void lin_far_inside_pk(McBatch B, int D, int l
     const int n = B.n[sq];
     const int I = blockIdx.x, J = I + D;
     if (J * 16 > n - 1) return;
+    if (one_strand_tile(B, sq, true, I * 16, J * 16 + 15)) return;
     const int nb = B.nb;
     const double* __restrict__ pk = B.pk + (size_t)sq * kPkCopies * B.pk_stride;
     // FM2F(I,J) = sum_K FM1(I,K) x FM(K,J)
@@ -351,6 +363,7 @@ __global__ __launch_bounds__(256) void lin_far_outside_pk(McBatch B, int D, int 
     const int n = B.n[sq];
     const int I = blockIdx.x, J = I + D;
     if (J * 16 > n - 1) return;
+    if (one_strand_tile(B, sq, false, I * 16, J * 16 + 15)) return;
     const int nb = B.nb;
     const double* __restrict__ pk = B.pk + (size_t)sq * kPkCopies * B.pk_stride;
     double* __restrict__ tab = B.tab + (size_t)sq * B.seq_stride;
@@ -412,6 +425,7 @@ __global__ __launch_bounds__(256) void lin_far2_inside(McBatch B, int D2)
     const int n = B.n[sq];
     const int I2 = blockIdx.x, J2 = I2 + D2;
     if (J2 * 64 > n - 1) return;
+    if (one_strand_tile(B, sq, true, I2 * 64, J2 * 64 + 63)) return;
     const int nb = B.nb, w = threadIdx.x >> 6;
     const int Ia = 4 * I2 + 2 * (w >> 1), Jb = 4 * J2 + 2 * (w & 1);
     const double* __restrict__ pk = B.pk + (size_t)sq * kPkCopies * B.pk_stride;
@@ -432,6 +446,7 @@ __global__ __launch_bounds__(256) void lin_far2_outside(McBatch B, int D2)
     const int n = B.n[sq];
     const int I2 = blockIdx.x, J2 = I2 + D2;
     if (J2 * 64 > n - 1) return;
+    if (one_strand_tile(B, sq, false, I2 * 64, J2 * 64 + 63)) return;
     const int nb = B.nb, w = threadIdx.x >> 6, last = (n - 1) / 16;
     const int Ia = 4 * I2 + 2 * (w >> 1), Jb = 4 * J2 + 2 * (w & 1);
     const double* __restrict__ pk = B.pk + (size_t)sq * kPkCopies * B.pk_stride;

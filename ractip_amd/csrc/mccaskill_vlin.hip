@@ -566,6 +566,8 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) __attribute__((amdgpu_wave
         fmsv = fm1v + o_fms * L->w_mu;
         fmv = fm2 + fmsv;
     }
+    // seeded two-molecule sweep: the one-strand cells of a mixed group keep the copied values (their far sums are not computed)
+    if (CUT && B.seeded && cut > 0 && valid && (j + 1 <= cut || i > cut)) return;
     tab[VL_FC * ts + at] = fc;
     tab[VL_FCX * ts + at] = fc * e_txi;
     tab[VL_FCB * ts + at] = fc * e_tau;
