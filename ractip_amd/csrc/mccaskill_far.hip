@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256) void lin_far_inside_pk(McBatch B, int D, int l
     const auto ta = [=](int K) { return pk_tile(nb, I, K); };
     const auto tb = [=](int K) { return pk_tile(nb, K, J); };
     const int I2 = I >> 2, J2 = J >> 2;
-    const bool two = l2 && J2 - I2 >= 4;   // K = 4(I2+2) .. 4(J2-1)-1 came from the macro tile
+    const bool two = l2 > 0 && n >= l2 && J2 - I2 >= 4;   // K = 4(I2+2) .. 4(J2-1)-1 came from the macro tile (l2 = shortest two-level sequence, 0 = none)
     d4 acc = pk_loop(pk + PK_FM1_A * B.pk_stride, pk + PK_FM_B * B.pk_stride, I + 2, two ? 4 * (I2 + 2) - 1 : J - 2, ta, tb);
     if (two) acc = pk_loop(pk + PK_FM1_A * B.pk_stride, pk + PK_FM_B * B.pk_stride, 4 * (J2 - 1), J - 2, ta, tb, acc);
     reduce_store(red, acc, B.tab + (size_t)sq * B.seq_stride + (size_t)LF_FM2F * B.tab_stride, B.ld, n, I * 16, J * 16, two);
@@ -369,12 +369,12 @@ __global__ __launch_bounds__(256) void lin_far_outside_pk(McBatch B, int D, int 
     double* __restrict__ tab = B.tab + (size_t)sq * B.seq_stride;
     const int I2 = I >> 2, J2 = J >> 2, last = (n - 1) / 16;
     if (blockIdx.z == 0) {   // FMOF(I,J) = sum_{K<=I-2} FM1(K,I)^T x FM2o(K,J); K <= 4(I2-1)-1 came from the macro tile
-        const bool two = l2 && I2 >= 2;
+        const bool two = l2 > 0 && n >= l2 && I2 >= 2;
         const d4 acc = pk_loop(pk + PK_FM1_B * B.pk_stride, pk + PK_FM2O_B * B.pk_stride, two ? 4 * (I2 - 1) : 0, I - 2,
                                [=](int K) { return pk_tile(nb, K, I); }, [=](int K) { return pk_tile(nb, K, J); });
         reduce_store(red, acc, tab + (size_t)LF_FMOF * B.tab_stride, B.ld, n, I * 16, J * 16, two);
     } else {                 // FM1OF(I,J) = sum_{K>=J+2} FM2o(I,K) x FM(J,K)^T; K >= 4(J2+2) came from the macro tile
-        const bool two = l2 && 4 * (J2 + 2) <= last;
+        const bool two = l2 > 0 && n >= l2 && 4 * (J2 + 2) <= last;
         const d4 acc = pk_loop(pk + PK_FM2O_A * B.pk_stride, pk + PK_FM_A * B.pk_stride, J + 2, two ? 4 * (J2 + 2) - 1 : last,
                                [=](int K) { return pk_tile(nb, I, K); }, [=](int K) { return pk_tile(nb, J, K); });
         reduce_store(red, acc, tab + (size_t)LF_FM1OF * B.tab_stride, B.ld, n, I * 16, J * 16, two);
@@ -419,10 +419,11 @@ __device__ __forceinline__ void far2_loop(Acc4& A, const double* __restrict__ pa
 }
 
 // inside: FM2F(macro tile (I2, I2+D2)) = sum_{K = 4(I2+2)}^{4(J2-1)-1} FM1(I,K) x FM(K,J) over its 4x4 tiles; grid = (macro tiles, sequences)
-__global__ __launch_bounds__(256) void lin_far2_inside(McBatch B, int D2)
+__global__ __launch_bounds__(256) void lin_far2_inside(McBatch B, int D2, int l2)
 {
     const int sq = blockIdx.y;
     const int n = B.n[sq];
+    if (n < l2) return;   // whether a sequence takes the two-level form depends on its own length only: its bits do not depend on the batch
     const int I2 = blockIdx.x, J2 = I2 + D2;
     if (J2 * 64 > n - 1) return;
     if (one_strand_tile(B, sq, true, I2 * 64, J2 * 64 + 63)) return;
@@ -440,10 +441,11 @@ __global__ __launch_bounds__(256) void lin_far2_inside(McBatch B, int D2)
 }
 
 // outside: blockIdx.z = 0: FMOF(macro tile) = sum_{K <= 4(I2-1)-1} FM1(K,I)^T x FM2o(K,J);  1: FM1OF = sum_{K >= 4(J2+2)} FM2o(I,K) x FM(J,K)^T
-__global__ __launch_bounds__(256) void lin_far2_outside(McBatch B, int D2)
+__global__ __launch_bounds__(256) void lin_far2_outside(McBatch B, int D2, int l2)
 {
     const int sq = blockIdx.y;
     const int n = B.n[sq];
+    if (n < l2) return;
     const int I2 = blockIdx.x, J2 = I2 + D2;
     if (J2 * 64 > n - 1) return;
     if (one_strand_tile(B, sq, false, I2 * 64, J2 * 64 + 63)) return;

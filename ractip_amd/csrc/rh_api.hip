@@ -46,8 +46,8 @@ __global__ void lin_f5i_tail(McBatch B, const LinModel* __restrict__ L, int jlo)
 __global__ void lin_f5o_head(McBatch B, const LinModel* __restrict__ L, int khi, int klo);
 __global__ void lin_far_inside_pk(McBatch B, int D, int l2);
 __global__ void lin_far_outside_pk(McBatch B, int D, int l2);
-__global__ void lin_far2_inside(McBatch B, int D2);
-__global__ void lin_far2_outside(McBatch B, int D2);
+__global__ void lin_far2_inside(McBatch B, int D2, int l2);
+__global__ void lin_far2_outside(McBatch B, int D2, int l2);
 __global__ void lin_finish(McBatch B, const LinModel* __restrict__ L, double* __restrict__ logz, int* __restrict__ bad);
 template <int W> __global__ void dxl_sweep(DxLinBatch B, const DxLinModel* __restrict__ L, int step, int groups);
 __global__ void dxl_sweep4(DxLinBatch B, const DxLinModel* __restrict__ L, int step, int groups);
@@ -698,8 +698,14 @@ int launch_mc_vienna(rh_ctx* c, int pin)
 //   outside: far(D) uses FM2o tiles of block diagonals >= D+2 (final before fine diagonal (D+1)*16-1) and FM1/FM tiles of
 //            every block diagonal (the last two are packed when the outside phase starts)
 // returns the number of launches it counts: 1 (the pack launch rides with its product; bench.py adds its traffic to the product's)
-// two-level products (64x64 macro tiles under the 16x16 tile kernels, mccaskill_far.hip) pay from ~12 macro blocks per axis on
-static int far_two_level(const rh_ctx* c, const McBatch& B) { return c->far2 >= 0 ? c->far2 : (B.nmax >= 768 ? 1 : 0); }
+// two-level products (64x64 macro tiles under the 16x16 tile kernels, mccaskill_far.hip) pay from 6 macro blocks per axis on
+// (measured: n = 200, 300 equal, n = 400 +2 %, n = 500 +4 %, n = 2000 +27 %)
+// returns the length from which a SEQUENCE takes the two-level form (0: no sequence of this batch does)
+static int far_two_level(const rh_ctx* c, const McBatch& B)
+{
+    const int from = c->far2 >= 0 ? (c->far2 ? 1 : 0) : 384;
+    return from > 0 && B.nmax >= from ? from : 0;
+}
 
 static int far_inside_step(rh_ctx* c, const McBatch& B, hipStream_t st, int D, int last_block, int banded = 0)
 {
@@ -708,7 +714,7 @@ static int far_inside_step(rh_ctx* c, const McBatch& B, hipStream_t st, int D, i
     KLAUNCH(c, 1, lin_pack_tiles, dim3(B.nb - (D - 2), B.ns, 2), dim3(256), st, B, D - 2, 0, banded);
     if (l2 && (D + 3) % 4 == 0) {   // D = 4*D2-3: every operand tile of macro block diagonal D2 is packed now
         const int D2 = (D + 3) / 4, last2 = (B.nmax - 1) / 64;
-        if (D2 >= 4 && D2 <= last2) KLAUNCH(c, 1, lin_far2_inside, dim3(last2 - D2 + 1, B.ns), dim3(256), st, B, D2);
+        if (D2 >= 4 && D2 <= last2) KLAUNCH(c, 1, lin_far2_inside, dim3(last2 - D2 + 1, B.ns), dim3(256), st, B, D2, l2);
     }
     KLAUNCH(c, 1, lin_far_inside_pk, dim3(last_block - D + 1, B.ns), dim3(256), st, B, D, l2);
     return 1;
@@ -731,7 +737,7 @@ static int far_outside_step(rh_ctx* c, const McBatch& B, hipStream_t st, int D, 
     if (l2) {   // macro block diagonal D2 holds tile block diagonals 4*D2-3 .. 4*D2+3: its products go first, their FM2o tiles (block diagonals >= 4*D2+5) are packed
         const int last2 = (B.nmax - 1) / 64;
         for (; c->far2_next >= 0 && 4 * c->far2_next + 3 >= D; c->far2_next--)
-            KLAUNCH(c, 3, lin_far2_outside, dim3(last2 - c->far2_next + 1, B.ns, 2), dim3(256), st, B, c->far2_next);
+            KLAUNCH(c, 3, lin_far2_outside, dim3(last2 - c->far2_next + 1, B.ns, 2), dim3(256), st, B, c->far2_next, l2);
     }
     KLAUNCH(c, 3, lin_far_outside_pk, dim3(last_block - D + 1, B.ns, 2), dim3(256), st, B, D, l2);
     return 1;
