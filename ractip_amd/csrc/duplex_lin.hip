@@ -237,25 +237,40 @@ __global__ __launch_bounds__(64 * W) RH_WPE_DX void dxl_sweep(DxLinBatch B, cons
 struct DxCellOps { double o_st, o_01, o_10, o_02, o_11, o_20, e_up, e_dn, e_ends, e_st, e_b01, e_b10, e_11; };
 
 // coefficient part of the operands of cell (sd, a) and the loads of the rows it may take from memory (mask bit k: row sd+dir*(2+k))
-__device__ __forceinline__ DxCellOps dx_cell_ops(int lda, const DxLinModel* __restrict__ L, const double* __restrict__ rawt,
-                                                 const double* __restrict__ dect, const uint8_t* __restrict__ s1, const uint8_t* __restrict__ s2,
-                                                 bool outside, int sd, int a, int L1, int L2, int smax, int rows_mask, bool* pairable)
+// the loads of a cell that depend on nothing but its position: letters and the (up to six) table cells of the rows before it
+struct DxCellRaw { int x, xm, xp, y, ym, yp; double v_st, v_01, v_10, v_02, v_11, v_20; bool incell, ok2, ok3, ok4; };
+__device__ __forceinline__ DxCellRaw dx_cell_loads(int lda, const double* __restrict__ rawt, const double* __restrict__ dect,
+                                                   const uint8_t* __restrict__ s1, const uint8_t* __restrict__ s2, bool outside, int sd, int a,
+                                                   int L1, int L2, int smax, int rows_mask)
 {
-    DxCellOps o = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const int b = sd - a, i = a, j = L2 + 1 - b;
-    const bool incell = sd >= 2 && sd <= smax && a >= 1 && a <= L1 && b >= 1 && b <= L2;
-    *pairable = false;
-    if (!incell) return o;
-    const int x = s1[i], xm = s1[i - 1], xp = s1[i + 1], y = s2[j], ym = s2[j - 1], yp = s2[j + 1];
-    if (!pairs(x, y)) return o;
-    *pairable = true;
+    // Branch-free: every load is issued whatever the cell is (addresses clamped into the tables), so that the letters and the six
+    // table cells travel together and the weight tables follow in ONE more round trip; a load behind `if (!pairs) return` is only
+    // issued once the letters have arrived.  The rows have kDxPad >= 3 columns on both sides.
+    DxCellRaw r;
+    const int b = sd - a;
+    r.incell = sd >= 2 && sd <= smax && a >= 1 && a <= L1 && b >= 1 && b <= L2;
+    const int i = r.incell ? a : 1, j = r.incell ? L2 + 1 - b : 1;
+    r.x = s1[i]; r.xm = s1[i - 1]; r.xp = s1[i + 1]; r.y = s2[j]; r.ym = s2[j - 1]; r.yp = s2[j + 1];
     const int dir = outside ? 1 : -1;     // sources lie at rows sd + dir*(2+t), columns a + dir*(1+l1)
     const int r2 = sd + 2 * dir, r3 = sd + 3 * dir, r4 = sd + 4 * dir;
-    if ((rows_mask & 1) && r2 >= 2 && r2 <= smax) o.o_st = rawt[(size_t)r2 * lda + a + dir];
-    if ((rows_mask & 2) && r3 >= 2 && r3 <= smax) { o.o_01 = dect[(size_t)r3 * lda + a + dir]; o.o_10 = dect[(size_t)r3 * lda + a + 2 * dir]; }
-    if ((rows_mask & 4) && r4 >= 2 && r4 <= smax) {
-        o.o_02 = dect[(size_t)r4 * lda + a + dir]; o.o_11 = dect[(size_t)r4 * lda + a + 2 * dir]; o.o_20 = dect[(size_t)r4 * lda + a + 3 * dir];
-    }
+    r.ok2 = (rows_mask & 1) && r2 >= 2 && r2 <= smax; r.ok3 = (rows_mask & 2) && r3 >= 2 && r3 <= smax; r.ok4 = (rows_mask & 4) && r4 >= 2 && r4 <= smax;
+    const int ac = a < 0 ? 0 : (a > L1 + 1 ? L1 + 1 : a);   // a cell has 1 <= a <= L1; anything else only needs an address inside the row
+    const int q2 = (r.ok2 ? r2 : 2) * lda + ac, q3 = (r.ok3 ? r3 : 2) * lda + ac, q4 = (r.ok4 ? r4 : 2) * lda + ac;   // >= 2*lda: 32-bit unsigned offsets
+    r.v_st = rawt[(unsigned)(q2 + dir)];
+    r.v_01 = dect[(unsigned)(q3 + dir)]; r.v_10 = dect[(unsigned)(q3 + 2 * dir)];
+    r.v_02 = dect[(unsigned)(q4 + dir)]; r.v_11 = dect[(unsigned)(q4 + 2 * dir)]; r.v_20 = dect[(unsigned)(q4 + 3 * dir)];
+    return r;
+}
+// ... and what depends on the letters: is it a pair, and the weights of its loops
+__device__ __forceinline__ DxCellOps dx_cell_weights(const DxLinModel* __restrict__ L, const DxCellRaw& r, bool outside, bool* pairable)
+{
+    DxCellOps o;
+    const int x = r.x, xm = r.xm, xp = r.xp, y = r.y, ym = r.ym, yp = r.yp;
+    const bool pr = r.incell && pairs(x, y);
+    *pairable = pr;
+    o.o_st = pr && r.ok2 ? r.v_st : 0.0;
+    o.o_01 = pr && r.ok3 ? r.v_01 : 0.0; o.o_10 = pr && r.ok3 ? r.v_10 : 0.0;
+    o.o_02 = pr && r.ok4 ? r.v_02 : 0.0; o.o_11 = pr && r.ok4 ? r.v_11 : 0.0; o.o_20 = pr && r.ok4 ? r.v_20 : 0.0;
     o.e_up = L->E_tm[((x * 5 + y) * 5 + xp) * 5 + ym];                          // terminal_mismatch[s1[i]][s2[j]][s1[i+1]][s2[j-1]]
     o.e_dn = L->E_tm[((y * 5 + x) * 5 + yp) * 5 + xm] * L->E_bp[x * 5 + y];     // terminal_mismatch[s2[j]][s1[i]][s2[j+1]][s1[i-1]] * base_pair
     if (!outside) {
@@ -268,6 +283,13 @@ __device__ __forceinline__ DxCellOps dx_cell_ops(int lda, const DxLinModel* __re
         o.e_b01 = L->E_b01[ym]; o.e_b10 = L->E_b10[xp]; o.e_11 = L->E_11[xp * 5 + ym];
     }
     return o;
+}
+__device__ __forceinline__ DxCellOps dx_cell_ops(int lda, const DxLinModel* __restrict__ L, const double* __restrict__ rawt,
+                                                 const double* __restrict__ dect, const uint8_t* __restrict__ s1, const uint8_t* __restrict__ s2,
+                                                 bool outside, int sd, int a, int L1, int L2, int smax, int rows_mask, bool* pairable)
+{
+    const DxCellRaw r = dx_cell_loads(lda, rawt, dect, s1, s2, outside, sd, a, L1, L2, smax, rows_mask);
+    return dx_cell_weights(L, r, outside, pairable);
 }
 // inside : inside[i][j]  = open  + stack + down * (0x1/1x0/t=2 shapes + windows)   (DuplexEngine.ipp:1029-1064)
 // outside: outside[p][q] = close + stack + up   * (...)                             (DuplexEngine.ipp:1094-1129, pulled)
@@ -441,17 +463,28 @@ __device__ __forceinline__ void win_pass8(const double* seg0, const double* __re
             lds_vptr vs = (lds_vptr)(seg0 + q * 104);
             const int len_max = r + 6 < 29 ? r + 6 : 29;      // longest window any of the 8 diagonals takes from this row
             double run = 0.0;
+            // eight reads at a time: left alone the scheduler hoists the reads of the whole row above the (dependent) running sum,
+            // and the registers they occupy cost the kernel a workgroup per CU
 #pragma unroll
-            for (int l = 1; l <= len_max; l++) {
-                run += outside ? vs[l - 1] : vs[36 - l];
-                const int k = l - r + 1, t = l - 1;            // the window of length l belongs to X_k, t = r+k-2 = l-1
-                if (k >= 0 && k < 8 && t >= 3 && t <= 28) acc[k] = fma(lam_pow[t + 2], run, acc[k]);
+            for (int l0 = 1; l0 <= len_max; l0 += 8) {
+                double x[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) if (l0 + u <= len_max) x[u] = outside ? vs[l0 + u - 1] : vs[36 - l0 - u];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int l = l0 + u;
+                    if (l > len_max) continue;
+                    run += x[u];
+                    const int k = l - r + 1, t = l - 1;        // the window of length l belongs to X_k, t = r+k-2 = l-1
+                    if (k >= 0 && k < 8 && t >= 3 && t <= 28) acc[k] = fma(lam_pow[t + 2], run, acc[k]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
 }
 
-__global__ __launch_bounds__(512) void dxl_strip8(DxLinBatch B, const DxLinModel* __restrict__ L, int step)
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 8))) void dxl_strip8(DxLinBatch B, const DxLinModel* __restrict__ L, int step)
 {
     constexpr int KD = 8, GS = 58, PAD = 8, CS = 80;
     __shared__ double seg[8][4][104];        // staged rows; afterwards: partial sums [8 wavefronts][8 diagonals][64]
@@ -494,30 +527,41 @@ __global__ __launch_bounds__(512) void dxl_strip8(DxLinBatch B, const DxLinModel
             return;
         }
     }
+    // ---- the 30 window rows: loads first, all of them in flight at once (unconditional, from clamped addresses: a load behind a
+    // branch is waited for behind that branch, which made these eight one round trip each), then the cell operands, whose chain of
+    // dependent loads (letters -> pair type -> table values) travels behind them; zeros where the padded row has no column
+    const int c0 = outside ? a0 + 1 : a0 - 36;
+    const int cl = c0 + lane, ch = c0 + 64 + (lane < 40 ? lane : 39);      // 104 columns: 64 + 40
+    const int cmax = B.n1max + 1 + kDxPad;
+    const bool okl = cl >= -kDxPad && cl <= cmax, okh = ch >= -kDxPad && ch <= cmax;
+    const int cls = cl < -kDxPad ? -kDxPad : (cl > cmax ? cmax : cl), chs = ch < -kDxPad ? -kDxPad : (ch > cmax ? cmax : ch);
+    double vl[4], vh[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int r = 1 + w + 8 * q;
+        const int row = outside ? sdA + r : sdA - r;
+        const int rowc = row < 2 ? 2 : (row > smax ? smax : row);
+        vl[q] = dect[(unsigned)(rowc * lda + cls)];     // (32-bit offsets from a uniform base: one address register per load;
+        vh[q] = dect[(unsigned)(rowc * lda + chs)];     //  rowc >= 2 and cls >= -kDxPad: never negative)
+    }
     // ---- operands of X_w that come from rows of earlier launches (rows 2, 3, 4 before it while those lie outside the strip)
     const int sdw = sdA + w * fwd;
     const bool mine = sdw >= 2 && sdw <= smax;
     bool pairable = false;
-    DxCellOps o = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (a >= 0 && a <= B.n1max + 1)
-        o = dx_cell_ops(lda, L, rawt, dect, s1, s2, outside, sdw, a, L1, L2, smax, (w < 2 ? 1 : 0) | (w < 3 ? 2 : 0) | (w < 4 ? 4 : 0), &pairable);
-
-    // ---- stage the 30 window rows (columns outside the padded row read as 0: the pads hold zeros, what lies beyond is another row)
-    {
-        const int c0 = outside ? a0 + 1 : a0 - 36;
-        const int cl = c0 + lane, ch = c0 + 64 + lane;           // 104 columns: 64 + 40
-        const bool okl = cl >= -kDxPad && cl <= B.n1max + 1 + kDxPad, okh = lane < 40 && ch >= -kDxPad && ch <= B.n1max + 1 + kDxPad;
+    const DxCellRaw craw = dx_cell_loads(lda, rawt, dect, s1, s2, outside, sdw, a, L1, L2, smax, (w < 2 ? 1 : 0) | (w < 3 ? 2 : 0) | (w < 4 ? 4 : 0));
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int r = 1 + w + 8 * q;
-            const int row = outside ? sdA + r : sdA - r;
-            if (r <= 30 && row >= 2 && row <= smax) {            // wave-uniform
-                const double* __restrict__ rp = dect + (size_t)row * lda;
-                seg[w][q][lane] = okl ? rp[cl] : 0.0;
-                if (lane < 40) seg[w][q][64 + lane] = okh ? rp[ch] : 0.0;
-            }
-        }
+    for (int q = 0; q < 4; q++) { asm volatile("" : "+v"(vl[q])); asm volatile("" : "+v"(vh[q])); }   // (keeps the loads where they were issued)
+#pragma unroll
+    for (int q = 0; q < 4; q++) {   // the window rows were requested first and arrive first: into LDS while the cell's own loads travel
+        const int r = 1 + w + 8 * q;
+        const int row = outside ? sdA + r : sdA - r;
+        const bool rv = r <= 30 && row >= 2 && row <= smax;               // wave-uniform; rows that do not exist are never read
+        seg[w][q][lane] = rv && okl ? vl[q] : 0.0;
+        if (lane < 40) seg[w][q][64 + lane] = rv && okh ? vh[q] : 0.0;
     }
+    __builtin_amdgcn_sched_barrier(0);
+    DxCellOps o = dx_cell_weights(L, craw, outside, &pairable);
     for (int k = threadIdx.x; k < 2 * KD * CS; k += 512) (&srow[0][0][0])[k] = 0.0;
     double acc[KD];
 #pragma unroll
