@@ -692,9 +692,11 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_outside_strip(Mc
     for (int q = 0; q < NT; q++) {   // this term set's own-column values: FM1[e][i-e] (FMo terms), FM2o[d0+e][i] (FM1o terms), e = 1+wt+TS*q.
         // Slot e = 32 is no term: it is paired with zero rows below.
         const int e = 1 + wt + TS * q, R = d0 + e;
+        // (eager '&': with '&&' the compiler turns the select into a branch, sinks the load into it and waits for it there --
+        //  one exposed round trip per value)
         const double v = fm1[(unsigned)(e * ld + i - e)], u = fm2o[(unsigned)(R * ld + i)];
-        a_lo[q] = (i - e >= 1 && i <= n - 1) ? v : 0.0;          // cell (i-e, i)
-        a_hi[q] = (i >= 1 && i <= n - 1 - R) ? u : 0.0;          // cell (i, i+R)
+        a_lo[q] = ((i - e >= 1) & (i <= n - 1)) ? v : 0.0;       // cell (i-e, i)
+        a_hi[q] = ((i >= 1) & (i <= n - 1 - R)) ? u : 0.0;       // cell (i, i+R)
     }
     // the letters are first touched HERE, behind the staging loads
     __builtin_amdgcn_sched_barrier(0);
@@ -720,7 +722,7 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_outside_strip(Mc
     double r_z;
     {
         const double f5v = f5i[ic - 1 <= n ? ic - 1 : n];
-        p_f5i = (i >= 1 && i - 1 <= n) ? f5v : 0.0;
+        p_f5i = ((i >= 1) & (i - 1 <= n)) ? f5v : 0.0;
         r_z = 1.0 / f5i[n];   // (one division per lane, not one per diagonal on the chain)
 #pragma unroll
         for (int sl = 0; sl < NSL; sl++) {
@@ -741,22 +743,6 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_outside_strip(Mc
             p_fc[sl] = v ? fcv : 0.0;
             p_f5o[sl] = v ? f5ov : 0.0;
         }
-        // the first of its steps may still need rows > d0 (unconditional loads, selected afterwards)
-        const int k0 = w, d = d0 - k0, j = i + d;
-        const bool v = i >= 1 && i <= n - 1 - d;
-        const bool right_ok = v && j + 1 <= n - 1, left_ok = v && i - 1 >= 1;
-        const unsigned a1 = (unsigned)((d + 1) * ld + ic), a2 = (unsigned)((d + 2) * ld + ic), a3 = (unsigned)((d + 3) * ld + ic), a4 = (unsigned)((d + 4) * ld + ic);
-        const double l_fmo = tab[S_FMO * ts + a1], l_fm1o = tab[S_FM1O * ts + a1 - 1];                    // FMo[d+1][i], FM1o[d+1][i-1]   ipp:3806, 3833
-        const double l_fm1o_up = tab[S_FM1O * ts + a2 - 1], l_fco_up = tab[S_FCO * ts + a2 - 1];          // ipp:3828
-        const double l_x01 = fcox[a3 - 1], l_x10 = fcox[a3 - 2], l_x11 = fcox[a4 - 2];
-        p_fmo = (right_ok & (k0 < 1)) ? l_fmo : 0.0;
-        p_fm1o = (left_ok & (k0 < 1)) ? l_fm1o : 0.0;
-        const bool up_ok = left_ok && right_ok;                                                          // the cell (i-1, j+1) is interior
-        p_fm1o_up = (up_ok & (k0 < 2)) ? l_fm1o_up : 0.0;
-        p_fco_up = (up_ok & (k0 < 2)) ? l_fco_up : 0.0;
-        p_x01 = (left_ok && j + 2 <= n - 1 && k0 < 3) ? l_x01 : 0.0;
-        p_x10 = (v && i - 2 >= 1 && j + 1 <= n - 1 && k0 < 3) ? l_x10 : 0.0;
-        p_x11 = (v && i - 2 >= 1 && j + 2 <= n - 1 && k0 < 4) ? l_x11 : 0.0;
     }
     // ---- staged rows -> LDS (cells outside the interior of their row are staged as 0); unconditional stores, pinned values
     double* const LX = lds + P::OFF_DUMMY;
@@ -770,20 +756,20 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_outside_strip(Mc
         const int ra = w + W * q, e = 1 + w + W * q, R = d0 + 1 + ra;
         double* const dA = ra < NM ? LA + (KD + ra) * CA : LX;
         double* const dD = e <= NM ? LDm + (e - 1) * CD : LX;
-        dA[lane] = (cA0 >= 1 && cA0 <= n - 1 - R) ? vA0[q] : 0.0;
-        LE[ra * CE + lane] = (cE0 >= 1 && cE0 <= n - 1 - R) ? vE0[q] : 0.0;
-        dD[lane] = (cD0 >= 1 && cD0 <= n - 1 - e) ? vD0[q] : 0.0;
+        dA[lane] = ((cA0 >= 1) & (cA0 <= n - 1 - R)) ? vA0[q] : 0.0;
+        LE[ra * CE + lane] = ((cE0 >= 1) & (cE0 <= n - 1 - R)) ? vE0[q] : 0.0;
+        dD[lane] = ((cD0 >= 1) & (cD0 <= n - 1 - e)) ? vD0[q] : 0.0;
     }
 #pragma unroll
     for (int p2 = 0; p2 < NR / 2; p2++) {
         const int rl = w + W * 2 * p2 + lhalf * W, R = d0 + 1 + rl;
         double* const dA = rl < NM ? LA + (KD + rl) * CA : LX;
-        dA[64 + lsub] = (cA1 >= 1 && cA1 <= n - 1 - R) ? vA1[p2] : 0.0;
-        LE[rl * CE + 64 + lsub] = (cE1 >= 1 && cE1 <= n - 1 - R) ? vE1[p2] : 0.0;
+        dA[64 + lsub] = ((cA1 >= 1) & (cA1 <= n - 1 - R)) ? vA1[p2] : 0.0;
+        LE[rl * CE + 64 + lsub] = ((cE1 >= 1) & (cE1 <= n - 1 - R)) ? vE1[p2] : 0.0;
     }
     {
         double* const dD = (dsel < NR && eD <= NM) ? LDm + (eD - 1) * CD : LX;
-        dD[64 + dsub] = (cD1 >= 1 && cD1 <= n - 1 - eD) ? vD1 : 0.0;
+        dD[64 + dsub] = ((cD1 >= 1) & (cD1 <= n - 1 - eD)) ? vD1 : 0.0;
     }
     for (int k = threadIdx.x; k < KD * CA; k += 64 * W) LA[k] = 0.0;
     for (int k = threadIdx.x; k < (P::RD - NM) * CD; k += 64 * W) LDm[NM * CD + k] = 0.0;
@@ -826,7 +812,26 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_outside_strip(Mc
     RH_STAMPO(2);
     double f1e[KD - 1];   // FM1[e][i-e], e = 1..KD-1: operands of the chain's own-row FMo terms
 #pragma unroll
-    for (int e = 1; e < KD; e++) { const double v = fm1[(unsigned)(e * ld + i - e)]; f1e[e - 1] = (i - e >= 1 && i <= n - 1) ? v : 0.0; }
+    for (int e = 1; e < KD; e++) { const double v = fm1[(unsigned)(e * ld + i - e)]; f1e[e - 1] = ((i - e >= 1) & (i <= n - 1)) ? v : 0.0; }
+    {   // (loaded here, behind the pre-phase, rather than with the other gathers: seven values fewer in registers while the staged rows
+        //  are in flight -- the kernel is at 128 VGPRs, and a spilled gather is waited for where it is spilled)
+        // the first of its steps may still need rows > d0 (unconditional loads, selected afterwards)
+        const int k0 = w, d = d0 - k0, j = i + d;
+        const bool v = i >= 1 && i <= n - 1 - d;
+        const bool right_ok = v && j + 1 <= n - 1, left_ok = v && i - 1 >= 1;
+        const unsigned a1 = (unsigned)((d + 1) * ld + ic), a2 = (unsigned)((d + 2) * ld + ic), a3 = (unsigned)((d + 3) * ld + ic), a4 = (unsigned)((d + 4) * ld + ic);
+        const double l_fmo = tab[S_FMO * ts + a1], l_fm1o = tab[S_FM1O * ts + a1 - 1];                    // FMo[d+1][i], FM1o[d+1][i-1]   ipp:3806, 3833
+        const double l_fm1o_up = tab[S_FM1O * ts + a2 - 1], l_fco_up = tab[S_FCO * ts + a2 - 1];          // ipp:3828
+        const double l_x01 = fcox[a3 - 1], l_x10 = fcox[a3 - 2], l_x11 = fcox[a4 - 2];
+        p_fmo = (right_ok & (k0 < 1)) ? l_fmo : 0.0;
+        p_fm1o = (left_ok & (k0 < 1)) ? l_fm1o : 0.0;
+        const bool up_ok = left_ok && right_ok;                                                          // the cell (i-1, j+1) is interior
+        p_fm1o_up = (up_ok & (k0 < 2)) ? l_fm1o_up : 0.0;
+        p_fco_up = (up_ok & (k0 < 2)) ? l_fco_up : 0.0;
+        p_x01 = (left_ok & (j + 2 <= n - 1) & (k0 < 3)) ? l_x01 : 0.0;
+        p_x10 = (v & (i - 2 >= 1) & (j + 1 <= n - 1) & (k0 < 3)) ? l_x10 : 0.0;
+        p_x11 = (v & (i - 2 >= 1) & (j + 2 <= n - 1) & (k0 < 4)) ? l_x11 : 0.0;
+        }
     RH_STAMPO(3);
     // enclosing single-branch loops: staged row rho is table row d0+1+rho = d+2+t with t = rho-1+k for diagonal d0-k; tap l1 reads column
     // i-1-l1 of it (index lane+31-l1).  Weights as in the inside strip: wT[l1][rho+k].
@@ -924,6 +929,7 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_outside_strip(Mc
         }
         gs[SL] += g0 + g1;
     };
+    double fco_s[NSL];
     auto fin = [&](auto KC) {
         constexpr int K = decltype(KC)::value, SL = K / W;
         const int d = d0 - K;
@@ -950,14 +956,9 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_outside_strip(Mc
         double fco = p_cad[SL] * (ext + multi) + p_cbd[SL] * (g + sp) + p_cst[SL] * o_fco_up;   // coefficients are 0 for a non-pair
         double fm2o = fmo + fco * p_ctja[SL];                                                  // ipp:3803, 4027
         if (!v) { fco = 0.0; fmo = 0.0; fm1o = 0.0; fm2o = 0.0; }
-        // posterior of pair (i, j+1) = FCo * FCi / Z, clipped to [0,1]                 (ipp:4689-4827)
-        double p = fco * p_fc[SL] * r_z;
-        if (v && lane >= KD - 1 && (!(p == p) || p > 1e300)) { atomicOr(&bad[sq], 1); p = 0.0; }
-        p = p > 1.0 ? 1.0 : (p < 0.0 ? 0.0 : p);
-        if (!(p == p)) p = 0.0;
         SFM2O[K * CS + PADL + lane] = fm2o; SFMO[K * CS + PADL + lane] = fmo; SFM1O[K * CS + PADL + lane] = fm1o;
         SFCO[K * CS + PADL + lane] = fco; SFCOX[K * CS + PADL + lane] = fco * p_tjbx[SL];
-        PART[(K * 3) * 64 + lane] = p;   // row (term set 0, diagonal K): consumed by pre<K> before this point
+        fco_s[SL] = fco;   // the posterior is taken from it after the chain, off the critical path
     };
     RH_STAMPO(6);
     // time slot T: wavefront T % W finishes step T (fin: the two terms of row T-1 + the epilogue); every later step K > T, on
@@ -975,6 +976,18 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_outside_strip(Mc
     RH_SLOT(0) RH_SLOT(1) RH_SLOT(2) RH_SLOT(3) RH_SLOT(4) RH_SLOT(5) RH_SLOT(6) RH_SLOT(7)
 #undef RH_SLOT
     RH_STAMPO(7);
+    // posterior of pair (i, j+1) = FCo * FCi / Z, clipped to [0,1] (ipp:4689-4827), by the wavefront that finished the diagonal; it goes
+    // to partial-sum row (term set 0, diagonal K, 0), which that wavefront read before the chain
+#pragma unroll
+    for (int sl = 0; sl < NSL; sl++) {
+        const int K = w + W * sl, d = d0 - K;
+        const bool v = i >= 1 && d >= 0 && i <= n - 1 - d;
+        double p = fco_s[sl] * p_fc[sl] * r_z;
+        if (v && lane >= KD - 1 && (!(p == p) || p > 1e300)) { atomicOr(&bad[sq], 1); p = 0.0; }
+        p = p > 1.0 ? 1.0 : (p < 0.0 ? 0.0 : p);
+        if (!(p == p)) p = 0.0;
+        PART[(K * 3) * 64 + lane] = p;
+    }
     lds_barrier();
     // ---- the strip's rows go to HBM now, off the chain
     if (lane >= KD - 1 && i >= 1) {
