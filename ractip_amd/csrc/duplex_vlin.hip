@@ -25,7 +25,7 @@ typedef const volatile __attribute__((address_space(3))) double* lds_vp;
 
 __device__ __forceinline__ double small_wd(const VLinModel* L, int l1, int l2, int t1, int t2, int si1, int sj1, int sp1, int sq1)
 {   // as small_w of mccaskill_vlin.hip: t1 = pair closing the loop seen from outside, t2 = the other pair (its rtype is taken here)
-    const int r2 = L->rtype[t2];
+    const int r2 = vienna_rtype(t2);
     const int tt = t1 * 8 + r2;
     if (l1 == 0 && l2 == 0) return L->E_stack[tt];
     if (l1 + l2 == 1) return L->E_bulge1[tt];
@@ -141,13 +141,13 @@ __global__ __launch_bounds__(256) void dxvl_sweep4(DxLinBatch B, const VLinModel
     const bool incell = mine && a >= 1 && a <= L1 && b >= 1 && b <= L2;
     int x = 0, xm = 0, xp = 0, y = 0, ym = 0, yp = 0;
     if (incell) { x = s1[i]; xm = s1[i - 1]; xp = s1[i + 1]; y = s2[j]; ym = s2[j - 1]; yp = s2[j + 1]; }
-    const int type = incell ? L->ptype[x * 5 + y] : 0;
+    const int type = incell ? vienna_ptype(x, y) : 0;
     const bool pairable = type != 0;
     const double* __restrict__ rawt = tab + T_RAW * ts + kDxPad;
     double sm7 = 0.0, e_tau = 1.0, mm_up = 0.0, mm_dn = 0.0, ends = 0.0;
     double c_st = 0.0, c_b01 = 0.0, c_b10 = 0.0;   // weights of the shapes of X_2 / X_3 whose source row belongs to this launch
     if (pairable) {
-        const int rt = L->rtype[type];
+        const int rt = vienna_rtype(type);
         e_tau = L->E_tau[type];
         mm_up = D->E_mmI[type * 25 + xp * 5 + ym];   // this pair as the upstream end of a generic loop
         mm_dn = D->E_mmI[rt * 25 + yp * 5 + xm];     // ... as the downstream end
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void dxvl_sweep4(DxLinBatch B, const VLinModel
             // source cell letters: inside (i-1-l1, j+1+l2), outside (i+1+l1, j-1-l2)
             const int si = i + dir * (1 + l1), sj = j - dir * (1 + l2);
             if (srow < 2 || srow > smax || si < 1 || si > L1 || sj < 1 || sj > L2) continue;
-            const int ts_ = L->ptype[s1[si] * 5 + s2[sj]];
+            const int ts_ = vienna_ptype(s1[si], s2[sj]);
             if (!ts_) continue;
             const int n1 = s1[si - dir], n2 = s2[sj + dir];   // the letters next to the source pair inside the loop
             const double wgt = outside ? small_wd(L, l1, l2, type, ts_, xp, ym, n1, n2) : small_wd(L, l1, l2, ts_, type, n1, n2, xm, yp);
@@ -231,10 +231,10 @@ __global__ __launch_bounds__(256) void dxvl_logz_part(DxLinBatch B, const VLinMo
         const int alo = sd - L2 > 1 ? sd - L2 : 1, ahi = sd - 1 < L1 ? sd - 1 : L1;
         for (int a = alo + threadIdx.x; a <= ahi; a += 256) {
             const int i = a, j = L2 + 1 - (sd - a);
-            const int type = L->ptype[s1[i] * 5 + s2[j]];
+            const int type = vienna_ptype(s1[i], s2[j]);
             if (!type) continue;
             npair++;
-            const int rt = L->rtype[type];
+            const int rt = vienna_rtype(type);
             const double cl = rowf * (i < L1 ? D->E_d3[rt * 5 + s1[i + 1]] : 1.0) * (j > 1 ? D->E_d5[rt * 5 + s2[j - 1]] : 1.0) * L->E_tau[type];
             acc = fma(in[(size_t)sd * B.lda + a], cl, acc);
         }

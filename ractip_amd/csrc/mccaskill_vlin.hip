@@ -186,7 +186,7 @@ __device__ __forceinline__ bool gap_ok_vl(int cut, int g) { return g != cut; }
 // next to the outer pair inside the loop, sp1/sq1 next to the inner pair
 __device__ __forceinline__ double small_w(const VLinModel* L, int l1, int l2, int t1, int t2, int si1, int sj1, int sp1, int sq1)
 {
-    const int r2 = L->rtype[t2];
+    const int r2 = vienna_rtype(t2);
     const int tt = t1 * 8 + r2;
     if (l1 == 0 && l2 == 0) return L->E_stack[tt];
     if (l1 + l2 == 1) return L->E_bulge1[tt];
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) __attribute__((amdgpu_wave
     const bool valid = i <= ncell;
     int s_im1 = 0, s_i = 0, s_ip1 = 0, s_j = 0, s_jp1 = 0, s_jp2 = 0;
     if (valid) { s_im1 = s[i - 1]; s_i = s[i]; s_ip1 = s[i + 1]; s_j = s[j]; s_jp1 = s[j + 1]; s_jp2 = s[j + 2]; }
-    const int type = (B.allow && valid && !B.allow[((size_t)sq * ld + i) * ld + (j + 1)]) ? 0 : L->ptype[s_i * 5 + s_jp1];   // 0: excluded by a structure constraint
+    const int type = (B.allow && valid && !B.allow[((size_t)sq * ld + i) * ld + (j + 1)]) ? 0 : vienna_ptype(s_i, s_jp1);   // 0: excluded by a structure constraint
     const bool pairable = valid && type != 0;
     // two-molecule form: the missing gap inside the pair limits both sides of an enclosed loop to their own strand
     const bool nick_in = CUT && valid && i <= cut && cut <= j;
@@ -409,29 +409,41 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) __attribute__((amdgpu_wave
             constexpr int NSEG = 2 * ((kMaxSingle / 2 + W) / W);
             int rseg[NSEG];
             double bA[NSEG], bB[NSEG];
+            // every load of the staging first, unconditional (a segment that is off reads row d-3, which exists, and is dropped): a load
+            // inside `if (on)` is waited for inside it, one memory round trip per segment and bulge tap
+            double g0[NSEG], g1[NSEG], x0[NSEG], xa[NSEG], xb[NSEG];
+#pragma unroll
+            for (int q = 0; q < NSEG; q++) {
+                const int g = w + (q >> 1) * W;
+                const int r = (q & 1) ? LAST - g : g;
+                const bool on = g <= HALF && r <= rmax && r >= 2;   // wave-uniform
+                const int rr = on ? r : 2;
+                const double* __restrict__ row = fcx + (d - 1 - rr) * ld + i0 + 1;
+                const double* __restrict__ brow = fcb + (d - 1 - rr) * ld + i + 1;
+                g0[q] = row[lane]; g1[q] = row[64 + (lane & 31)];
+                x0[q] = brow[0]; xa[q] = brow[rr - 1]; xb[q] = brow[rr];
+            }
+#pragma unroll
+            for (int q = 0; q < NSEG; q++) {
+                asm volatile("" : "+v"(g0[q])); asm volatile("" : "+v"(g1[q])); asm volatile("" : "+v"(x0[q])); asm volatile("" : "+v"(xa[q])); asm volatile("" : "+v"(xb[q]));
+            }
 #pragma unroll
             for (int q = 0; q < NSEG; q++) {
                 const int g = w + (q >> 1) * W;
                 const int r = (q & 1) ? LAST - g : g;
                 const bool on = g <= HALF && r <= rmax && r >= 2;   // wave-uniform
                 rseg[q] = on ? r : -1;
-                bA[q] = bB[q] = 0.0;
-                if (on) {
-                    const int col0 = i0 + 1;
-                    if (r >= 4) {
-                        const double* __restrict__ row = fcx + (d - 1 - r) * ld + col0;
-                        gbuf[w][q][lane] = col0 + lane < ld ? row[lane] : 0.0;
-                        if (lane < 32) gbuf[w][q][64 + lane] = col0 + 64 + lane < ld ? row[64 + lane] : 0.0;
-                    }
-                    // bulges of length t on the 3' side (l1 = 0: column i+1) and on the 5' side (l1 = t: column i+1+t)
-                    const double* __restrict__ brow = fcb + (d - 1 - r) * ld + i + 1;
-                    const int tA = r - 1;
-                    const bool a0 = valid && tA >= 2 && l1max >= 0 && tA <= l2max, a1 = valid && tA >= 2 && tA <= l1max && l2max >= 0;
-                    const bool b0 = valid1 && r <= kMaxSingle && l1max1 >= 0 && r <= l2max1, b1 = valid1 && r <= kMaxSingle && r <= l1max1 && l2max1 >= 0;
-                    const double x0 = (a0 || b0) ? brow[0] : 0.0;
-                    bA[q] = (a0 ? x0 : 0.0) + (a1 ? brow[tA] : 0.0);
-                    bB[q] = (b0 ? x0 : 0.0) + (b1 ? brow[r] : 0.0);
+                const int col0 = i0 + 1;
+                if (on && r >= 4) {
+                    gbuf[w][q][lane] = col0 + lane < ld ? g0[q] : 0.0;
+                    if (lane < 32) gbuf[w][q][64 + lane] = col0 + 64 + lane < ld ? g1[q] : 0.0;
                 }
+                // bulges of length t on the 3' side (l1 = 0: column i+1) and on the 5' side (l1 = t: column i+1+t)
+                const int tA = r - 1;
+                const bool a0 = on & valid & (tA >= 2) & (l1max >= 0) & (tA <= l2max), a1 = on & valid & (tA >= 2) & (tA <= l1max) & (l2max >= 0);
+                const bool b0 = on & valid1 & (r <= kMaxSingle) & (l1max1 >= 0) & (r <= l2max1), b1 = on & valid1 & (r <= kMaxSingle) & (r <= l1max1) & (l2max1 >= 0);
+                bA[q] = (a0 ? x0[q] : 0.0) + (a1 ? xa[q] : 0.0);
+                bB[q] = (b0 ? x0[q] : 0.0) + (b1 ? xb[q] : 0.0);
             }
 #pragma unroll
             for (int q = 0; q < NSEG; q++)
@@ -512,39 +524,53 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) __attribute__((amdgpu_wave
     if (w != 0 || !valid) return;
     double e_txo = 0, e_tmc = 0, e_tmh = 0, e_txi = 0, e_tsa = 0, e_tau = 1, e_tet = 1, nick = 0.0;
     double o_fca = 0, o_fm1 = 0, o_fms = 0, sm7 = 0.0;
-    {   // epilogue operands: loaded here, after the term loops, so that they do not occupy registers during them
-        e_txo = L->TXO[idx]; e_tmc = L->TMC[idx]; e_tmh = L->TMH[idx];
-        e_txi = L->TXI[idx_raw]; e_tsa = L->TSA[idd]; e_tau = L->E_tau[type];
-        if (nick_in && pairable && d >= kMinHairpin)
-            nick = B.xs[(size_t)sq * ld + i + 1] * B.xp[(size_t)sq * ld + j] *
-                   L->TNC[25 * (5 * s_i + (GAPOK(i) ? s_ip1 : 0)) + 5 * s_jp1 + (GAPOK(j) ? s_j : 0)];
-        if (d == 4 && pairable) {   // tetraloop bonus: closing pair + 4 loop letters
-            int code = 0; bool ok = true;
-#pragma unroll
-            for (int k = 0; k < 6; k++) { const int c = s[i + k]; ok = ok && c != 0; code = code * 4 + (c - 1); }
-            if (ok) e_tet = L->E_tetra[code];
+    {   // epilogue operands: loaded here, after the term loops, so that they do not occupy registers during them -- and ALL AT ONCE:
+        // every index below follows from letters that arrived long ago (pair types are arithmetic, vienna_ptype), every load is
+        // unconditional from a clamped address and selected afterwards.  Behind per-lane `if`s these were ~20 dependent round trips.
+        const int b_ip2 = s[i + 2 <= n + 1 ? i + 2 : n + 1], b_ip3 = s[i + 3 <= n + 1 ? i + 3 : n + 1];     // letters i+2, i+3, j-1, j-2
+        const int b_jm1 = s[j - 1 >= 0 ? j - 1 : 0], b_jm2 = s[j - 2 >= 0 ? j - 2 : 0];
+        const double l_txo = L->TXO[idx], l_tmc = L->TMC[idx], l_tmh = L->TMH[idx], l_txi = L->TXI[idx_raw], l_tsa = L->TSA[idd], l_tau = L->E_tau[type];
+        const unsigned dm1 = (unsigned)((d >= 1 ? d - 1 : 0) * ld + i), dm2 = (unsigned)((d >= 2 ? d - 2 : 0) * ld + i);
+        const double l_fca = tab[VL_FCA * ts + dm2 + 1], l_fm1 = tab[VL_FM1 * ts + dm1 + 1], l_fms = tab[VL_FMS * ts + dm1];
+        double l_nick = 0.0;
+        if constexpr (CUT) {
+            const bool nk = nick_in & pairable & (d >= kMinHairpin);
+            const size_t o = (size_t)sq * ld;
+            const double xs = B.xs[o + (nk ? i + 1 : 1)], xp = B.xp[o + (nk ? j : 1)];
+            const double tn = L->TNC[25 * (5 * s_i + (GAPOK(i) ? s_ip1 : 0)) + 5 * s_jp1 + (GAPOK(j) ? s_j : 0)];
+            l_nick = nk ? xs * xp * tn : 0.0;
         }
+        // tetraloop bonus (d = 4: the letters i .. i+5 are s_i, s_ip1, i+2, i+3, s_j, s_jp1)
+        const bool tet_ok = (d == 4) & pairable & (s_i != 0) & (s_ip1 != 0) & (b_ip2 != 0) & (b_ip3 != 0) & (s_j != 0) & (s_jp1 != 0);
+        const int tet_code = tet_ok ? ((((( (s_i - 1) * 4 + (s_ip1 - 1)) * 4 + (b_ip2 - 1)) * 4 + (b_ip3 - 1)) * 4 + (s_j - 1)) * 4 + (s_jp1 - 1)) : 0;
+        const double l_tet = L->E_tetra[tet_code];
+        // the seven tabulated shapes: inner pair letters (p, q) = (i+1+l1, j-l2), raw table cell (p, q-1)
+        const double* __restrict__ fc = tab + VL_FC * ts;
+        double sv[7], sw[7];
+        bool sok[7];
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+            const int l1 = (k == 2 || k == 3 || k == 4) ? 1 : (k >= 5 ? 2 : 0);
+            const int l2 = (k == 1 || k == 3 || k == 5) ? 1 : ((k == 4 || k == 6) ? 2 : 0);
+            const int t = l1 + l2;
+            sok[k] = pairable & (d - 2 - t >= 0) & (l1 <= l1max) & (l2 <= l2max);
+            // letters of the inner pair and next to it, out of the eight letters held: p = i+1+l1, q = j-l2
+            const int sp = l1 == 0 ? s_ip1 : (l1 == 1 ? b_ip2 : b_ip3), spm = l1 == 0 ? s_i : (l1 == 1 ? s_ip1 : b_ip2);
+            const int sq_ = l2 == 0 ? s_j : (l2 == 1 ? b_jm1 : b_jm2), sqp = l2 == 0 ? s_jp1 : (l2 == 1 ? s_j : b_jm1);
+            const int t2 = vienna_ptype(sp, sq_);
+            sv[k] = fc[(unsigned)((sok[k] ? d - 2 - t : 0) * ld + i + 1 + l1)];
+            sw[k] = small_w(L, l1, l2, type, t2, s_ip1, s_j, spm, sqp);
+        }
+        e_txo = l_txo; e_tmc = l_tmc; e_tmh = l_tmh; e_txi = l_txi; e_tsa = l_tsa; e_tau = l_tau;
+        nick = l_nick;
+        e_tet = tet_ok ? l_tet : 1.0;
         if (d >= 2) {   // a multiloop element may not touch the missing gap
-            if (GAPOK(i) && GAPOK(j)) o_fca = tab[VL_FCA * ts + (d - 2) * ld + i + 1];
-            if (GAPOK(i) && GAPOK(i + 1)) o_fm1 = tab[VL_FM1 * ts + (d - 1) * ld + i + 1];
-            if (GAPOK(j - 1) && GAPOK(j)) o_fms = tab[VL_FMS * ts + (d - 1) * ld + i];
+            o_fca = (GAPOK(i) & GAPOK(j)) ? l_fca : 0.0;
+            o_fm1 = (GAPOK(i) & GAPOK(i + 1)) ? l_fm1 : 0.0;
+            o_fms = (GAPOK(j - 1) & GAPOK(j)) ? l_fms : 0.0;
         }
-        if (pairable && d >= 2) {
-            // the seven tabulated shapes: inner pair letters (p, q) = (i+1+l1, j-l2), raw table cell (p, q-1)
-            const double* __restrict__ fc = tab + VL_FC * ts;
 #pragma unroll
-            for (int k = 0; k < 7; k++) {
-                const int l1 = (k == 2 || k == 3 || k == 4) ? 1 : (k >= 5 ? 2 : 0);
-                const int l2 = (k == 1 || k == 3 || k == 5) ? 1 : ((k == 4 || k == 6) ? 2 : 0);
-                const int t = l1 + l2;
-                if (d - 2 - t >= 0 && l1 <= l1max && l2 <= l2max) {
-                    const int p = i + 1 + l1, q = j - l2;
-                    const int t2 = L->ptype[s[p] * 5 + s[q]];
-                    const double v = fc[(d - 2 - t) * ld + p];
-                    sm7 = fma(v, small_w(L, l1, l2, type, t2, s_ip1, s_j, s[p - 1], s[q + 1]), sm7);
-                }
-            }
-        }
+        for (int k = 0; k < 7; k++) sm7 = fma(sok[k] ? sv[k] : 0.0, sw[k], sm7);
     }
 
     double fm2 = acc2, g = accc, gb = accb;
@@ -622,7 +648,7 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) __attribute__((amdgpu_wave
             const double* __restrict__ xs = B.xs + (size_t)sq * ld;
             const double* __restrict__ xpo = B.xpo + (size_t)sq * ld;
             for (int i = 1 + threadIdx.x; i <= cut; i += 64 * WR) {
-                if (b + 1 - i < 4 || !L->ptype[s[i] * 5 + s[b + 1]]) continue;
+                if (b + 1 - i < 4 || !vienna_ptype(s[i], s[b + 1])) continue;
                 const int ix = 25 * (5 * s[i] + (GAPOK(i) ? s[i + 1] : 0)) + 5 * s[b + 1] + (GAPOK(b) ? s[b] : 0);
                 acc = fma(fco[(b - i) * ld + i] * L->TNC[ix], xs[i + 1], acc);
             }
@@ -631,7 +657,7 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) __attribute__((amdgpu_wave
             const double* __restrict__ xp = B.xp + (size_t)sq * ld;
             const double* __restrict__ xso = B.xso + (size_t)sq * ld;
             for (int j = cut + threadIdx.x; j <= n - 1; j += 64 * WR) {
-                if (j + 1 - (a - 1) < 4 || !L->ptype[s[a - 1] * 5 + s[j + 1]]) continue;
+                if (j + 1 - (a - 1) < 4 || !vienna_ptype(s[a - 1], s[j + 1])) continue;
                 const int ix = 25 * (5 * s[a - 1] + (GAPOK(a - 1) ? s[a] : 0)) + 5 * s[j + 1] + (GAPOK(j) ? s[j] : 0);
                 acc = fma(fco[(j - a + 1) * ld + a - 1] * L->TNC[ix], xp[j], acc);
             }
@@ -676,7 +702,7 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) __attribute__((amdgpu_wave
     const bool valid = i <= ncell;
     int s_im1 = 0, s_i = 0, s_ip1 = 0, s_j = 0, s_jp1 = 0, s_jp2 = 0;
     if (valid) { s_im1 = s[i - 1]; s_i = s[i]; s_ip1 = s[i + 1]; s_j = s[j]; s_jp1 = s[j + 1]; s_jp2 = s[j + 2]; }
-    const int type = (B.allow && valid && !B.allow[((size_t)sq * ld + i) * ld + (j + 1)]) ? 0 : L->ptype[s_i * 5 + s_jp1];   // 0: excluded by a structure constraint
+    const int type = (B.allow && valid && !B.allow[((size_t)sq * ld + i) * ld + (j + 1)]) ? 0 : vienna_ptype(s_i, s_jp1);   // 0: excluded by a structure constraint
     const bool pairable = valid && type != 0;
     const bool guard_m = d >= 2;
     // two-molecule form: the sides of an ENCLOSING loop (letters io..i and j+1..jo+1) may not cross the missing gap
@@ -914,7 +940,7 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) __attribute__((amdgpu_wave
                 const int l2 = (k == 1 || k == 3 || k == 5) ? 1 : ((k == 4 || k == 6) ? 2 : 0);
                 const int io = i - 1 - l1, jo = j + 1 + l2;
                 if (io >= 1 && jo <= n - 1 && l1 <= l1max && l2 <= l2max) {
-                    const int to = L->ptype[s[io] * 5 + s[jo + 1]];
+                    const int to = vienna_ptype(s[io], s[jo + 1]);
                     const double v = fco[(jo - io) * ld + io];
                     sm7 = fma(v, small_w(L, l1, l2, to, type, s[io + 1], s[jo], s_im1, s_jp2), sm7);
                 }
@@ -993,7 +1019,7 @@ __global__ __launch_bounds__(256) void vlin_acc_prep(McBatch B, const VLinModel*
         double v = 0.0;
         const int u = q - p - 1;
         if (p >= 1 && q <= n && u >= kMinHairpin) {
-            const int type = L->ptype[s[p] * 5 + s[q]];
+            const int type = vienna_ptype(s[p], s[q]);
             if (type) {
                 double e = hplen[u];
                 if (u == 3) e *= L->E_tau[type];
@@ -1090,7 +1116,7 @@ __global__ __launch_bounds__(256) void vlin_acc_gaps(McBatch B, const VLinModel*
                 const double fc = FC[ics[u]];
                 if (fc != 0.0) {
                     const int k = right ? kl - 1 - r : kl, l = k + r + 1;      // inner pair letters
-                    const int ti = L->ptype[s[k] * 5 + s[l]];
+                    const int ti = vienna_ptype(s[k], s[l]);
                     for (int o = 0; o <= 2; o++) {
                         const int l1 = right ? o : g, l2 = right ? g : o;
                         const bool tabulated = (l1 <= 2 && l2 <= 2) && !(l1 + l2 == 2 && (l1 == 0 || l2 == 0));   // 0x2 / 2x0 are bulges
@@ -1100,7 +1126,7 @@ __global__ __launch_bounds__(256) void vlin_acc_gaps(McBatch B, const VLinModel*
                         if (p < 1 || q > n) continue;
                         const double fo = FCO[(size_t)D * ld + p];
                         if (fo == 0.0) continue;
-                        const int to = L->ptype[s[p] * 5 + s[q]];
+                        const int to = vienna_ptype(s[p], s[q]);
                         acc = fma(fo * small_w(L, l1, l2, to, ti, s[p + 1], s[q - 1], s[k - 1], s[l + 1]), fc, acc);
                     }
                 }

@@ -57,6 +57,16 @@ struct ViennaDx {
 };
 constexpr int kViennaSem18 = 1, kViennaSem20 = 2;
 
+// pair type of two nucleotide codes (A,C,G,U = 1..4, other 0): CG=1 GC=2 GU=3 UG=4 AU=5 UA=6, and the type of the reversed
+// pair, in arithmetic: the kernels' first use of a letter is its pair type, and a table lookup there is one more memory round
+// trip in front of everything that depends on it (ViennaDx::ptype / rtype hold the same values)
+__host__ __device__ inline int vienna_ptype(int a, int b)
+{
+    const int s = a + b;
+    return s == 5 ? (a == 2 ? 1 : (a == 3 ? 2 : (a == 1 ? 5 : (a == 4 ? 6 : 0)))) : (s == 7 ? (a == 3 ? 3 : (a == 4 ? 4 : 0)) : 0);
+}
+__host__ __device__ inline int vienna_rtype(int t) { return (t == 0 || t == 7) ? t : (((t - 1) ^ 1) + 1); }
+
 // LoopEnergy for the seven shapes with joint tables (stack, 1-bulges, int11, int21, int22): type = pair type of the
 // pair that closes the loop seen from outside, type_2 = rtype of the other pair; si1/sj1 = the unpaired letters next
 // to the first pair inside the loop (5' side / 3' side), sp1/sq1 = those next to the second pair
