@@ -803,35 +803,45 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) __attribute__((amdgpu_wave
             constexpr int NSEG = 2 * ((kMaxSingle / 2 + W) / W);
             int rseg[NSEG];
             double bA[NSEG], bB[NSEG];
+            // all loads of the staging first, unconditional (a segment that is off reads row d+3, which exists, and is dropped; a
+            // column outside the interior lies in a neighbouring row of the table and is replaced by 0): see vlin_inside_diag
+            double g0[NSEG], g1[NSEG], x0[NSEG], xa[NSEG], xb[NSEG];
+#pragma unroll
+            for (int q = 0; q < NSEG; q++) {
+                const int g = w + (q >> 1) * W;
+                const int r = (q & 1) ? LAST - g : g;
+                const bool on = g <= HALF && r <= rmax && r >= 2;
+                const int rr = on ? r : 2;
+                const double* __restrict__ row = fcox + (d + 1 + rr) * ld + (i0 - 1 - rr);
+                const double* __restrict__ rowb = fcob + (d + 1 + rr) * ld + (i - 1);
+                g0[q] = row[lane]; g1[q] = row[64 + (lane & 31)];
+                x0[q] = rowb[0]; xa[q] = rowb[-(rr - 1)]; xb[q] = rowb[-rr];
+            }
+#pragma unroll
+            for (int q = 0; q < NSEG; q++) {
+                asm volatile("" : "+v"(g0[q])); asm volatile("" : "+v"(g1[q])); asm volatile("" : "+v"(x0[q])); asm volatile("" : "+v"(xa[q])); asm volatile("" : "+v"(xb[q]));
+            }
 #pragma unroll
             for (int q = 0; q < NSEG; q++) {
                 const int g = w + (q >> 1) * W;
                 const int r = (q & 1) ? LAST - g : g;
                 const bool on = g <= HALF && r <= rmax && r >= 2;
                 rseg[q] = on ? r : -1;
-                bA[q] = bB[q] = 0.0;
-                if (on) {
-                    const int cmax = n - 1 - (d + 1 + r);         // last interior column of the source row
-                    if (r >= 4) {
-                        const int col0 = i0 - 1 - r;
-                        const double* __restrict__ row = fcox + (d + 1 + r) * ld;
-                        const int c = col0 + lane;
-                        gbuf[w][q][lane] = (c >= 1 && c <= cmax) ? row[c] : 0.0;
-                        const int c2 = col0 + 64 + lane;
-                        if (lane < 32) gbuf[w][q][64 + lane] = (c2 >= 1 && c2 <= cmax) ? row[c2] : 0.0;
-                    }
-                    // bulges: outer pair at column i-1 (3' side) or i-1-t (5' side) of the source row
-                    const double* __restrict__ row = fcob + (d + 1 + r) * ld;
-                    const int tA = r - 1, c0 = i - 1, cA = i - 1 - tA, cB = i - 1 - r;
-                    const bool in0 = c0 >= 1 && c0 <= cmax;
-                    const bool a0 = valid && tA >= 2 && in0 && l1max >= 0 && tA <= l2max;
-                    const bool a1 = valid && tA >= 2 && cA >= 1 && cA <= cmax && tA <= l1max && l2max >= 0;
-                    const bool b0 = valid1 && r <= kMaxSingle && in0 && l1max1 >= 0 && r <= l2max1;
-                    const bool b1 = valid1 && r <= kMaxSingle && cB >= 1 && cB <= cmax && r <= l1max1 && l2max1 >= 0;
-                    const double x0 = (a0 || b0) ? row[c0] : 0.0;
-                    bA[q] = (a0 ? x0 : 0.0) + (a1 ? row[cA] : 0.0);
-                    bB[q] = (b0 ? x0 : 0.0) + (b1 ? row[cB] : 0.0);
+                const int cmax = n - 1 - (d + 1 + r);         // last interior column of the source row
+                if (on && r >= 4) {
+                    const int c = i0 - 1 - r + lane, c2 = c + 64;
+                    gbuf[w][q][lane] = ((c >= 1) & (c <= cmax)) ? g0[q] : 0.0;
+                    if (lane < 32) gbuf[w][q][64 + lane] = ((c2 >= 1) & (c2 <= cmax)) ? g1[q] : 0.0;
                 }
+                // bulges: outer pair at column i-1 (3' side) or i-1-t (5' side) of the source row
+                const int tA = r - 1, c0 = i - 1, cA = i - 1 - tA, cB = i - 1 - r;
+                const bool in0 = (c0 >= 1) & (c0 <= cmax);
+                const bool a0 = on & valid & (tA >= 2) & in0 & (l1max >= 0) & (tA <= l2max);
+                const bool a1 = on & valid & (tA >= 2) & (cA >= 1) & (cA <= cmax) & (tA <= l1max) & (l2max >= 0);
+                const bool b0 = on & valid1 & (r <= kMaxSingle) & in0 & (l1max1 >= 0) & (r <= l2max1);
+                const bool b1 = on & valid1 & (r <= kMaxSingle) & (cB >= 1) & (cB <= cmax) & (r <= l1max1) & (l2max1 >= 0);
+                bA[q] = (a0 ? x0[q] : 0.0) + (a1 ? xa[q] : 0.0);
+                bB[q] = (b0 ? x0[q] : 0.0) + (b1 ? xb[q] : 0.0);
             }
 #pragma unroll
             for (int q = 0; q < NSEG; q++)
@@ -918,34 +928,46 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) __attribute__((amdgpu_wave
     if (w != 0 || !valid) return;
     double e_txo = 0, e_tmc = 0, e_txi = 0, e_tsa = 0, e_tau = 1;
     double o_fmso = 0, o_fm1o = 0, o_f5o = 0, o_f5i = 0, o_fm1o_up = 0, o_fc = 0, o_z = 1, sm7 = 0.0, o_x = 0.0;
-    {   // epilogue operands: loaded after the term loops so that they do not occupy registers during them
-        e_txo = L->TXO[idx]; e_tmc = L->TMC[idx];
-        e_txi = L->TXI[idx_raw]; e_tsa = L->TSA[idd]; e_tau = L->E_tau[type];
-        if (guard_m) {
-            if (j + 1 <= n - 1 && GAPOK(j) && GAPOK(j + 1)) o_fmso = tab[VL_FMSO * ts + (d + 1) * ld + i];
-            if (i - 1 >= 1 && GAPOK(i - 1) && GAPOK(i)) o_fm1o = tab[VL_FM1O * ts + (d + 1) * ld + i - 1];
+    {   // epilogue operands: loaded after the term loops so that they do not occupy registers during them, all at once and without a
+        // branch in front of any load (see vlin_inside_diag): the indices follow from letters, the letters were requested at the start
+        const int b_im2 = s[i - 2 >= 0 ? i - 2 : 0], b_im3 = s[i - 3 >= 0 ? i - 3 : 0];
+        const int b_jp3 = s[j + 3 <= n + 1 ? j + 3 : n + 1], b_jp4 = s[j + 4 <= n + 1 ? j + 4 : n + 1];
+        const double l_txo = L->TXO[idx], l_tmc = L->TMC[idx], l_txi = L->TXI[idx_raw], l_tsa = L->TSA[idd], l_tau = L->E_tau[type];
+        const bool ok_so = guard_m & (j + 1 <= n - 1) & GAPOK(j) & GAPOK(j + 1), ok_1o = guard_m & (i - 1 >= 1) & GAPOK(i - 1) & GAPOK(i);
+        const bool ok_up = up_ok & GAPOK(i - 1) & GAPOK(j + 1);
+        const double l_fmso = tab[VL_FMSO * ts + (unsigned)((ok_so ? d + 1 : d) * ld + i)];
+        const double l_fm1o = tab[VL_FM1O * ts + (unsigned)((ok_1o ? d + 1 : d) * ld + (ok_1o ? i - 1 : i))];
+        const double l_up = tab[VL_FM1O * ts + (unsigned)((ok_up ? d + 2 : d) * ld + (ok_up ? i - 1 : i))];
+        const double l_f5o = f5o[j + 1], l_f5i = f5i[i - 1], l_z = f5i[n], l_fc = tab[VL_FC * ts + at];
+        double l_x = 0.0;
+        if constexpr (CUT) {   // stem of one of the exterior halves of the loop around the missing gap
+            const size_t o = (size_t)sq * ld;
+            const bool right = i > cut, left = j + 1 <= cut;
+            const double a1 = (right ? B.xpo : B.xso)[o + (right ? j + 1 : i)], a2 = (right ? B.xp : B.xs)[o + (right ? i - 1 : (left ? j + 2 : 1))];
+            l_x = (right | left) ? a1 * a2 : 0.0;
         }
-        o_f5o = f5o[j + 1]; o_f5i = f5i[i - 1]; o_z = f5i[n];
-        o_fc = tab[VL_FC * ts + at];
-        if (up_ok && GAPOK(i - 1) && GAPOK(j + 1)) o_fm1o_up = tab[VL_FM1O * ts + (d + 2) * ld + i - 1];
-        // stem of one of the exterior halves of the loop around the missing gap
-        if (CUT && i > cut) o_x = B.xpo[(size_t)sq * ld + j + 1] * B.xp[(size_t)sq * ld + i - 1];
-        if (CUT && j + 1 <= cut) o_x = B.xso[(size_t)sq * ld + i] * B.xs[(size_t)sq * ld + j + 2];
-        if (pairable) {
-            // the seven tabulated shapes: outer pair letters (io, jo+1) = (i-1-l1, j+2+l2), raw outside cell (io, jo)
-            const double* __restrict__ fco = tab + VL_FCO * ts;
+        // the seven tabulated shapes: outer pair letters (io, jo+1) = (i-1-l1, j+2+l2), raw outside cell (io, jo)
+        const double* __restrict__ fco = tab + VL_FCO * ts;
+        double sv[7], sw[7];
+        bool sok[7];
 #pragma unroll
-            for (int k = 0; k < 7; k++) {
-                const int l1 = (k == 2 || k == 3 || k == 4) ? 1 : (k >= 5 ? 2 : 0);
-                const int l2 = (k == 1 || k == 3 || k == 5) ? 1 : ((k == 4 || k == 6) ? 2 : 0);
-                const int io = i - 1 - l1, jo = j + 1 + l2;
-                if (io >= 1 && jo <= n - 1 && l1 <= l1max && l2 <= l2max) {
-                    const int to = vienna_ptype(s[io], s[jo + 1]);
-                    const double v = fco[(jo - io) * ld + io];
-                    sm7 = fma(v, small_w(L, l1, l2, to, type, s[io + 1], s[jo], s_im1, s_jp2), sm7);
-                }
-            }
+        for (int k = 0; k < 7; k++) {
+            const int l1 = (k == 2 || k == 3 || k == 4) ? 1 : (k >= 5 ? 2 : 0);
+            const int l2 = (k == 1 || k == 3 || k == 5) ? 1 : ((k == 4 || k == 6) ? 2 : 0);
+            const int io = i - 1 - l1, jo = j + 1 + l2;
+            sok[k] = pairable & (io >= 1) & (jo <= n - 1) & (l1 <= l1max) & (l2 <= l2max);
+            // letters io, io+1 and jo, jo+1 out of the eight held
+            const int s_io = l1 == 0 ? s_im1 : (l1 == 1 ? b_im2 : b_im3), s_io1 = l1 == 0 ? s_i : (l1 == 1 ? s_im1 : b_im2);
+            const int s_jo = l2 == 0 ? s_jp1 : (l2 == 1 ? s_jp2 : b_jp3), s_jo1 = l2 == 0 ? s_jp2 : (l2 == 1 ? b_jp3 : b_jp4);
+            const int to = vienna_ptype(s_io, s_jo1);
+            sv[k] = fco[(unsigned)(sok[k] ? (jo - io) * ld + io : d * ld + i)];
+            sw[k] = small_w(L, l1, l2, to, type, s_io1, s_jo, s_im1, s_jp2);
         }
+        e_txo = l_txo; e_tmc = l_tmc; e_txi = l_txi; e_tsa = l_tsa; e_tau = l_tau;
+        o_fmso = ok_so ? l_fmso : 0.0; o_fm1o = ok_1o ? l_fm1o : 0.0; o_fm1o_up = ok_up ? l_up : 0.0;
+        o_f5o = l_f5o; o_f5i = l_f5i; o_z = l_z; o_fc = l_fc; o_x = l_x;
+#pragma unroll
+        for (int k = 0; k < 7; k++) sm7 = fma(sok[k] ? sv[k] : 0.0, sw[k], sm7);
     }
 
     double sm = accm, s1 = acc1, g = accc, gb = accb;
