@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void vlin_co_seed(McBatch B, McBatch S)
 // taps) and leaves them in B.rowp; the MODE 2 launch of d+1 (one wavefront per group) adds the two fresh FM2 terms and runs
 // the epilogue.  F5 / XP / XS groups run in both launches unchanged.
 template <int W, int BS, bool CUT, int MODE>
-__global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) __attribute__((amdgpu_waves_per_eu(MODE == 1 ? RH_VLA_WPE : 6, 8))) void vlin_inside_diag(McBatch B, const VLinModel* __restrict__ L, int d, double hp_d, int pin)
+__global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) __attribute__((amdgpu_waves_per_eu(MODE == 0 ? 6 : RH_VLA_WPE, 8))) void vlin_inside_diag(McBatch B, const VLinModel* __restrict__ L, int d, double hp_d, int pin)
 {
     constexpr int WR = MODE == 2 ? 1 : W;
     __shared__ double part[MODE == 1 ? 6 : 3][WR][64];
@@ -356,15 +356,20 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) __attribute__((amdgpu_wave
             if (J1 - I >= 4) { kA1 = (I + 2) * BS; kB1 = (J1 - 1) * BS; }
         }
         if constexpr (MODE == 2) {
-            // the look-ahead sum of the previous launch + the two terms that touch row d-1
-            if (valid) {
-                acc2 = rowp[i];
-                if (d >= 2) {
-                    const int k1 = i + 1, k2 = i + d - 1;
-                    if (k1 < kA || k1 >= kB) acc2 = fma(fm1[ld], fm[(d - 1) * ld + 1], acc2);                       // m = 1
-                    if (d >= 3 && (k2 < kA || k2 >= kB)) acc2 = fma(fm1[(d - 1) * ld], fm[ld + d - 1], acc2);        // m = d-1
-                }
-                if (BS > 0 && kB > 0) acc2 += tab[VL_FM2F * ts + d * ld + i];
+            // the look-ahead sum of the previous launch + the two terms that touch row d-1: six loads, requested together and
+            // selected afterwards (a lane past the diagonal reads its neighbours' cells; fma results it does not want are dropped whole)
+            {
+                const int dm = d >= 1 ? d - 1 : 0;
+                const double r0 = rowp[i], a1 = fm1[ld], b1 = fm[dm * ld + 1], a2 = fm1[dm * ld], b2 = fm[ld + dm];
+                const double f2 = tab[VL_FM2F * ts + d * ld + i];
+                const int k1 = i + 1, k2 = i + d - 1;
+                const bool c1 = valid & (d >= 2) & ((k1 < kA) | (k1 >= kB)), c2 = valid & (d >= 3) & ((k2 < kA) | (k2 >= kB));
+                acc2 = valid ? r0 : 0.0;
+                const double t1 = fma(a1, b1, acc2);
+                acc2 = c1 ? t1 : acc2;                                                                              // m = 1
+                const double t2 = fma(a2, b2, acc2);
+                acc2 = c2 ? t2 : acc2;                                                                              // m = d-1
+                acc2 = (valid & (BS > 0) & (kB > 0)) ? acc2 + f2 : acc2;
             }
         } else {
         constexpr int UF = MODE == 1 ? 6 : 8;
@@ -396,7 +401,7 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) __attribute__((amdgpu_wave
     // ---- generic interior loops (LDS-staged filters over FCX) and long bulges (two taps per length over FCB)
     double accc = 0.0, accb = 0.0, acccn = 0.0, accbn = 0.0;
     if constexpr (MODE == 2) {
-        if (valid) { accc = rowp[ld + i]; accb = rowp[2 * ld + i]; }
+        { const double rc = rowp[ld + i], rb = rowp[2 * ld + i]; accc = valid ? rc : 0.0; accb = valid ? rb : 0.0; }
         if (!pairable) { accc = 0.0; accb = 0.0; }
     } else if constexpr (MODE == 1) {
         // staged row r = 2..31 is table row d-1-r: filter / bulge length t = r-1 of diagonal d and t = r of diagonal d+1
@@ -610,7 +615,7 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) __attribute__((amdgpu_wave
 // filter of length t+1 over the staged row of the filter of length t, the bulge taps) into B.rowp; the MODE 2 launch of d-1
 // (one wavefront per group) adds the two e = 1 terms and runs the epilogue.  Pairs are (odd, even) whatever the batch.
 template <int W, int BS, bool CUT, int MODE>
-__global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) __attribute__((amdgpu_waves_per_eu(MODE == 1 ? RH_VLA_WPE : 6, 8))) void vlin_outside_diag(McBatch B, const VLinModel* __restrict__ L, int d, int pin, int* __restrict__ bad)
+__global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) __attribute__((amdgpu_waves_per_eu(MODE == 0 ? 6 : RH_VLA_WPE, 8))) void vlin_outside_diag(McBatch B, const VLinModel* __restrict__ L, int d, int pin, int* __restrict__ bad)
 {
     constexpr int WR = MODE == 2 ? 1 : W;
     __shared__ double part[MODE == 1 ? 8 : 4][WR][64];
@@ -724,19 +729,25 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) __attribute__((amdgpu_wave
     double accm = 0.0, acc1 = 0.0, accc = 0.0, accb = 0.0;
     double accmn = 0.0, acc1n = 0.0, acccn = 0.0, accbn = 0.0;   // MODE 1: diagonal d-1 without its e = 1 terms
     if constexpr (MODE == 2) {
-        // the look-ahead sums of the previous launch + the e = 1 terms (row d+1) + the block products
-        if (valid) {
-            accm = rowp[i]; acc1 = rowp[B.ld + i]; accc = rowp[2 * B.ld + i]; accb = rowp[3 * B.ld + i];
-            if (guard_m) {
-                int mineA = i - 1, mineB = n - 1 - j;
-                if (BS > 0) {
-                    const int limA = i - (i / (BS > 0 ? BS : 1) - 1) * BS, limB = (j / (BS > 0 ? BS : 1) + 2) * BS - 1 - j;
-                    mineA = mineA < limA ? mineA : limA; mineB = mineB < limB ? mineB : limB;
-                }
-                if (1 <= mineA) accm = fma(tab[VL_FM2O * ts + (d + 1) * ld + i - 1], tab[VL_FM1 * ts + ld + i - 1], accm);
-                if (1 <= mineB) acc1 = fma(tab[VL_FM2O * ts + (d + 1) * ld + i], tab[VL_FM * ts + ld + j], acc1);
-                if (BS > 0) { accm += tab[VL_FMOF * ts + d * ld + i]; acc1 += tab[VL_FM1OF * ts + d * ld + i]; }
-            } else { accm = 0.0; acc1 = 0.0; }
+        // the look-ahead sums of the previous launch + the e = 1 terms (row d+1) + the block products: ten loads, requested together
+        // (rows d+1 and 1 exist for every d this launch sees; columns of a lane past the diagonal lie in the table) and selected afterwards
+        {
+            const double r0 = rowp[i], r1 = rowp[B.ld + i], r2 = rowp[2 * B.ld + i], r3 = rowp[3 * B.ld + i];
+            const unsigned up = (unsigned)((d + 1) * ld + i), jc = (unsigned)(j <= n ? j : n);
+            const double xa = tab[VL_FM2O * ts + up - 1], ya = tab[VL_FM1 * ts + (unsigned)(ld + i - 1)];
+            const double xb = tab[VL_FM2O * ts + up], yb = tab[VL_FM * ts + (unsigned)ld + jc];
+            const double fa = tab[VL_FMOF * ts + (unsigned)(d * ld + i)], fb = tab[VL_FM1OF * ts + (unsigned)(d * ld + i)];
+            int mineA = i - 1, mineB = n - 1 - j;
+            if (BS > 0) {
+                const int limA = i - (i / (BS > 0 ? BS : 1) - 1) * BS, limB = (j / (BS > 0 ? BS : 1) + 2) * BS - 1 - j;
+                mineA = mineA < limA ? mineA : limA; mineB = mineB < limB ? mineB : limB;
+            }
+            const bool gm = valid & guard_m;
+            accm = gm ? r0 : 0.0; acc1 = gm ? r1 : 0.0; accc = valid ? r2 : 0.0; accb = valid ? r3 : 0.0;
+            const double ta = fma(xa, ya, accm), tb = fma(xb, yb, acc1);
+            accm = (gm & (1 <= mineA)) ? ta : accm;
+            acc1 = (gm & (1 <= mineB)) ? tb : acc1;
+            if (BS > 0) { accm = gm ? accm + fa : accm; acc1 = gm ? acc1 + fb : acc1; }
         }
         if (!pairable) { accc = 0.0; accb = 0.0; }
     } else {
