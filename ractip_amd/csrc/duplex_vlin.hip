@@ -115,16 +115,25 @@ __global__ __launch_bounds__(256) void dxvl_sweep4(DxLinBatch B, const VLinModel
 
     // ---- loops of length >= 2 (all four wavefronts): stage the mismatch-decorated rows t = w, w+4, ..., then filter
     const double* __restrict__ src = tab + T_MM * ts + kDxPad;
+    {   // all sixteen loads first, unconditional (a row that does not exist reads row 2 and is never used): behind `if (row exists)` each
+        // was waited for inside its branch, one memory round trip per row
+        double v0[8], v1[8];
 #pragma unroll
-    for (int q = 0; q < 8; q++) {
-        const int t = w + 4 * q;
-        const int row = outside ? sdA + 2 + t : sdA - 2 - t;
-        if (t <= kMaxSingle && row >= 2 && row <= smax) {   // wave-uniform
+        for (int q = 0; q < 8; q++) {
+            const int t = w + 4 * q;
+            const int row = outside ? sdA + 2 + t : sdA - 2 - t;
+            const bool on = t <= kMaxSingle && row >= 2 && row <= smax;   // wave-uniform
             const int skip = t > 27 ? t - 27 : 0;
-            const int c0 = outside ? a0 + 1 : a0 - 4 - t + skip;
-            const double* __restrict__ r = src + (size_t)row * lda + c0;
-            buf[w][q][lane] = r[lane];
-            if (lane < 32) buf[w][q][64 + lane] = r[64 + lane];
+            const int c0 = outside ? a0 + 1 : a0 - 4 - t + skip;           // >= -kDxPad - 3: inside the padded row or the end of the one before
+            const double* __restrict__ r = src + (size_t)(on ? row : 2) * lda + c0;
+            v0[q] = r[lane]; v1[q] = r[64 + (lane & 31)];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) { asm volatile("" : "+v"(v0[q])); asm volatile("" : "+v"(v1[q])); }
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            buf[w][q][lane] = v0[q];
+            if (lane < 32) buf[w][q][64 + lane] = v1[q];
         }
     }
     double accg[4] = {0.0, 0.0, 0.0, 0.0}, accb[4] = {0.0, 0.0, 0.0, 0.0};
@@ -139,20 +148,30 @@ __global__ __launch_bounds__(256) void dxvl_sweep4(DxLinBatch B, const VLinModel
     // ---- epilogue of X_w: letters, pair type, the tabulated shapes whose rows are final (before the barrier)
     const int b = sdw - a, i = a, j = L2 + 1 - b;
     const bool incell = mine && a >= 1 && a <= L1 && b >= 1 && b <= L2;
-    int x = 0, xm = 0, xp = 0, y = 0, ym = 0, yp = 0;
-    if (incell) { x = s1[i]; xm = s1[i - 1]; xp = s1[i + 1]; y = s2[j]; ym = s2[j - 1]; yp = s2[j + 1]; }
+    // letters i-3 .. i+3 of s1 and j-3 .. j+3 of s2 (clamped into the padded sequences): everything the seven tabulated shapes index
+    // with, requested at once; pair types are arithmetic, every table value is loaded unconditionally and selected afterwards
+    int c1[7], c2[7];
+    {
+        const int ic = incell ? i : 1, jc = incell ? j : 1;
+#pragma unroll
+        for (int u = 0; u < 7; u++) {
+            const int p1 = ic + u - 3, p2 = jc + u - 3;
+            c1[u] = s1[p1 < 0 ? 0 : (p1 > L1 + 1 ? L1 + 1 : p1)];
+            c2[u] = s2[p2 < 0 ? 0 : (p2 > L2 + 1 ? L2 + 1 : p2)];
+        }
+    }
+    const int x = c1[3], xm = c1[2], xp = c1[4], y = c2[3], ym = c2[2], yp = c2[4];
     const int type = incell ? vienna_ptype(x, y) : 0;
     const bool pairable = type != 0;
     const double* __restrict__ rawt = tab + T_RAW * ts + kDxPad;
     double sm7 = 0.0, e_tau = 1.0, mm_up = 0.0, mm_dn = 0.0, ends = 0.0;
     double c_st = 0.0, c_b01 = 0.0, c_b10 = 0.0;   // weights of the shapes of X_2 / X_3 whose source row belongs to this launch
-    if (pairable) {
+    {
         const int rt = vienna_rtype(type);
-        e_tau = L->E_tau[type];
-        mm_up = D->E_mmI[type * 25 + xp * 5 + ym];   // this pair as the upstream end of a generic loop
-        mm_dn = D->E_mmI[rt * 25 + yp * 5 + xm];     // ... as the downstream end
-        if (!outside) ends = D->E_init * (i > 1 ? D->E_d5[type * 5 + xm] : 1.0) * (j < L2 ? D->E_d3[type * 5 + yp] : 1.0) * e_tau;   // pf_duplex.c:321-326
-        else ends = (i < L1 ? D->E_d3[rt * 5 + xp] : 1.0) * (j > 1 ? D->E_d5[rt * 5 + ym] : 1.0) * e_tau;                            // pf_duplex.c:361-365
+        const double l_tau = L->E_tau[type], l_up = D->E_mmI[type * 25 + xp * 5 + ym], l_dn = D->E_mmI[rt * 25 + yp * 5 + xm];
+        const double l_d5i = D->E_d5[type * 5 + xm], l_d3i = D->E_d3[type * 5 + yp], l_d3o = D->E_d3[rt * 5 + xp], l_d5o = D->E_d5[rt * 5 + ym];
+        double sv[7], sw[7];
+        bool sok[7];
 #pragma unroll
         for (int k = 0; k < 7; k++) {
             const int l1 = (k == 2 || k == 3 || k == 4) ? 1 : (k >= 5 ? 2 : 0);
@@ -161,16 +180,28 @@ __global__ __launch_bounds__(256) void dxvl_sweep4(DxLinBatch B, const VLinModel
             const int srow = sdw + dir * (2 + l1 + l2), scol = a + dir * (1 + l1);
             // source cell letters: inside (i-1-l1, j+1+l2), outside (i+1+l1, j-1-l2)
             const int si = i + dir * (1 + l1), sj = j - dir * (1 + l2);
-            if (srow < 2 || srow > smax || si < 1 || si > L1 || sj < 1 || sj > L2) continue;
-            const int ts_ = vienna_ptype(s1[si], s2[sj]);
-            if (!ts_) continue;
-            const int n1 = s1[si - dir], n2 = s2[sj + dir];   // the letters next to the source pair inside the loop
-            const double wgt = outside ? small_wd(L, l1, l2, type, ts_, xp, ym, n1, n2) : small_wd(L, l1, l2, ts_, type, n1, n2, xm, yp);
+            // held letters: s1[i+o] = c1[3+o], s2[j+o] = c2[3+o]
+            const int o1 = dir * (1 + l1), o2 = -dir * (1 + l2);
+            const int ts_ = vienna_ptype(c1[3 + o1], c2[3 + o2]);
+            const int n1 = c1[3 + o1 - dir], n2 = c2[3 + o2 + dir];   // the letters next to the source pair inside the loop
+            sok[k] = pairable & (srow >= 2) & (srow <= smax) & (si >= 1) & (si <= L1) & (sj >= 1) & (sj <= L2) & (ts_ != 0);
+            sw[k] = outside ? small_wd(L, l1, l2, type, ts_, xp, ym, n1, n2) : small_wd(L, l1, l2, ts_, type, n1, n2, xm, yp);
             const bool fresh = (w == 2 && k == 0) || (w == 3 && k <= 2);   // row of this launch: value arrives through `hand`
-            if (!fresh) sm7 = fma(rawt[(size_t)srow * lda + scol], wgt, sm7);
-            else if (k == 0) c_st = wgt;
-            else if (k == 1) c_b01 = wgt;
-            else c_b10 = wgt;
+            const int rc = (srow >= 2 && srow <= smax) ? srow : 2, cc = scol < -kDxPad ? -kDxPad : (scol > B.n1max + 1 + kDxPad ? B.n1max + 1 + kDxPad : scol);
+            sv[k] = fresh ? 0.0 : rawt[(size_t)rc * lda + cc];
+        }
+        if (pairable) {
+            e_tau = l_tau; mm_up = l_up; mm_dn = l_dn;
+            if (!outside) ends = D->E_init * (i > 1 ? l_d5i : 1.0) * (j < L2 ? l_d3i : 1.0) * e_tau;   // pf_duplex.c:321-326
+            else ends = (i < L1 ? l_d3o : 1.0) * (j > 1 ? l_d5o : 1.0) * e_tau;                         // pf_duplex.c:361-365
+        }
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+            const bool fresh = (w == 2 && k == 0) || (w == 3 && k <= 2);
+            if (!fresh) sm7 = fma(sok[k] ? sv[k] : 0.0, sok[k] ? sw[k] : 0.0, sm7);
+            else if (k == 0) c_st = sok[k] ? sw[k] : 0.0;
+            else if (k == 1) c_b01 = sok[k] ? sw[k] : 0.0;
+            else c_b10 = sok[k] ? sw[k] : 0.0;
         }
     }
     // X_3's bulges of length 2 lie on row A + dir (window index t = -1: no other diagonal uses it, so it is not staged)
