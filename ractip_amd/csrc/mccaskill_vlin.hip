@@ -1111,16 +1111,21 @@ __global__ __launch_bounds__(256) void vlin_acc_gaps(McBatch B, const VLinModel*
         const int pc = right ? pos - 1 - D : pos;
         return (live && pc >= 1 && pc + D <= n - 1) ? T[(size_t)D * ld + pc] : 0.0;
     };
-    double win[NW];
+#ifndef RH_ACC_UR
+#define RH_ACC_UR 2   // measured: 2 -> 28.2 ms (outside + accessibility), 4 -> 28.7, 8 -> 31.6: the kernel runs at the copy bandwidth (33 GB per 128 sequences)
+#endif
+    // inner spans per batch of loads.  The window holds the outer values of the WHOLE batch (NW + UR - 1 of them), so that it slides by UR
+    // once per batch (30 register moves per UR spans; sliding by one per span cost as many moves as the span has FMAs)
+    constexpr int UR = RH_ACC_UR;
+    double win[NW + UR - 1];
 #pragma unroll
-    for (int o = 0; o < NW; o++) win[o] = outer_at(FCOX, 2 + g + o);
+    for (int o = 0; o < NW + UR - 1; o++) win[o] = outer_at(FCOX, 2 + g + o);
     const int kl = right ? pos - 1 - g : pos + 1 + g;   // inner 3' letter l (right) resp. inner 5' letter k (left)
     const int rmax = right ? kl - 2 : n - 1 - kl;       // inner spans 0..rmax are interior
     double acc = 0.0;
     // largest interior inner span of any thread of this block (threads are consecutive letters)
     const int pos_lo = blockIdx.x * blockDim.x + 1, pos_hi = pos_lo + (int)blockDim.x - 1 < n ? pos_lo + (int)blockDim.x - 1 : n;
     const int rlim = right ? pos_hi - 1 - g - 2 : n - 1 - (pos_lo + 1 + g);
-    constexpr int UR = 2;   // inner spans per batch of loads (measured: 2 best, 4 -3 %, 8 -9 % on the accessibility phase) (all loads of a batch are issued before any arithmetic)
     for (int r0 = 0; r0 <= rlim; r0 += UR) {
         double xs[UR], wn[UR], bo[UR], bi[UR];
         bool ok[UR];
@@ -1132,7 +1137,7 @@ __global__ __launch_bounds__(256) void vlin_acc_gaps(McBatch B, const VLinModel*
             const int kc = right ? kl - 1 - r : kl;          // inner cell column
             ics[u] = (size_t)r * ld + (ok[u] ? kc : 1);
             xs[u] = ok[u] ? FCX[ics[u]] : 0.0;
-            wn[u] = outer_at(FCOX, r + 1 + 2 + g + (NW - 1));   // enters the window after inner span r
+            wn[u] = outer_at(FCOX, r0 + UR + 2 + g + (NW - 1) + u);   // enters the window of the next batch at index NW-1+u
             bo[u] = (ok[u] && g >= 2) ? outer_at(FCOB, r + 2 + g) : 0.0;   // bulge (own gap g >= 2, other gap 0)
             bi[u] = (ok[u] && g >= 2) ? FCB[ics[u]] : 0.0;
         }
@@ -1141,34 +1146,40 @@ __global__ __launch_bounds__(256) void vlin_acc_gaps(McBatch B, const VLinModel*
             const int r = r0 + u;
             double sum = 0.0;
 #pragma unroll
-            for (int o = 0; o < NW; o++) sum = fma(wt[o], win[o], sum);
+            for (int o = 0; o < NW; o++) sum = fma(wt[o], win[u + o], sum);
             acc = fma(xs[u], sum, acc);
             acc = fma(bo[u] * L->WB[g], bi[u], acc);
-            // the tabulated shapes that involve this gap length
-            if (ok[u] && g <= 2) {
+            // the tabulated shapes that involve this gap length (g <= 2: four of the sixty slices).  Two batches of loads -- letters and
+            // table cells, then the loop weights -- with no data-dependent branch in front of any of them: behind `if (fc != 0)` ...
+            // `if (fo == 0) continue` every cell paid four or five dependent round trips, and these slices set the kernel's duration
+            if (g <= 2) {
+                const auto clampi = [](int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); };
+                const int k = right ? kl - 1 - r : kl, l = k + r + 1;          // inner pair letters
                 const double fc = FC[ics[u]];
-                if (fc != 0.0) {
-                    const int k = right ? kl - 1 - r : kl, l = k + r + 1;      // inner pair letters
-                    const int ti = vienna_ptype(s[k], s[l]);
-                    for (int o = 0; o <= 2; o++) {
-                        const int l1 = right ? o : g, l2 = right ? g : o;
-                        const bool tabulated = (l1 <= 2 && l2 <= 2) && !(l1 + l2 == 2 && (l1 == 0 || l2 == 0));   // 0x2 / 2x0 are bulges
-                        if (!tabulated) continue;
-                        const int D = r + 2 + g + o;
-                        const int p = k - 1 - l1, q = p + D + 1;
-                        if (p < 1 || q > n) continue;
-                        const double fo = FCO[(size_t)D * ld + p];
-                        if (fo == 0.0) continue;
-                        const int to = vienna_ptype(s[p], s[q]);
-                        acc = fma(fo * small_w(L, l1, l2, to, ti, s[p + 1], s[q - 1], s[k - 1], s[l + 1]), fc, acc);
-                    }
-                }
-            }
-            // slide the window: the outer values of r+1 are those of r one o further
+                const int sk = s[clampi(k, n + 1)], sl = s[clampi(l, n + 1)], skm = s[clampi(k - 1, n + 1)], slp = s[clampi(l + 1, n + 1)];
+                const int ti = vienna_ptype(sk, sl);
+                double fo[3], sw[3];
+                bool use[3];
 #pragma unroll
-            for (int o = 0; o + 1 < NW; o++) win[o] = win[o + 1];
-            win[NW - 1] = wn[u];
+                for (int o = 0; o <= 2; o++) {
+                    const int l1 = right ? o : g, l2 = right ? g : o;
+                    const bool tabulated = (l1 <= 2 && l2 <= 2) && !(l1 + l2 == 2 && (l1 == 0 || l2 == 0));   // 0x2 / 2x0 are bulges
+                    const int D = r + 2 + g + o;
+                    const int p = k - 1 - l1, q = p + D + 1;
+                    use[o] = ok[u] & tabulated & (p >= 1) & (q <= n);
+                    fo[o] = FCO[(size_t)(use[o] ? D : 0) * ld + (use[o] ? p : 1)];
+                    const int sp = s[clampi(p, n + 1)], sq_ = s[clampi(q, n + 1)], spp = s[clampi(p + 1, n + 1)], sqm = s[clampi(q - 1, n + 1)];
+                    sw[o] = small_w(L, l1, l2, vienna_ptype(sp, sq_), ti, spp, sqm, skm, slp);
+                }
+#pragma unroll
+                for (int o = 0; o <= 2; o++) acc = fma(use[o] ? fo[o] * sw[o] : 0.0, use[o] ? fc : 0.0, acc);
+            }
         }
+        // slide the window by the batch
+#pragma unroll
+        for (int o = 0; o + 1 < NW; o++) win[o] = win[o + UR];
+#pragma unroll
+        for (int u = 0; u < UR; u++) win[NW - 1 + u] = wn[u];
     }
     // layout [side][g][pos]: consecutive lanes = consecutive letters (vlin_acc_gsuf / vlin_acc_final read it the same way)
     if (live) gaps[((size_t)(2 * sq + (right ? 1 : 0)) * 32 + g) * ld + pos] = acc / Z;
