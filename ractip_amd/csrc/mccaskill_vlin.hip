@@ -1080,12 +1080,15 @@ __global__ __launch_bounds__(256) void vlin_acc_prep(McBatch B, const VLinModel*
 // values needed for r+1 are those of r shifted by one o: they live in a 31-entry register window, one new load per r
 // (instead of 31), the generic weights w(g,o) in scalar registers.  Bulges and the tabulated small loops are a handful
 // of (g,o) combinations and are added with direct loads.
-__global__ __launch_bounds__(256) void vlin_acc_gaps(McBatch B, const VLinModel* __restrict__ L, double* __restrict__ gaps)
+__global__ __launch_bounds__(256) void vlin_acc_gaps(McBatch B, const VLinModel* __restrict__ L, double* __restrict__ gaps, int ng, int nchunk, double* __restrict__ part)
 {
     const int sq = blockIdx.y;
     const int n = B.n[sq], ld = B.ld;
-    const int g = blockIdx.z % 30 + 1;
-    const bool right = blockIdx.z >= 30;
+    // blockIdx.z = chunk * 2 ng + slice: gap lengths 1..ng per side; nchunk > 1: the inner spans are dealt to nchunk workgroups in
+    // contiguous ranges and the partial sums go to `part` (vlin_acc_gsum adds them in chunk order)
+    const int chunk = blockIdx.z / (2 * ng), slice = blockIdx.z % (2 * ng);
+    const int g = slice % ng + 1;
+    const bool right = slice >= ng;
     const int pos = blockIdx.x * blockDim.x + threadIdx.x + 1;   // p (left) or q (right)
     const bool live = pos <= n;
     const uint8_t* __restrict__ s = B.seq + (size_t)sq * B.lds;
@@ -1118,16 +1121,30 @@ __global__ __launch_bounds__(256) void vlin_acc_gaps(McBatch B, const VLinModel*
     // once per batch (30 register moves per UR spans; sliding by one per span cost as many moves as the span has FMAs)
     constexpr int UR = RH_ACC_UR;
     double win[NW + UR - 1];
+    const int rcs = (((B.nmax + nchunk - 1) / nchunk) + UR - 1) / UR * UR, r_begin = chunk * rcs;   // this workgroup's inner spans: r_begin .. r_begin+rcs-1
 #pragma unroll
-    for (int o = 0; o < NW + UR - 1; o++) win[o] = outer_at(FCOX, 2 + g + o);
+    for (int o = 0; o < NW + UR - 1; o++) win[o] = outer_at(FCOX, r_begin + 2 + g + o);
     const int kl = right ? pos - 1 - g : pos + 1 + g;   // inner 3' letter l (right) resp. inner 5' letter k (left)
     const int rmax = right ? kl - 2 : n - 1 - kl;       // inner spans 0..rmax are interior
     double acc = 0.0;
+    // letters of the tabulated shapes (g <= 2).  One end of the inner pair and of every outer pair is fixed for a thread; the other
+    // ends are the four letters c0 + dir*(r + j), j = 0..3 (left: l, l+1 and q = l+1+o, q-1; right: k, k-1 and p = k-1-o, p+1), a
+    // window that slides by one per inner span: one new letter per span instead of sixteen loads
+    const auto clampi = [](int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); };
+    const int c0 = right ? kl - 1 : kl + 1, dir = right ? -1 : 1;
+    const auto letter = [&](int j) -> int { return s[clampi(c0 + dir * j, n + 1)]; };
+    const int f_in0 = s[clampi(kl, n + 1)], f_in1 = s[clampi(right ? kl + 1 : kl - 1, n + 1)];       // left: k, k-1; right: l, l+1
+    const int f_out0 = s[clampi(pos, n + 1)], f_out1 = s[clampi(right ? pos - 1 : pos + 1, n + 1)];   // left: p, p+1; right: q, q-1
+    int V[UR + 3];
+#pragma unroll
+    for (int j = 0; j < UR + 3; j++) V[j] = g <= 2 ? letter(r_begin + j) : 0;
     // largest interior inner span of any thread of this block (threads are consecutive letters)
     const int pos_lo = blockIdx.x * blockDim.x + 1, pos_hi = pos_lo + (int)blockDim.x - 1 < n ? pos_lo + (int)blockDim.x - 1 : n;
     const int rlim = right ? pos_hi - 1 - g - 2 : n - 1 - (pos_lo + 1 + g);
-    for (int r0 = 0; r0 <= rlim; r0 += UR) {
+    const int r_end = rlim < r_begin + rcs - 1 ? rlim : r_begin + rcs - 1;
+    for (int r0 = r_begin; r0 <= r_end; r0 += UR) {
         double xs[UR], wn[UR], bo[UR], bi[UR];
+        int nl[UR];
         bool ok[UR];
         size_t ics[UR];
 #pragma unroll
@@ -1140,6 +1157,7 @@ __global__ __launch_bounds__(256) void vlin_acc_gaps(McBatch B, const VLinModel*
             wn[u] = outer_at(FCOX, r0 + UR + 2 + g + (NW - 1) + u);   // enters the window of the next batch at index NW-1+u
             bo[u] = (ok[u] && g >= 2) ? outer_at(FCOB, r + 2 + g) : 0.0;   // bulge (own gap g >= 2, other gap 0)
             bi[u] = (ok[u] && g >= 2) ? FCB[ics[u]] : 0.0;
+            nl[u] = g <= 2 ? letter(r0 + UR + 3 + u) : 0;     // enters the letter window of the next batch at index 3+u
         }
 #pragma unroll
         for (int u = 0; u < UR; u++) {
@@ -1153,10 +1171,9 @@ __global__ __launch_bounds__(256) void vlin_acc_gaps(McBatch B, const VLinModel*
             // table cells, then the loop weights -- with no data-dependent branch in front of any of them: behind `if (fc != 0)` ...
             // `if (fo == 0) continue` every cell paid four or five dependent round trips, and these slices set the kernel's duration
             if (g <= 2) {
-                const auto clampi = [](int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); };
-                const int k = right ? kl - 1 - r : kl, l = k + r + 1;          // inner pair letters
+                const int k = right ? kl - 1 - r : kl;                         // inner pair (k, l = k+r+1)
                 const double fc = FC[ics[u]];
-                const int sk = s[clampi(k, n + 1)], sl = s[clampi(l, n + 1)], skm = s[clampi(k - 1, n + 1)], slp = s[clampi(l + 1, n + 1)];
+                const int sk = right ? V[u] : f_in0, skm = right ? V[u + 1] : f_in1, sl = right ? f_in0 : V[u], slp = right ? f_in1 : V[u + 1];
                 const int ti = vienna_ptype(sk, sl);
                 double fo[3], sw[3];
                 bool use[3];
@@ -1168,7 +1185,8 @@ __global__ __launch_bounds__(256) void vlin_acc_gaps(McBatch B, const VLinModel*
                     const int p = k - 1 - l1, q = p + D + 1;
                     use[o] = ok[u] & tabulated & (p >= 1) & (q <= n);
                     fo[o] = FCO[(size_t)(use[o] ? D : 0) * ld + (use[o] ? p : 1)];
-                    const int sp = s[clampi(p, n + 1)], sq_ = s[clampi(q, n + 1)], spp = s[clampi(p + 1, n + 1)], sqm = s[clampi(q - 1, n + 1)];
+                    const int sp = right ? V[u + 1 + o] : f_out0, spp = right ? V[u + o] : f_out1;
+                    const int sq_ = right ? f_out0 : V[u + 1 + o], sqm = right ? f_out1 : V[u + o];
                     sw[o] = small_w(L, l1, l2, vienna_ptype(sp, sq_), ti, spp, sqm, skm, slp);
                 }
 #pragma unroll
@@ -1180,9 +1198,155 @@ __global__ __launch_bounds__(256) void vlin_acc_gaps(McBatch B, const VLinModel*
         for (int o = 0; o + 1 < NW; o++) win[o] = win[o + UR];
 #pragma unroll
         for (int u = 0; u < UR; u++) win[NW - 1 + u] = wn[u];
+#pragma unroll
+        for (int j = 0; j < 3; j++) V[j] = V[j + UR];
+#pragma unroll
+        for (int u = 0; u < UR; u++) V[3 + u] = nl[u];
     }
     // layout [side][g][pos]: consecutive lanes = consecutive letters (vlin_acc_gsuf / vlin_acc_final read it the same way)
-    if (live) gaps[((size_t)(2 * sq + (right ? 1 : 0)) * 32 + g) * ld + pos] = acc / Z;
+    if (live) {
+        if (nchunk == 1) gaps[((size_t)(2 * sq + (right ? 1 : 0)) * 32 + g) * ld + pos] = acc / Z;
+        else part[(((size_t)chunk * 2 * B.ns + 2 * sq + (right ? 1 : 0)) * ng + (g - 1)) * ld + pos] = acc / Z;
+    }
+}
+
+// gaps[side][g][pos] = sum over the chunks of vlin_acc_gaps, in chunk order (g = 1..ng)
+__global__ __launch_bounds__(256) void vlin_acc_gsum(McBatch B, double* __restrict__ gaps, const double* __restrict__ part, int ng, int nchunk)
+{
+    const int sq = blockIdx.y, side = blockIdx.z / ng, g = blockIdx.z % ng + 1;
+    const int pos = blockIdx.x * blockDim.x + threadIdx.x + 1;
+    if (pos > B.n[sq]) return;
+    double acc = 0.0;
+    for (int c = 0; c < nchunk; c++) acc += part[(((size_t)c * 2 * B.ns + 2 * sq + side) * ng + (g - 1)) * B.ld + pos];
+    gaps[((size_t)(2 * sq + side) * 32 + g) * B.ld + pos] = acc;
+}
+
+// The same sums for the gap lengths g = 3..30 (no tabulated shape involves them) with the LANES over the gap length: one letter per
+// wavefront, lane (h, gi) <-> own gap g = gi+1, other gaps o = 14h .. 14h+13.  For one letter the outer values of all its (g, o) are ONE
+// sequence in the outer span D = r+2+g+o -- FCoX[D][p] (left) / FCoX[D][q-1-D] (right), and FCoB likewise for the bulges -- kept as a
+// ring of 56 in LDS (mirrored, so a lane reads base+offset without wrapping; only spans <= r+32 carry a non-zero weight, g+o <= 30);
+// the two lanes without a gap length (gi = 30, 31 of h = 0) load the entry D = r+56 of the two rings at step r, 24 steps before its
+// first use.  A lane keeps its 14 generic weights w(g, o) AND its window of 14 outer values in registers: the window slides by one per
+// step, so a step reads one new value from the ring, and the steps are unrolled in blocks of 14 -- a quarter of the ring -- so that
+// the window rotates through fixed registers (other gap 14h+oo at step u of a block is win[(u + oo) % 14]) and every LDS address of a
+// block is one per-block register plus an immediate.  Inner cells FCX / FCB[r][column]: one load pair per step, two steps ahead, at
+// 32-bit offsets from the sequence's table block that advance by the row pitch and stop at the lane's last interior cell (the host
+// falls back to vlin_acc_gaps when a table block exceeds 4 GB).  A lane past its last span is masked out of the arithmetic; worker
+// lanes store into a scratch ring of their own so that the producers' stores need no branch.
+// vlin_acc_gaps (one thread per letter AND gap length, 31-entry register window, UR = 2 spans per batch of loads) re-reads every table
+// once per gap length; a first version of this kernel that read its whole window from LDS every step ran at the LDS bandwidth.
+__global__ __launch_bounds__(256) void vlin_acc_gaps_wide(McBatch B, const VLinModel* __restrict__ L, double* __restrict__ gaps)
+{
+    constexpr int NO = 14;                                   // other gaps per lane: o = 14h + oo (g >= 3, g+o <= 30)
+    constexpr int RN = 4 * NO;                               // ring entries
+    __shared__ double rings[4][2][2 * RN + 16];
+    __shared__ double scratch[4][64 + 2 * RN];
+    const int sq = blockIdx.y;
+    const bool right = blockIdx.z != 0;
+    const int n = B.n[sq], ld = B.ld;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, gi = lane & 31;
+    const int pos = blockIdx.x * 4 + w + 1;                  // the wavefront's letter
+    if (pos > n) return;                                     // wave-uniform
+    const int g = gi + 1;
+    const bool worker = gi >= 2 && gi < 30, prod = gi >= 30 && h == 0;
+    const double* __restrict__ tab = B.tab + (size_t)sq * B.seq_stride;
+    const size_t ts = B.tab_stride;
+    const double Z = B.f5i[(size_t)sq * ld + n];
+    double wr[NO];
+#pragma unroll
+    for (int oo = 0; oo < NO; oo++) {
+        const int o = NO * h + oo, t = g + o;
+        const bool ok = worker & (t <= kMaxSingle);   // (unconditional loads, selected afterwards: behind a branch every weight is a round trip of its own)
+        const double v = L->shape_w[ok ? t * (t + 1) / 2 + (right ? o : g) : 0];
+        wr[oo] = ok ? v : 0.0;                        // 0 for o = 0 (bulge) as in vlin_acc_gaps
+    }
+    const double wbv = L->WB[g < 31 ? g : 30];
+    const double wb = (worker & (h == 0)) ? wbv : 0.0;
+    double* const ring = &rings[w][0][0];
+    double* const ringb = &rings[w][1][0];
+    if (lane < RN) {   // spans 0..55 of both rings, one per lane: outer cell of span D for this letter = column p (left) resp. q-1-D (right); 0 outside the interior
+        const int D = lane, pc = right ? pos - 1 - D : pos;
+        const bool ok = pc >= 1 && pc + D <= n - 1;
+        const unsigned ix = (unsigned)(ok ? D * ld + pc : 1);
+        const double a = tab[VL_FCOX * ts + ix], b = tab[VL_FCOB * ts + ix];
+        ring[D] = ring[D + RN] = ok ? a : 0.0;
+        ringb[D] = ringb[D + RN] = ok ? b : 0.0;
+    }
+    const int kl = right ? pos - 1 - g : pos + 1 + g;        // inner 3' letter l (right) resp. inner 5' letter k (left)
+    const int rmax = right ? kl - 2 : n - 1 - kl;            // inner spans 0..rmax are interior
+    const int rl = right ? pos - 6 : n - pos - 5;            // the largest of them in this wavefront (g = 3)
+    // one load pair per lane and step: a worker its inner cells, a producer the ring entry of span r+56.  Either walks down one table
+    // column (left) or anti-diagonal (right): cell = first + r * stride for r <= last, the cell of `last` afterwards
+    const int stride8 = (right ? ld - 1 : ld) * 8;
+    int last = prod ? (right ? pos - 2 - RN : n - 1 - RN - pos) : rmax;
+    if ((worker && kl < 1) || !(worker || prod)) last = -1;
+    const bool any = last >= 0;
+    const int first_ix = !any ? 1 : (prod ? RN * ld + (right ? pos - 1 - RN : pos) : (right ? kl - 1 : kl));
+    const size_t t_a = (!any || worker) ? VL_FCX : (gi == 30 ? VL_FCOX : VL_FCOB);
+    const char* const tab8 = (const char*)tab;
+    unsigned off = (unsigned)((t_a * ts + first_ix) * 8);                       // byte offset of the load of step r in table t_a
+    const unsigned offmax = off + (unsigned)(any ? last : 0) * (unsigned)stride8;
+    const unsigned d_b = (unsigned)(((size_t)VL_FCB - t_a) * ts * 8);           // (mod 2^32) the same cell of FCB
+    const int last_w = worker ? last : -1;                                      // lanes whose arithmetic counts at step r: r <= last_w
+    const int last_p = prod ? last : -1;
+#ifndef RH_ACCW_PF
+#define RH_ACCW_PF 2
+#endif
+    constexpr int PF = RH_ACCW_PF;   // inner cells are loaded PF steps ahead (slot r % PF; NO % PF == 0 keeps the slots fixed registers)
+    static_assert(NO % PF == 0, "prefetch slots rotate within a block");
+    double xa[PF], xb[PF];
+#pragma unroll
+    for (int u = 0; u < PF; u++) {
+        xa[u] = *(const double*)(tab8 + off); xb[u] = *(const double*)(tab8 + (off + d_b));
+        if (u + 1 < PF) { const unsigned o2 = off + stride8; off = o2 < offmax ? o2 : offmax; }
+    }
+    typedef const volatile __attribute__((address_space(3))) double* lds_rp;
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the rings are written and read by this wavefront only
+    double win[NO];
+    {
+        const lds_rp rp = (lds_rp)(ring + (2 + g + NO * h) % RN);
+#pragma unroll
+        for (int oo = 0; oo < NO; oo++) win[oo] = rp[oo];
+    }
+    const int c_a = (g + NO * h) % RN, c_b = g % RN;
+    double* const wdst = prod ? (gi == 30 ? ring : ringb) : &scratch[w][lane];   // producers: their ring; everyone else: a scratch ring of their own
+    double acc = 0.0, accb = 0.0;
+    int r0m = 0;                                             // r0 mod RN: 0, 14, 28, 42
+    for (int r0 = 0; r0 <= rl; r0 += NO) {
+        int ba = r0m + c_a, bb = r0m + c_b;
+        ba = ba >= RN ? ba - RN : ba; bb = bb >= RN ? bb - RN : bb;
+        const lds_rp rpa = (lds_rp)(ring + ba), rpb = (lds_rp)(ringb + bb);
+        double* const wp = wdst + r0m;
+#pragma unroll
+        for (int u = 0; u < NO; u++) {
+            const int r = r0 + u;
+            const double xa0 = xa[u % PF], xb0 = xb[u % PF];
+            asm volatile("" : "+v"(xa[u % PF]), "+v"(xb[u % PF]));
+            // loads of step r+PF
+            { const unsigned o2 = off + stride8; off = o2 < offmax ? o2 : offmax; }
+            xa[u % PF] = *(const double*)(tab8 + off); xb[u % PF] = *(const double*)(tab8 + (off + d_b));
+            const double nv = rpa[u + 2 + NO];                // span r+2+g+14h+14: other gap 14h+13 of the next step
+            const double bv = rpb[u + 2];                     // bulge: own gap g, other gap 0, outer span r+2+g
+            if (r <= last_w) {
+                double s = 0.0;
+#pragma unroll
+                for (int oo = 0; oo < NO; oo++) s = fma(wr[oo], win[(u + oo) % NO], s);
+                acc = fma(xa0, s, acc);
+                accb = fma(xb0, bv, accb);
+            }
+            win[u % NO] = nv;
+            {   // span r+56 takes the place of span r, which no lane needs any more (the smallest span read at step r is r+5)
+                const double v = r <= last_p ? xa0 : 0.0;
+                wp[u] = v; wp[u + RN] = v;
+            }
+            asm volatile("" : "+v"(acc));   // (a step's FMAs stay in front of the next step's volatile ring reads: hoisted, a block's reads cost 56 VGPRs)
+        }
+        r0m = r0m + NO == RN ? 0 : r0m + NO;
+    }
+    acc = fma(wb, accb, acc);
+    acc += __shfl_xor(acc, 32, 64);
+    // layout [side][g][pos] as vlin_acc_gaps
+    if (worker && h == 0) gaps[((size_t)(2 * sq + (right ? 1 : 0)) * 32 + g) * ld + pos] = acc / Z;
 }
 
 // gap probabilities -> suffix sums over the gap length: S[g][pos] = sum_{l >= g} G[l][pos]; one thread per (letter, side)

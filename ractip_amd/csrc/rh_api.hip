@@ -70,7 +70,9 @@ __global__ void mcv_outside_diag(McBatch B, const ViennaDx* __restrict__ V, int 
 __global__ void mcv_acc_prep(McBatch B, const ViennaDx* __restrict__ V);
 __global__ void mcv_acc_hscan(McBatch B, int slot);
 __global__ void vlin_acc_prep(McBatch B, const VLinModel* __restrict__ L, const double* __restrict__ hplen);
-__global__ void vlin_acc_gaps(McBatch B, const VLinModel* __restrict__ L, double* __restrict__ gaps);
+__global__ void vlin_acc_gaps(McBatch B, const VLinModel* __restrict__ L, double* __restrict__ gaps, int ng, int nchunk, double* __restrict__ part);
+__global__ void vlin_acc_gsum(McBatch B, double* __restrict__ gaps, const double* __restrict__ part, int ng, int nchunk);
+__global__ void vlin_acc_gaps_wide(McBatch B, const VLinModel* __restrict__ L, double* __restrict__ gaps);
 __global__ void vlin_acc_hsum(McBatch B, int max_w);
 __global__ void vlin_acc_gsuf(McBatch B, double* __restrict__ gaps);
 __global__ void vlin_acc_final(McBatch B, const VLinModel* __restrict__ L, const double* __restrict__ gaps, int max_w);
@@ -275,6 +277,7 @@ struct rh_ctx {
     int far2 = -1;                 // two-level block products: -1 = by size (nmax >= 768), 0 / 1 forced (RH_FAR2)
     int far2_next = -1;            // launch-sequence state of far_outside_step
     int strip_w = 8;               // wavefronts per strip workgroup (RH_STRIP_W = 4 | 8)
+    int acc_wide = 1;              // Vienna-BL accessibility: vlin_acc_gaps_wide for the gap lengths 3..30 (RH_ACC_WIDE=0: vlin_acc_gaps for all)
     int strip_xcd = 1;             // groups of one sequence consecutive on one XCD (RH_STRIP_XCD=0: sequence-major launch order only)
     double* d_wT = nullptr;        // transposed, zero-padded single-branch weights wT[l1][t+1] of the strip kernels
     bool far_pk = true;            // ... on packed operand tiles (lin_pack_tiles + lin_far_*_pk); RH_FAR_PK=0: gather per product
@@ -507,7 +510,8 @@ int stage(rh_ctx* c, int ns, const char* const* seqs, const int* lens, bool with
         B.rowp = (double*)c->d_rowp;
         if ((rc = ensure(c, &c->d_f5, &c->cap_f5, sizeof(double) * 2 * B.ld * ns, false))) return rc;
         if ((rc = ensure(c, &c->d_up, &c->cap_up, sizeof(double) * B.ld * c->max_w * ns, false))) return rc;
-        if (vienna && (rc = ensure(c, &c->d_gaps, &c->cap_gaps, sizeof(double) * 2 * 32 * B.ld * ns, false))) return rc;
+        // gap probabilities [2 ns][32][ld] + the chunk sums of the gap lengths 1, 2 [8][2 ns][2][ld] (launch_mc_vlin)
+        if (vienna && (rc = ensure(c, &c->d_gaps, &c->cap_gaps, sizeof(double) * (2 * 32 + 8 * 2 * 2) * B.ld * ns, false))) return rc;
         if (vienna) {
             const VLinModel& H = *c->h_vlin;
             c->h_hplen.resize((size_t)B.ld);
@@ -835,7 +839,16 @@ int launch_mc_vlin(rh_ctx* c, int pin, int phase, bool co)
     hipLaunchKernelGGL(vlin_acc_prep, dim3(tiles * tiles, B.ns), dim3(256), 0, st, B, c->d_vlin, (const double*)c->d_hplen);
     hipLaunchKernelGGL(mcv_acc_hscan, dim3((B.nmax + 1 + 255) / 256, B.ns), dim3(256), 0, st, B, 10 /* VL_FM2F */);
     hipLaunchKernelGGL(vlin_acc_hsum, dim3((B.nmax + 3) / 4, B.ns), dim3(256), 0, st, B, c->max_w);
-    hipLaunchKernelGGL(vlin_acc_gaps, dim3((B.nmax + 255) / 256, B.ns, 60), dim3(256), 0, st, B, c->d_vlin, (double*)c->d_gaps);
+    if (c->acc_wide) {
+        // gap lengths 1, 2 (the tabulated shapes: six times the loads of a generic length): one thread per letter and length, the inner
+        // spans in 8 chunks; 3..30: the lanes over the gap length (vlin_acc_gaps_wide)
+        constexpr int NG = 2, NCH = 8;
+        double* part = (double*)c->d_gaps + (size_t)2 * 32 * B.ld * B.ns;
+        hipLaunchKernelGGL(vlin_acc_gaps, dim3((B.nmax + 255) / 256, B.ns, 2 * NG * NCH), dim3(256), 0, st, B, c->d_vlin, (double*)c->d_gaps, NG, NCH, part);
+        hipLaunchKernelGGL(vlin_acc_gsum, dim3((B.nmax + 255) / 256, B.ns, 2 * NG), dim3(256), 0, st, B, (double*)c->d_gaps, (const double*)part, NG, NCH);
+        hipLaunchKernelGGL(vlin_acc_gaps_wide, dim3((B.nmax + 3) / 4, B.ns, 2), dim3(256), 0, st, B, c->d_vlin, (double*)c->d_gaps);
+    } else
+        hipLaunchKernelGGL(vlin_acc_gaps, dim3((B.nmax + 255) / 256, B.ns, 60), dim3(256), 0, st, B, c->d_vlin, (double*)c->d_gaps, 30, 1, (double*)nullptr);
     hipLaunchKernelGGL(vlin_acc_gsuf, dim3((B.nmax + 255) / 256, B.ns, 2), dim3(256), 0, st, B, (double*)c->d_gaps);
     hipLaunchKernelGGL(vlin_acc_final, dim3((B.nmax + 255) / 256, B.ns, c->max_w), dim3(256), 0, st, B, c->d_vlin, (const double*)c->d_gaps, c->max_w);
     c->n_launch[1] += 6;
@@ -1280,7 +1293,7 @@ size_t shape_key(const rh_ctx* c, int which)
         for (size_t v : {(size_t)B.ns, (size_t)B.nmax, (size_t)B.ld, (size_t)B.lds, (size_t)B.tab, (size_t)B.seq, (size_t)B.n,
                          (size_t)B.f5i, (size_t)B.bp, (size_t)B.up, (size_t)c->d_bad, (size_t)c->d_mclogz, (size_t)c->lin_w, (size_t)c->lin_w_in,
                          (size_t)c->lin_bs, (size_t)B.tri_stride, (size_t)c->far_mfma, (size_t)c->max_w, (size_t)c->d_gaps,
-                         (size_t)c->d_hplen, (size_t)B.allow, (size_t)B.pk, (size_t)c->far_pk, (size_t)B.rowp, (size_t)c->lookahead, (size_t)c->strip, (size_t)c->d_wT, (size_t)c->strip_w, (size_t)c->strip_xcd, (size_t)(c->far2 + 2)})
+                         (size_t)c->d_hplen, (size_t)B.allow, (size_t)B.pk, (size_t)c->far_pk, (size_t)B.rowp, (size_t)c->lookahead, (size_t)c->strip, (size_t)c->d_wT, (size_t)c->strip_w, (size_t)c->strip_xcd, (size_t)(c->far2 + 2), (size_t)c->acc_wide})
             h = mix(h, v);
     } else {
         const DxLinBatch& X = c->dxl;
@@ -1568,6 +1581,7 @@ static rh_ctx* create_ctx(int device, int model, const char* param_file, const c
     if (const char* e = std::getenv("RH_STRIP_W")) c->strip_w = std::atoi(e) == 4 ? 4 : 8;
     if (const char* e = std::getenv("RH_FAR2")) c->far2 = std::atoi(e);
     if (const char* e = std::getenv("RH_STRIP_XCD")) c->strip_xcd = std::atoi(e);
+    if (const char* e = std::getenv("RH_ACC_WIDE")) c->acc_wide = std::atoi(e);
     if (const char* e = std::getenv("RH_CO_SEED")) c->co_seed = std::atoi(e);
     if (const char* e = std::getenv("RH_DX_W")) c->dx_w = std::atoi(e);
     if (const char* e = std::getenv("RH_DX_QUAD")) c->dx_quad = std::atoi(e) != 0;
