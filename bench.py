@@ -284,7 +284,8 @@ def main():
         # measured on MI355X (r02): n=500: 7389 pairs/s device-resident at 256 pairs/step; n=2000: 308 at 32
         batch = args.batch or (256 if n <= 600 else (64 if n <= 1200 else 32))
         if args.model == "vienna" and not args.batch:
-            batch = max(1, batch // 2) if n <= 1200 else batch   # n=2000: 48 pairs/s at 32, 42 at 16 (125 GB of tables)
+            # n=500: 1763 / 1816 / 1835 pairs/s at 128 / 192 / 256 (2 contexts x 61 GB of tables at 256); n=2000: 48 pairs/s at 32, 42 at 16 (125 GB)
+            batch = batch if n <= 600 else (max(1, batch // 2) if n <= 1200 else batch)
         # every rank draws from ONE stream and keeps its own slice: distinct pairs per rank (weak scaling)
         all_pairs = random_pairs(batch * world, n, seed=12345)
         pairs = all_pairs[rank * batch:(rank + 1) * batch]

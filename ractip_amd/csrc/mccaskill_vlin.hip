@@ -1221,77 +1221,84 @@ __global__ __launch_bounds__(256) void vlin_acc_gsum(McBatch B, double* __restri
     gaps[((size_t)(2 * sq + side) * 32 + g) * B.ld + pos] = acc;
 }
 
-// The same sums for the gap lengths g = 3..30 (no tabulated shape involves them) with the LANES over the gap length: one letter per
-// wavefront, lane (h, gi) <-> own gap g = gi+1, other gaps o = 14h .. 14h+13.  For one letter the outer values of all its (g, o) are ONE
-// sequence in the outer span D = r+2+g+o -- FCoX[D][p] (left) / FCoX[D][q-1-D] (right), and FCoB likewise for the bulges -- kept as a
-// ring of 56 in LDS (mirrored, so a lane reads base+offset without wrapping; only spans <= r+32 carry a non-zero weight, g+o <= 30);
-// the two lanes without a gap length (gi = 30, 31 of h = 0) load the entry D = r+56 of the two rings at step r, 24 steps before its
-// first use.  A lane keeps its 14 generic weights w(g, o) AND its window of 14 outer values in registers: the window slides by one per
-// step, so a step reads one new value from the ring, and the steps are unrolled in blocks of 14 -- a quarter of the ring -- so that
-// the window rotates through fixed registers (other gap 14h+oo at step u of a block is win[(u + oo) % 14]) and every LDS address of a
-// block is one per-block register plus an immediate.  Inner cells FCX / FCB[r][column]: one load pair per step, two steps ahead, at
-// 32-bit offsets from the sequence's table block that advance by the row pitch and stop at the lane's last interior cell (the host
-// falls back to vlin_acc_gaps when a table block exceeds 4 GB).  A lane past its last span is masked out of the arithmetic; worker
-// lanes store into a scratch ring of their own so that the producers' stores need no branch.
+// The same sums for the gap lengths g = 3..30 (no tabulated shape involves them) with the LANES over the pairs of gap lengths: one
+// letter per wavefront.  The pairs (own gap g, other gap o) with a generic weight are the triangle g + o <= 30; cut into runs of eight
+// consecutive o for one g it has exactly 64 runs (kGapJob), one per lane, so a lane does 8 FMAs per inner span and 4 of 5 are useful
+// (lanes over g alone: half).  For one letter the outer values of all its (g, o) are ONE sequence in the outer span D = r+2+g+o --
+// FCoX[D][p] (left) / FCoX[D][q-1-D] (right), and FCoB likewise for the bulges -- kept as a ring of 56 spans in LDS (mirrored, so a
+// lane reads base+offset without wrapping): a block of eight inner spans r0.. reads the spans r0+5 .. r0+47, and sixteen lanes load
+// the next eight spans of both rings one block ahead.  A lane keeps its 8 weights w(g, o) AND its window of 8 outer values in
+// registers: the window slides by one per step, so a step reads one new value from the ring, and the steps are unrolled in blocks of
+// 8 -- a seventh of the ring -- so that the window rotates through fixed registers (other gap 8c+oo at step u of a block is
+// win[(u + oo) mod 8]) and every LDS address of a block is one per-block register plus an immediate.  Inner cells FCX / FCB[r][column]:
+// one load pair per step, RH_ACCW_PF steps ahead, at 32-bit offsets from the sequence's table block that advance by the row pitch
+// and stop at the lane's last interior cell (the host falls back to vlin_acc_gaps when a table block exceeds 4 GB).  A lane past its
+// last span is masked out of the arithmetic.
 // vlin_acc_gaps (one thread per letter AND gap length, 31-entry register window, UR = 2 spans per batch of loads) re-reads every table
 // once per gap length; a first version of this kernel that read its whole window from LDS every step ran at the LDS bandwidth.
+__device__ const unsigned char kGapJob[64] = {   // g + 32 c: lane's own gap length and run of other gaps o = 8c .. 8c+7
+    3, 35, 67, 99, 4, 36, 68, 100, 5, 37, 69, 101, 6, 38, 70, 102, 7, 39, 71, 8, 40, 72, 9, 41, 73, 10, 42, 74, 11, 43, 75, 12, 44, 76, 13, 45, 77, 14, 46, 78, 15, 47, 16, 48, 17, 49, 18, 50, 19, 51, 20, 52, 21, 53, 22, 54, 23, 24, 25, 26, 27, 28, 29, 30 };
+#ifndef RH_ACCW_PF
+#define RH_ACCW_PF 2
+#endif
 __global__ __launch_bounds__(256) void vlin_acc_gaps_wide(McBatch B, const VLinModel* __restrict__ L, double* __restrict__ gaps)
 {
-    constexpr int NO = 14;                                   // other gaps per lane: o = 14h + oo (g >= 3, g+o <= 30)
-    constexpr int RN = 4 * NO;                               // ring entries
-    __shared__ double rings[4][2][2 * RN + 16];
-    __shared__ double scratch[4][64 + 2 * RN];
+    constexpr int NO = 8;                                    // other gaps per lane
+    constexpr int RN = 7 * NO;                               // ring entries
+    __shared__ double rings[4][2][2 * RN];
+    __shared__ double red[4][64 + 4];
     const int sq = blockIdx.y;
     const bool right = blockIdx.z != 0;
     const int n = B.n[sq], ld = B.ld;
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, gi = lane & 31;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int pos = blockIdx.x * 4 + w + 1;                  // the wavefront's letter
     if (pos > n) return;                                     // wave-uniform
-    const int g = gi + 1;
-    const bool worker = gi >= 2 && gi < 30, prod = gi >= 30 && h == 0;
+    const int job = kGapJob[lane], g = job & 31, c = job >> 5;
     const double* __restrict__ tab = B.tab + (size_t)sq * B.seq_stride;
     const size_t ts = B.tab_stride;
     const double Z = B.f5i[(size_t)sq * ld + n];
     double wr[NO];
 #pragma unroll
     for (int oo = 0; oo < NO; oo++) {
-        const int o = NO * h + oo, t = g + o;
-        const bool ok = worker & (t <= kMaxSingle);   // (unconditional loads, selected afterwards: behind a branch every weight is a round trip of its own)
+        const int o = NO * c + oo, t = g + o;
+        const bool ok = t <= kMaxSingle;              // (unconditional loads, selected afterwards: behind a branch every weight is a round trip of its own)
         const double v = L->shape_w[ok ? t * (t + 1) / 2 + (right ? o : g) : 0];
         wr[oo] = ok ? v : 0.0;                        // 0 for o = 0 (bulge) as in vlin_acc_gaps
     }
-    const double wbv = L->WB[g < 31 ? g : 30];
-    const double wb = (worker & (h == 0)) ? wbv : 0.0;
+    const double wbv = L->WB[g];
+    const double wb = c == 0 ? wbv : 0.0;
     double* const ring = &rings[w][0][0];
     double* const ringb = &rings[w][1][0];
-    if (lane < RN) {   // spans 0..55 of both rings, one per lane: outer cell of span D for this letter = column p (left) resp. q-1-D (right); 0 outside the interior
-        const int D = lane, pc = right ? pos - 1 - D : pos;
-        const bool ok = pc >= 1 && pc + D <= n - 1;
-        const unsigned ix = (unsigned)(ok ? D * ld + pc : 1);
+    // outer cell of span D for this letter = column p (left) resp. q-1-D (right); 0 outside the interior
+    const auto outer_ix = [&](int D, bool* ok) -> unsigned {
+        const int pc = right ? pos - 1 - D : pos;
+        *ok = pc >= 1 && pc + D <= n - 1;
+        return (unsigned)(*ok ? D * ld + pc : 1);
+    };
+    if (lane < RN) {   // spans 0..55 of both rings, one per lane
+        bool ok;
+        const unsigned ix = outer_ix(lane, &ok);
         const double a = tab[VL_FCOX * ts + ix], b = tab[VL_FCOB * ts + ix];
-        ring[D] = ring[D + RN] = ok ? a : 0.0;
-        ringb[D] = ringb[D + RN] = ok ? b : 0.0;
+        ring[lane] = ring[lane + RN] = ok ? a : 0.0;
+        ringb[lane] = ringb[lane + RN] = ok ? b : 0.0;
     }
+    // lanes 0..15 feed the rings: lane f loads span r0+56+(f & 7) of FCoX (f < 8) / FCoB during block r0 and stores it at the start of block r0+8
+    const bool feeder = lane < 2 * NO;
+    const double* __restrict__ ftab = tab + (lane < NO ? VL_FCOX : VL_FCOB) * ts;
+    double* const fdst = (lane < NO ? ring : ringb) + (lane & (NO - 1));
+    double fv = 0.0;
     const int kl = right ? pos - 1 - g : pos + 1 + g;        // inner 3' letter l (right) resp. inner 5' letter k (left)
     const int rmax = right ? kl - 2 : n - 1 - kl;            // inner spans 0..rmax are interior
     const int rl = right ? pos - 6 : n - pos - 5;            // the largest of them in this wavefront (g = 3)
-    // one load pair per lane and step: a worker its inner cells, a producer the ring entry of span r+56.  Either walks down one table
-    // column (left) or anti-diagonal (right): cell = first + r * stride for r <= last, the cell of `last` afterwards
+    // inner cells: down one table column (left) or anti-diagonal (right): cell = first + r * stride for r <= last, the cell of `last` afterwards
     const int stride8 = (right ? ld - 1 : ld) * 8;
-    int last = prod ? (right ? pos - 2 - RN : n - 1 - RN - pos) : rmax;
-    if ((worker && kl < 1) || !(worker || prod)) last = -1;
+    const int last = kl < 1 ? -1 : rmax;
     const bool any = last >= 0;
-    const int first_ix = !any ? 1 : (prod ? RN * ld + (right ? pos - 1 - RN : pos) : (right ? kl - 1 : kl));
-    const size_t t_a = (!any || worker) ? VL_FCX : (gi == 30 ? VL_FCOX : VL_FCOB);
+    const int first_ix = !any ? 1 : (right ? kl - 1 : kl);
     const char* const tab8 = (const char*)tab;
-    unsigned off = (unsigned)((t_a * ts + first_ix) * 8);                       // byte offset of the load of step r in table t_a
+    unsigned off = (unsigned)(((size_t)VL_FCX * ts + first_ix) * 8);            // byte offset of the FCX cell of step r
     const unsigned offmax = off + (unsigned)(any ? last : 0) * (unsigned)stride8;
-    const unsigned d_b = (unsigned)(((size_t)VL_FCB - t_a) * ts * 8);           // (mod 2^32) the same cell of FCB
-    const int last_w = worker ? last : -1;                                      // lanes whose arithmetic counts at step r: r <= last_w
-    const int last_p = prod ? last : -1;
-#ifndef RH_ACCW_PF
-#define RH_ACCW_PF 2
-#endif
+    const unsigned d_b = (unsigned)(((size_t)VL_FCB - (size_t)VL_FCX) * ts * 8);   // (mod 2^32) the same cell of FCB
     constexpr int PF = RH_ACCW_PF;   // inner cells are loaded PF steps ahead (slot r % PF; NO % PF == 0 keeps the slots fixed registers)
     static_assert(NO % PF == 0, "prefetch slots rotate within a block");
     double xa[PF], xb[PF];
@@ -1304,19 +1311,27 @@ __global__ __launch_bounds__(256) void vlin_acc_gaps_wide(McBatch B, const VLinM
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the rings are written and read by this wavefront only
     double win[NO];
     {
-        const lds_rp rp = (lds_rp)(ring + (2 + g + NO * h) % RN);
+        const lds_rp rp = (lds_rp)(ring + 2 + g + NO * c);   // (<= 39: no wrap)
 #pragma unroll
         for (int oo = 0; oo < NO; oo++) win[oo] = rp[oo];
     }
-    const int c_a = (g + NO * h) % RN, c_b = g % RN;
-    double* const wdst = prod ? (gi == 30 ? ring : ringb) : &scratch[w][lane];   // producers: their ring; everyone else: a scratch ring of their own
+    const int c_a = g + NO * c, c_b = g;                     // <= 30
     double acc = 0.0, accb = 0.0;
-    int r0m = 0;                                             // r0 mod RN: 0, 14, 28, 42
+    int r0m = 0;                                             // r0 mod RN
     for (int r0 = 0; r0 <= rl; r0 += NO) {
+        if (feeder) {
+            if (r0 > 0) {   // spans r0+48 .. r0+55 take the place of r0-8 .. r0-1
+                double* const d = fdst + (r0m == 0 ? RN - NO : r0m - NO);
+                d[0] = fv; d[RN] = fv;
+            }
+            bool ok;
+            const unsigned ix = outer_ix(r0 + RN + (lane & (NO - 1)), &ok);
+            const double v = ftab[ix];
+            fv = ok ? v : 0.0;
+        }
         int ba = r0m + c_a, bb = r0m + c_b;
         ba = ba >= RN ? ba - RN : ba; bb = bb >= RN ? bb - RN : bb;
         const lds_rp rpa = (lds_rp)(ring + ba), rpb = (lds_rp)(ringb + bb);
-        double* const wp = wdst + r0m;
 #pragma unroll
         for (int u = 0; u < NO; u++) {
             const int r = r0 + u;
@@ -1325,9 +1340,9 @@ __global__ __launch_bounds__(256) void vlin_acc_gaps_wide(McBatch B, const VLinM
             // loads of step r+PF
             { const unsigned o2 = off + stride8; off = o2 < offmax ? o2 : offmax; }
             xa[u % PF] = *(const double*)(tab8 + off); xb[u % PF] = *(const double*)(tab8 + (off + d_b));
-            const double nv = rpa[u + 2 + NO];                // span r+2+g+14h+14: other gap 14h+13 of the next step
+            const double nv = rpa[u + 2 + NO];                // span r+2+g+8c+8: other gap 8c+7 of the next step
             const double bv = rpb[u + 2];                     // bulge: own gap g, other gap 0, outer span r+2+g
-            if (r <= last_w) {
+            if (r <= last) {
                 double s = 0.0;
 #pragma unroll
                 for (int oo = 0; oo < NO; oo++) s = fma(wr[oo], win[(u + oo) % NO], s);
@@ -1335,18 +1350,19 @@ __global__ __launch_bounds__(256) void vlin_acc_gaps_wide(McBatch B, const VLinM
                 accb = fma(xb0, bv, accb);
             }
             win[u % NO] = nv;
-            {   // span r+56 takes the place of span r, which no lane needs any more (the smallest span read at step r is r+5)
-                const double v = r <= last_p ? xa0 : 0.0;
-                wp[u] = v; wp[u + RN] = v;
-            }
-            asm volatile("" : "+v"(acc));   // (a step's FMAs stay in front of the next step's volatile ring reads: hoisted, a block's reads cost 56 VGPRs)
+            asm volatile("" : "+v"(acc));   // (a step's FMAs stay in front of the next step's volatile ring reads)
         }
         r0m = r0m + NO == RN ? 0 : r0m + NO;
     }
     acc = fma(wb, accb, acc);
-    acc += __shfl_xor(acc, 32, 64);
+    // the runs of one gap length are consecutive lanes: the first adds them up
+    red[w][lane] = acc;
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    const int nc = (31 - g + NO - 1) / NO;
+#pragma unroll
+    for (int q = 1; q < 4; q++) { const double v = ((lds_rp)&red[w][lane])[q]; if (q < nc) acc += v; }
     // layout [side][g][pos] as vlin_acc_gaps
-    if (worker && h == 0) gaps[((size_t)(2 * sq + (right ? 1 : 0)) * 32 + g) * ld + pos] = acc / Z;
+    if (c == 0) gaps[((size_t)(2 * sq + (right ? 1 : 0)) * 32 + g) * ld + pos] = acc / Z;
 }
 
 // gap probabilities -> suffix sums over the gap length: S[g][pos] = sum_{l >= g} G[l][pos]; one thread per (letter, side)
