@@ -281,11 +281,12 @@ def main():
             all_pairs = _shard.zscore_shuffles(oxys, fhla, 12, batch * world, 1)
             pairs = all_pairs[rank * batch:(rank + 1) * batch]
     else:
-        # measured on MI355X (r02): n=500: 7389 pairs/s device-resident at 256 pairs/step; n=2000: 308 at 32
-        batch = args.batch or (256 if n <= 600 else (64 if n <= 1200 else 32))
+        # measured on MI355X (r02, CONTRAfold model): n=500: 9029 / 9337 / 9506 / 9571 pairs/s at 256 / 384 / 512 / 768 pairs per step (a strip
+        # launch is 8 rounds of workgroups at 256 pairs: the tail of every launch weighs less on a longer one); n=2000: 308 at 32, 490 at 64
+        batch = args.batch or (512 if n <= 600 else (64 if n <= 1200 else 32))
         if args.model == "vienna" and not args.batch:
             # n=500: 1763 / 1816 / 1835 pairs/s at 128 / 192 / 256 (2 contexts x 61 GB of tables at 256); n=2000: 48 pairs/s at 32, 42 at 16 (125 GB)
-            batch = batch if n <= 600 else (max(1, batch // 2) if n <= 1200 else batch)
+            batch = 256 if n <= 600 else (max(1, batch // 2) if n <= 1200 else batch)
         # every rank draws from ONE stream and keeps its own slice: distinct pairs per rank (weak scaling)
         all_pairs = random_pairs(batch * world, n, seed=12345)
         pairs = all_pairs[rank * batch:(rank + 1) * batch]

@@ -839,7 +839,7 @@ int launch_mc_vlin(rh_ctx* c, int pin, int phase, bool co)
     hipLaunchKernelGGL(vlin_acc_prep, dim3(tiles * tiles, B.ns), dim3(256), 0, st, B, c->d_vlin, (const double*)c->d_hplen);
     hipLaunchKernelGGL(mcv_acc_hscan, dim3((B.nmax + 1 + 255) / 256, B.ns), dim3(256), 0, st, B, 10 /* VL_FM2F */);
     hipLaunchKernelGGL(vlin_acc_hsum, dim3((B.nmax + 3) / 4, B.ns), dim3(256), 0, st, B, c->max_w);
-    if (c->acc_wide) {
+    if (c->acc_wide && (size_t)kViennaMcTables * B.tab_stride * sizeof(double) < ((size_t)1 << 32)) {   // (vlin_acc_gaps_wide addresses a sequence's tables with 32-bit offsets)
         // gap lengths 1, 2 (the tabulated shapes: six times the loads of a generic length): one thread per letter and length, the inner
         // spans in 8 chunks; 3..30: the lanes over the gap length (vlin_acc_gaps_wide)
         constexpr int NG = 2, NCH = 8;

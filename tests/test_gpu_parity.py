@@ -516,6 +516,36 @@ def test_vienna_bl_full_size_pair(vctx):
     assert (np.diff(r["up2"], axis=1) <= 1e-12).all()
 
 
+def test_vienna_bl_accessibility_organisations_agree(hotlib, monkeypatch):
+    """The gap-probability sums behind `up` have two organisations: one thread per letter and gap length (vlin_acc_gaps, all 30 lengths;
+    RH_ACC_WIDE=0) and the default (lengths 1-2 chunked over the inner spans + vlin_acc_gaps_wide: one lane per run of eight
+    (own gap, other gap) pairs, outer values from an LDS ring).  Same sums in a different order: equal to 1e-12, ragged lengths
+    incl. sequences shorter than the ring (56 spans) and than one block of inner spans."""
+    import ractip_amd
+    rng = np.random.default_rng(77)
+    seqs = ["".join(rng.choice(list("ACGU"), size=n)) for n in (9, 23, 57, 64, 131, 300, 412, 38)]
+    pairs = list(zip(seqs[0::2], seqs[1::2]))
+
+    def run(wide):
+        monkeypatch.setenv("RH_ACC_WIDE", wide)
+        c = ractip_amd.Context(device=0, model=ractip_amd.hot.RH_MODEL_VIENNA_BL)
+        try:
+            c.set_max_w(15)
+            c.batch_upload(pairs)
+            c.batch_compute()
+            assert c.last_path() == 1   # scaled linear path
+            return [c.batch_results(p) for p in range(len(pairs))]
+        finally:
+            c.close()
+            monkeypatch.delenv("RH_ACC_WIDE")
+
+    a, b = run("0"), run("1")
+    for (s1, s2), x, y in zip(pairs, a, b):
+        for k, s in (("up1", s1), ("up2", s2)):
+            assert x[k].shape == y[k].shape and x[k].shape[0] == len(s)
+            assert np.abs(x[k] - y[k]).max() <= 1e-12, (k, len(s))
+
+
 def test_vienna_bl_linear_path_falls_back_on_overflow(vctx):
     """A 1200-nt perfect GC helix has log Z ~ 2.5 per nucleotide: the scaled linear values leave the double range, the
     device flags it and the batch is recomputed in log space; results equal the log-space context's."""
