@@ -409,6 +409,9 @@ def main():
             if tf is not None and (tb is not None or not kd["of_which_block_product"]):
                 nfine = kd["launches_per_step"] - kd["of_which_block_product"]
                 traffic = (tf * nfine + (tb or 0.0) * kd["of_which_block_product"]) / kd["launches_per_step"]
+            if traffic is None and traffic_note is None:
+                traffic_note = ("this sweep is several kernels (look-ahead pairs + block products shared with the single-molecule folds): "
+                                "per-kernel counter bytes per dispatch are in profiles/pmc_traffic.json under %s_n%d_b%d" % (args.model, n, batch))
         except (OSError, ValueError):
             traffic_note = "profiles/pmc_traffic.json unreadable"
         launch_s = kd["avg_launch_us"] * 1e-6
