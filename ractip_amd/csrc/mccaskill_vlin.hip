@@ -30,10 +30,47 @@ __device__ __forceinline__ double wsum_vl(double v)
     return v;
 }
 
+// pin bits 0..6: sequence on blockIdx.x (1) or blockIdx.y (0); bit 7: windowed grid of the two-molecule sweeps, first cell group in
+// bits 8.. (see window_slot_vl)
 __device__ __forceinline__ void block_map_vl(int pin, int* sq, int* slot)
 {
-    *sq = pin ? blockIdx.x : blockIdx.y;
-    *slot = pin ? blockIdx.y : blockIdx.x;
+    *sq = (pin & 127) ? blockIdx.x : blockIdx.y;
+    *slot = (pin & 127) ? blockIdx.y : blockIdx.x;
+}
+// Two-molecule sweeps compute only the groups that hold a cell with letters on both strands: for one diagonal that is a short run
+// of consecutive groups around the cut, the same for every pair of a batch of equal lengths.  The host launches that run only (the
+// union over the batch; a workgroup that merely finds out that it has nothing to do still costs two dependent scalar loads): grid
+// index 0..2 = the F5 / XP / XS groups of the sequence, 3.. = cell group slot0 + index - 3.  False: nothing to do.
+// acc += sum_{k = lo + tid, step nt, k <= hi} A(k) * B(k) for the serial sums of the F5 / XP / XS groups: four terms per batch of loads, every
+// load unconditional at a clamped index and both factors selected to 0 afterwards (the same FMAs in the same order as the plain loop,
+// so the same bits).  In the one-wavefront launches of the look-ahead pairs these groups have up to n/64 terms per thread; one
+// exposed memory round trip per term made them the longest workgroups of those launches.
+template <class FA, class FB>
+__device__ __forceinline__ double dot4_vl(int lo, int hi, int tid, int nt, double acc, FA&& A, FB&& B)
+{
+    for (int k = lo + tid; k <= hi; k += 4 * nt) {
+        double x[4], y[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int kk = k + u * nt;
+            ok[u] = kk <= hi;
+            const int kc = ok[u] ? kk : hi;
+            x[u] = A(kc); y[u] = B(kc);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) acc = fma(ok[u] ? x[u] : 0.0, ok[u] ? y[u] : 0.0, acc);
+    }
+    return acc;
+}
+template <bool CUT>
+__device__ __forceinline__ bool window_slot_vl(int pin, int ngroup, int* slot)
+{
+    if (!CUT || !(pin & 128)) return *slot <= ngroup + (CUT ? 2 : 0);
+    const int b = *slot;
+    if (b < 3) { *slot = ngroup + b; return true; }
+    *slot = (pin >> 8) + b - 3;
+    return *slot < ngroup;
 }
 
 template <int T>
@@ -257,16 +294,16 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) __attribute__((amdgpu_wave
     constexpr int WR = MODE == 2 ? 1 : W;
     __shared__ double part[MODE == 1 ? 6 : 3][WR][64];
     __shared__ double gbuf[MODE == 2 ? 1 : W][MODE == 2 ? 1 : 2 * ((kMaxSingle / 2 + W) / W)][MODE == 2 ? 1 : 96];
-    double* __restrict__ rowp = B.rowp + (size_t)(pin ? blockIdx.x : blockIdx.y) * 3 * B.ld;   // look-ahead sums of the next diagonal
     int sq, slot;
     block_map_vl(pin, &sq, &slot);
+    double* __restrict__ rowp = B.rowp + (size_t)sq * 3 * B.ld;   // look-ahead sums of the next diagonal
     if (sq >= B.ns) return;
     const int n = B.n[sq];
     if (d > n - 1) return;
     const int ncell = n - 1 - d > 0 ? n - 1 - d : 0;
     const int ngroup = (ncell + 63) >> 6;
     const int cut = CUT ? B.cut[sq] : 0;   // CUT = false: one molecule per sequence, every gap test folds away
-    if (slot > ngroup + (CUT ? 2 : 0)) return;
+    if (!window_slot_vl<CUT>(pin, ngroup, &slot)) return;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int ld = B.ld;
     const size_t ts = B.tab_stride;
@@ -282,8 +319,8 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) __attribute__((amdgpu_wave
         const int b = cut + d + 1, a = cut - d;
         if (is_xp ? b > n : a < 1) return;
         double acc = 0.0;
-        if (is_xp) for (int k = cut + threadIdx.x; k <= b - 2; k += 64 * WR) acc = fma(xv[k], fca[(b - k - 2) * ld + (k + 1)], acc);
-        else for (int l = a + 4 + threadIdx.x; l <= cut; l += 64 * WR) acc = fma(fca[(l - 1 - a) * ld + a], xv[l + 1], acc);
+        if (is_xp) acc = dot4_vl(cut, b - 2, threadIdx.x, 64 * WR, acc, [&](int k) { return xv[k]; }, [&](int k) { return fca[(b - k - 2) * ld + (k + 1)]; });
+        else acc = dot4_vl(a + 4, cut, threadIdx.x, 64 * WR, acc, [&](int l) { return fca[(l - 1 - a) * ld + a]; }, [&](int l) { return xv[l + 1]; });
         acc = wsum_vl(acc);
         if (lane == 0) part[0][w][0] = acc;
         __syncthreads();
@@ -301,7 +338,7 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) __attribute__((amdgpu_wave
         const int jj = d + 1;
         const double* __restrict__ fca = tab + VL_FCA * ts;
         double acc = 0.0;
-        for (int k = threadIdx.x; k <= jj - 2; k += 64 * WR) acc = fma(f5i[k], fca[(jj - 2 - k) * ld + (k + 1)], acc);
+        acc = dot4_vl(0, jj - 2, threadIdx.x, 64 * WR, acc, [&](int k) { return f5i[k]; }, [&](int k) { return fca[(jj - 2 - k) * ld + (k + 1)]; });
         acc = wsum_vl(acc);
         if (lane == 0) part[0][w][0] = acc;
         __syncthreads();
@@ -332,7 +369,12 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) __attribute__((amdgpu_wave
     const bool valid1 = MODE == 1 && i <= n - 1 - d1;
     const bool nick_in1 = CUT && valid1 && i <= cut && cut <= j + 1;
     const int l1max1 = nick_in1 ? cut - i - 1 : 99, l2max1 = nick_in1 ? j - cut : 99;
-    const bool masked = CUT && __any(l1max < kMaxSingle || l2max < kMaxSingle || l1max1 < kMaxSingle || l2max1 < kMaxSingle);   // the same for all W wavefronts of the group
+    // Seeded two-molecule sweep: every cell that is computed here has letters on both strands, and the interior loops of such a cell
+    // close over inner pairs with letters on both strands only (each side of the loop stays on its strand) -- a property of the INNER
+    // cell.  The staged FCX rows are therefore masked once, on their way into LDS (MODE 1), and the filters run unmasked and unrolled;
+    // the per-lane limits of vfilt_pair_m (a rolled loop, one LDS and one scalar round trip per tap) remain for the unseeded sweep.
+    const bool data_mask = CUT && MODE == 1 && B.seeded && cut > 0;
+    const bool masked = CUT && !data_mask && __any(l1max < kMaxSingle || l2max < kMaxSingle || l1max1 < kMaxSingle || l2max1 < kMaxSingle);   // the same for all W wavefronts of the group
 
     // epilogue operands (wave 0 only), issued ahead of the term loops
     const size_t at = d * ld + i;
@@ -440,8 +482,10 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) __attribute__((amdgpu_wave
                 rseg[q] = on ? r : -1;
                 const int col0 = i0 + 1;
                 if (on && r >= 4) {
-                    gbuf[w][q][lane] = col0 + lane < ld ? g0[q] : 0.0;
-                    if (lane < 32) gbuf[w][q][64 + lane] = col0 + 64 + lane < ld ? g1[q] : 0.0;
+                    const int sp = d - 1 - r;   // span of the staged row: inner cell (p, sp) has letters on both strands iff p <= cut <= p + sp
+                    const int p0 = col0 + lane, p1 = col0 + 64 + lane;
+                    gbuf[w][q][lane] = (p0 < ld && (!data_mask || (p0 <= cut && cut <= p0 + sp))) ? g0[q] : 0.0;
+                    if (lane < 32) gbuf[w][q][64 + lane] = (p1 < ld && (!data_mask || (p1 <= cut && cut <= p1 + sp))) ? g1[q] : 0.0;
                 }
                 // bulges of length t on the 3' side (l1 = 0: column i+1) and on the 5' side (l1 = t: column i+1+t)
                 const int tA = r - 1;
@@ -631,7 +675,7 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) __attribute__((amdgpu_wave
     if (ncell < 1 && ncell1 < 1) return;
     const int ngroup = ((ncell > ncell1 ? ncell : ncell1) + 63) >> 6;
     const int cut = CUT ? B.cut[sq] : 0;   // CUT = false: one molecule per sequence, every gap test folds away
-    if (slot > ngroup + (CUT ? 2 : 0)) return;
+    if (!window_slot_vl<CUT>(pin, ngroup, &slot)) return;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int ld = B.ld;
     const size_t ts = B.tab_stride;
@@ -652,21 +696,46 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) __attribute__((amdgpu_wave
         if (is_xp) {
             const double* __restrict__ xs = B.xs + (size_t)sq * ld;
             const double* __restrict__ xpo = B.xpo + (size_t)sq * ld;
-            for (int i = 1 + threadIdx.x; i <= cut; i += 64 * WR) {
-                if (b + 1 - i < 4 || !vienna_ptype(s[i], s[b + 1])) continue;
-                const int ix = 25 * (5 * s[i] + (GAPOK(i) ? s[i + 1] : 0)) + 5 * s[b + 1] + (GAPOK(b) ? s[b] : 0);
-                acc = fma(fco[(b - i) * ld + i] * L->TNC[ix], xs[i + 1], acc);
+            // pairs (i, b+1) around the missing gap, i on s1: the letters of four of them, then their cells and weights, then the FMAs
+            // (a pair that does not exist contributes fma(0, 0, acc) = acc: the same bits as skipping it)
+            const int s_b1 = s[b + 1], s_b0 = GAPOK(b) ? s[b] : 0;
+            for (int i = 1 + threadIdx.x; i <= cut; i += 4 * 64 * WR) {
+                int si[4], sn[4], ic[4];
+                bool ok[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const int ii = i + u * 64 * WR; ok[u] = ii <= cut; ic[u] = ok[u] ? ii : cut; si[u] = s[ic[u]]; sn[u] = s[ic[u] + 1]; }
+                double f[4], t[4], x[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    ok[u] = ok[u] & (b + 1 - ic[u] >= 4) & (vienna_ptype(si[u], s_b1) != 0);
+                    const int ix = 25 * (5 * si[u] + (GAPOK(ic[u]) ? sn[u] : 0)) + 5 * s_b1 + s_b0;
+                    f[u] = fco[(b - ic[u]) * ld + ic[u]]; t[u] = L->TNC[ix]; x[u] = xs[ic[u] + 1];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) acc = fma(ok[u] ? f[u] * t[u] : 0.0, ok[u] ? x[u] : 0.0, acc);
             }
-            for (int bb = b + 2 + threadIdx.x; bb <= n; bb += 64 * WR) acc2 = fma(xpo[bb], fca[(bb - b - 2) * ld + b + 1], acc2);
+            acc2 = dot4_vl(b + 2, n, threadIdx.x, 64 * WR, acc2, [&](int bb) { return xpo[bb]; }, [&](int bb) { return fca[(bb - b - 2) * ld + b + 1]; });
         } else {
             const double* __restrict__ xp = B.xp + (size_t)sq * ld;
             const double* __restrict__ xso = B.xso + (size_t)sq * ld;
-            for (int j = cut + threadIdx.x; j <= n - 1; j += 64 * WR) {
-                if (j + 1 - (a - 1) < 4 || !vienna_ptype(s[a - 1], s[j + 1])) continue;
-                const int ix = 25 * (5 * s[a - 1] + (GAPOK(a - 1) ? s[a] : 0)) + 5 * s[j + 1] + (GAPOK(j) ? s[j] : 0);
-                acc = fma(fco[(j - a + 1) * ld + a - 1] * L->TNC[ix], xp[j], acc);
+            // pairs (a-1, j+1) around the missing gap, j+1 on s2 (see above)
+            const int s_a1 = s[a - 1], s_a0 = GAPOK(a - 1) ? s[a] : 0;
+            for (int j = cut + threadIdx.x; j <= n - 1; j += 4 * 64 * WR) {
+                int sj1[4], sj0[4], jc[4];
+                bool ok[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const int jj = j + u * 64 * WR; ok[u] = jj <= n - 1; jc[u] = ok[u] ? jj : n - 1; sj1[u] = s[jc[u] + 1]; sj0[u] = s[jc[u]]; }
+                double f[4], t[4], x[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    ok[u] = ok[u] & (jc[u] + 1 - (a - 1) >= 4) & (vienna_ptype(s_a1, sj1[u]) != 0);
+                    const int ix = 25 * (5 * s_a1 + s_a0) + 5 * sj1[u] + (GAPOK(jc[u]) ? sj0[u] : 0);
+                    f[u] = fco[(jc[u] - a + 1) * ld + a - 1]; t[u] = L->TNC[ix]; x[u] = xp[jc[u]];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) acc = fma(ok[u] ? f[u] * t[u] : 0.0, ok[u] ? x[u] : 0.0, acc);
             }
-            for (int aa = 1 + threadIdx.x; aa <= a - 2; aa += 64 * WR) acc2 = fma(xso[aa], fca[(a - 2 - aa) * ld + aa], acc2);
+            acc2 = dot4_vl(1, a - 2, threadIdx.x, 64 * WR, acc2, [&](int aa) { return xso[aa]; }, [&](int aa) { return fca[(a - 2 - aa) * ld + aa]; });
         }
         acc = wsum_vl(acc); acc2 = wsum_vl(acc2);
         if (lane == 0) { part[0][w][0] = acc; part[1][w][0] = acc2; }
@@ -685,7 +754,7 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) __attribute__((amdgpu_wave
         if (k > n - 1) return;   // (MODE 1 on a diagonal beyond this sequence's first)
         const double* __restrict__ fca = tab + VL_FCA * ts + (k + 1);
         double acc = 0.0;
-        for (int jj = k + 2 + threadIdx.x; jj <= n; jj += 64 * WR) acc = fma(f5o[jj], fca[(jj - 2 - k) * ld], acc);
+        acc = dot4_vl(k + 2, n, threadIdx.x, 64 * WR, acc, [&](int jj) { return f5o[jj]; }, [&](int jj) { return fca[(jj - 2 - k) * ld]; });
         acc = wsum_vl(acc);
         if (lane == 0) part[0][w][0] = acc;
         __syncthreads();
@@ -719,7 +788,10 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) __attribute__((amdgpu_wave
     const int l1max1 = (CUT && valid1 && cut <= i - 1) ? i - 2 - cut : 99;
     const int l2max1 = (CUT && valid1 && cut >= j1 + 1) ? cut - j1 - 2 : 99;
     const bool guard_m1 = MODE == 1 && d1 >= 2;
-    const bool masked = CUT && __any(l1max < kMaxSingle || l2max < kMaxSingle || l1max1 < kMaxSingle || l2max1 < kMaxSingle);
+    // the limits above bind exactly the cells whose letters lie on one strand (i > cut, or j+1 <= cut), and with a cut those are not
+    // wanted (nothing reads their outside values; `wanted` in the posterior): the filters run unmasked and unrolled whenever there is
+    // a cut.  vfilt_pair_rev_m (a rolled loop, one LDS and one scalar round trip per tap) set the duration of these launches.
+    const bool masked = CUT && cut == 0 && __any(l1max < kMaxSingle || l2max < kMaxSingle || l1max1 < kMaxSingle || l2max1 < kMaxSingle);
 
     const size_t at = d * ld + i;
     const bool up_ok = i - 1 >= 1 && j + 1 <= n - 1;

@@ -277,6 +277,8 @@ struct rh_ctx {
     int far2 = -1;                 // two-level block products: -1 = by size (nmax >= 768), 0 / 1 forced (RH_FAR2)
     int far2_next = -1;            // launch-sequence state of far_outside_step
     int strip_w = 8;               // wavefronts per strip workgroup (RH_STRIP_W = 4 | 8)
+    int co_cut_min = 0, co_cut_max = 0;   // smallest / largest cut (length of s1) of the two-molecule batch: bounds of the groups its sweeps launch
+    int co_window = 1;             // two-molecule sweeps launch only the groups around the cut (RH_CO_WINDOW=0: all groups, most of which return at once)
     int acc_wide = 1;              // Vienna-BL accessibility: vlin_acc_gaps_wide for the gap lengths 3..30 (RH_ACC_WIDE=0: vlin_acc_gaps for all)
     int strip_xcd = 1;             // groups of one sequence consecutive on one XCD (RH_STRIP_XCD=0: sequence-major launch order only)
     double* d_wT = nullptr;        // transposed, zero-padded single-branch weights wT[l1][t+1] of the strip kernels
@@ -602,6 +604,8 @@ int stage(rh_ctx* c, int ns, const char* const* seqs, const int* lens, bool with
                 for (int i = 0; i < a; i++) cc[(size_t)p * C.lds + 1 + i] = vienna_code(seqs[2 * p][i]);
                 for (int i = 0; i < b; i++) cc[(size_t)p * C.lds + 1 + a + i] = vienna_code(seqs[2 * p + 1][i]);
                 nn[p] = a + b; nn[np + p] = a;
+                c->co_cut_min = p == 0 ? a : std::min(c->co_cut_min, a);
+                c->co_cut_max = p == 0 ? a : std::max(c->co_cut_max, a);
             }
             if ((rc = ensure(c, &c->d_coseq, &c->cap_coseq, cc.size(), false))) return rc;
             if ((rc = ensure(c, &c->d_con, &c->cap_con, sizeof(int) * nn.size(), false))) return rc;
@@ -761,11 +765,23 @@ int launch_mc_vlin(rh_ctx* c, int pin, int phase, bool co)
     int* nf = co ? &c->n_far[2] : (phase == 0 ? &c->n_far[0] : &c->n_far[1]);
     const int extra = co ? 3 : 1;   // F5 (+ XP, XS)
     const int last_block = BS > 0 ? (B.nmax - 1) / BS : 0;
+    // two-molecule sweeps: the groups of diagonal dd with a cell on both strands are 1 + 64 slot <= cut < 1 + 64 slot + 64 + dd; the
+    // union over the batch's cuts is launched behind the three F5 / XP / XS groups (window_slot_vl); cells = all cell groups of the launch
+    const bool window = co && c->co_window && c->co_cut_min >= 1;
+    const auto windowed = [&](int dd, int cells, int* pin_arg) -> int {
+        const int t = c->co_cut_min - 65 - dd;
+        const int lo = std::max(0, (t >= 0 ? t / 64 : -((-t + 63) / 64)) + 1), hi = std::min(cells - 1, (c->co_cut_max - 1) / 64);
+        *pin_arg = pin | 128 | (lo << 8);
+        return 3 + std::max(0, hi - lo + 1);
+    };
     if (phase == 0) {
         hipLaunchKernelGGL(vlin_init, dim3((B.ns + 63) / 64), dim3(64), 0, st, B, bad);
         if (co && B.seeded) hipLaunchKernelGGL(vlin_co_seed, dim3(c->mc.nmax, B.ns), dim3(256), 0, st, B, c->mc);
         for (int d = 0; d <= B.nmax - 1; d++) {
-            const int groups = (std::max(B.nmax - 1 - d, 0) + 63) / 64 + extra;
+            const int cells = (std::max(B.nmax - 1 - d, 0) + 63) / 64;
+            const bool la1 = BS == 16 && c->lookahead && (d & 1) == 0;   // this launch also feeds diagonal d+1
+            int pin_k = pin;
+            const int groups = (window && B.seeded) ? windowed(la1 ? d + 1 : d, cells, &pin_k) : cells + extra;
             const double hp_d = c->h_hplen[d];
             const dim3 grid = pin ? dim3(B.ns, groups) : dim3(groups, B.ns);
             bool done = false;
@@ -773,16 +789,16 @@ int launch_mc_vlin(rh_ctx* c, int pin, int phase, bool co)
                 if (c->lookahead) {   // look-ahead pairs: even diagonal = full launch that also accumulates d+1's sums, odd = one wavefront per group
                     done = true;
                     if ((d & 1) == 0) {
-                        if (co) KLAUNCH(c, 0, (vlin_inside_diag<W, 16, true, 1>), grid, dim3(64 * W), st, B, c->d_vlin, d, hp_d, pin);
+                        if (co) KLAUNCH(c, 0, (vlin_inside_diag<W, 16, true, 1>), grid, dim3(64 * W), st, B, c->d_vlin, d, hp_d, pin_k);
                         else KLAUNCH(c, 0, (vlin_inside_diag<W, 16, false, 1>), grid, dim3(64 * W), st, B, c->d_vlin, d, hp_d, pin);
                     } else {
-                        if (co) KLAUNCH(c, 0, (vlin_inside_diag<W, 16, true, 2>), grid, dim3(64), st, B, c->d_vlin, d, hp_d, pin);
+                        if (co) KLAUNCH(c, 0, (vlin_inside_diag<W, 16, true, 2>), grid, dim3(64), st, B, c->d_vlin, d, hp_d, pin_k);
                         else KLAUNCH(c, 0, (vlin_inside_diag<W, 16, false, 2>), grid, dim3(64), st, B, c->d_vlin, d, hp_d, pin);
                     }
                 }
             }
             if (!done) {
-                if (co) KLAUNCH(c, 0, (vlin_inside_diag<W, BS, true, 0>), grid, dim3(64 * W), st, B, c->d_vlin, d, hp_d, pin);
+                if (co) KLAUNCH(c, 0, (vlin_inside_diag<W, BS, true, 0>), grid, dim3(64 * W), st, B, c->d_vlin, d, hp_d, pin_k);
                 else KLAUNCH(c, 0, (vlin_inside_diag<W, BS, false, 0>), grid, dim3(64 * W), st, B, c->d_vlin, d, hp_d, pin);
             }
             (*nl)++;
@@ -807,22 +823,27 @@ int launch_mc_vlin(rh_ctx* c, int pin, int phase, bool co)
         if constexpr (BS == 16) {
             if (la) {
                 done = true;
+                int pin_k = pin;
                 if (d & 1) {
-                    const int groups = (B.nmax - d + 63) / 64 + extra;   // cells of diagonal d-1
+                    const int cells = (B.nmax - d + 63) / 64;   // cells of diagonal d-1
+                    const int groups = window ? windowed(d, cells, &pin_k) : cells + extra;
                     const dim3 grid = pin ? dim3(B.ns, groups) : dim3(groups, B.ns);
-                    if (co) KLAUNCH(c, 2, (vlin_outside_diag<W, 16, true, 1>), grid, dim3(64 * W), st, B, c->d_vlin, d, pin, bad);
+                    if (co) KLAUNCH(c, 2, (vlin_outside_diag<W, 16, true, 1>), grid, dim3(64 * W), st, B, c->d_vlin, d, pin_k, bad);
                     else KLAUNCH(c, 2, (vlin_outside_diag<W, 16, false, 1>), grid, dim3(64 * W), st, B, c->d_vlin, d, pin, bad);
                 } else {
-                    const int groups = (B.nmax - 1 - d + 63) / 64 + extra;
+                    const int cells = (B.nmax - 1 - d + 63) / 64;
+                    const int groups = window ? windowed(d, cells, &pin_k) : cells + extra;
                     const dim3 grid = pin ? dim3(B.ns, groups) : dim3(groups, B.ns);
-                    if (co) KLAUNCH(c, 2, (vlin_outside_diag<W, 16, true, 2>), grid, dim3(64), st, B, c->d_vlin, d, pin, bad);
+                    if (co) KLAUNCH(c, 2, (vlin_outside_diag<W, 16, true, 2>), grid, dim3(64), st, B, c->d_vlin, d, pin_k, bad);
                     else KLAUNCH(c, 2, (vlin_outside_diag<W, 16, false, 2>), grid, dim3(64), st, B, c->d_vlin, d, pin, bad);
                 }
             }
         }
         if (!done) {
-            const int groups = (B.nmax - 1 - d + 63) / 64 + extra;
-            if (co) KLAUNCH(c, 2, (vlin_outside_diag<W, BS, true, 0>), pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(64 * W), st, B, c->d_vlin, d, pin, bad);
+            const int cells = (B.nmax - 1 - d + 63) / 64;
+            int pin_k = pin;
+            const int groups = window ? windowed(d, cells, &pin_k) : cells + extra;
+            if (co) KLAUNCH(c, 2, (vlin_outside_diag<W, BS, true, 0>), pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(64 * W), st, B, c->d_vlin, d, pin_k, bad);
             else KLAUNCH(c, 2, (vlin_outside_diag<W, BS, false, 0>), pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(64 * W), st, B, c->d_vlin, d, pin, bad);
         }
         (*nl)++;
@@ -1293,7 +1314,7 @@ size_t shape_key(const rh_ctx* c, int which)
         for (size_t v : {(size_t)B.ns, (size_t)B.nmax, (size_t)B.ld, (size_t)B.lds, (size_t)B.tab, (size_t)B.seq, (size_t)B.n,
                          (size_t)B.f5i, (size_t)B.bp, (size_t)B.up, (size_t)c->d_bad, (size_t)c->d_mclogz, (size_t)c->lin_w, (size_t)c->lin_w_in,
                          (size_t)c->lin_bs, (size_t)B.tri_stride, (size_t)c->far_mfma, (size_t)c->max_w, (size_t)c->d_gaps,
-                         (size_t)c->d_hplen, (size_t)B.allow, (size_t)B.pk, (size_t)c->far_pk, (size_t)B.rowp, (size_t)c->lookahead, (size_t)c->strip, (size_t)c->d_wT, (size_t)c->strip_w, (size_t)c->strip_xcd, (size_t)(c->far2 + 2), (size_t)c->acc_wide})
+                         (size_t)c->d_hplen, (size_t)B.allow, (size_t)B.pk, (size_t)c->far_pk, (size_t)B.rowp, (size_t)c->lookahead, (size_t)c->strip, (size_t)c->d_wT, (size_t)c->strip_w, (size_t)c->strip_xcd, (size_t)(c->far2 + 2), (size_t)c->acc_wide, (size_t)c->co_window, (size_t)c->co_cut_min, (size_t)c->co_cut_max})
             h = mix(h, v);
     } else {
         const DxLinBatch& X = c->dxl;
@@ -1582,6 +1603,7 @@ static rh_ctx* create_ctx(int device, int model, const char* param_file, const c
     if (const char* e = std::getenv("RH_FAR2")) c->far2 = std::atoi(e);
     if (const char* e = std::getenv("RH_STRIP_XCD")) c->strip_xcd = std::atoi(e);
     if (const char* e = std::getenv("RH_ACC_WIDE")) c->acc_wide = std::atoi(e);
+    if (const char* e = std::getenv("RH_CO_WINDOW")) c->co_window = std::atoi(e);
     if (const char* e = std::getenv("RH_CO_SEED")) c->co_seed = std::atoi(e);
     if (const char* e = std::getenv("RH_DX_W")) c->dx_w = std::atoi(e);
     if (const char* e = std::getenv("RH_DX_QUAD")) c->dx_quad = std::atoi(e) != 0;
