@@ -546,6 +546,45 @@ def test_vienna_bl_accessibility_organisations_agree(hotlib, monkeypatch):
             assert np.abs(x[k] - y[k]).max() <= 1e-12, (k, len(s))
 
 
+def test_vienna_bl_two_molecule_organisations_agree(hotlib, monkeypatch):
+    """The scaled linear two-molecule sweeps have three switches that must not change hp or log Z beyond the order of a few sums:
+    RH_CO_SEED (1: one-strand inside cells copied from the single folds, the staged rows masked by the inner cell's strands and the
+    filters unrolled; 0: every cell computed, per-lane filter limits), RH_CO_WINDOW (1: only the groups around the cut are launched),
+    and both together.  Ragged pairs: cuts at a group boundary (64), next to one (63, 65), a one-letter strand, s1 longer than s2."""
+    import ractip_amd
+    from _oracle import ViennaOracle
+    rng = np.random.default_rng(78)
+    rs = lambda n: "".join(rng.choice(list("ACGU"), size=n))
+    pairs = [(rs(64), rs(70)), (rs(63), rs(130)), (rs(65), rs(41)), (rs(1), rs(90)), (rs(200), rs(33)), (rs(129), rs(127))]
+
+    def run(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        c = ractip_amd.Context(device=0, model=ractip_amd.hot.RH_MODEL_VIENNA_BL)
+        try:
+            c.set_hybrid(True)
+            c.batch_upload(pairs)
+            c.batch_compute()
+            assert c.last_path() == 1   # scaled linear path
+            return [c.batch_results(p) for p in range(len(pairs))]
+        finally:
+            c.close()
+            for k in env:
+                monkeypatch.delenv(k)
+
+    base = run({})
+    vo = ViennaOracle()
+    for (s1, s2), r in list(zip(pairs, base))[:3]:
+        o = vo.cofold(s1, s2)
+        assert abs(r["logZ"][2] - o["logZ"]) < 1e-8
+        assert_prob_close(r["hp"], o["hp"], rel=REL, what="cofold hp %d/%d" % (len(s1), len(s2)))
+    for env in ({"RH_CO_SEED": "0"}, {"RH_CO_WINDOW": "0"}, {"RH_CO_SEED": "0", "RH_CO_WINDOW": "0"}):
+        got = run(env)
+        for (s1, s2), r, r0 in zip(pairs, got, base):
+            assert abs(r["logZ"][2] - r0["logZ"][2]) < 1e-10, (env, len(s1), len(s2))
+            assert_prob_close(r["hp"], r0["hp"], rel=1e-10, what="%r hp %d/%d" % (env, len(s1), len(s2)))
+
+
 def test_vienna_bl_linear_path_falls_back_on_overflow(vctx):
     """A 1200-nt perfect GC helix has log Z ~ 2.5 per nucleotide: the scaled linear values leave the double range, the
     device flags it and the batch is recomputed in log space; results equal the log-space context's."""
