@@ -235,6 +235,24 @@ __device__ __forceinline__ double small_w(const VLinModel* L, int l1, int l2, in
 
 }  // namespace
 
+#ifdef RH_VSTAMPS
+// tuning build only (tools/build_variant.py vstamps -DRH_VSTAMPS=1): per-phase cycle totals of vlin_inside_diag<.., CUT = (RH_VSTAMPS == 2), MODE 1>,
+// wavefront 0 of every cell workgroup (tools/vstamps.py)
+__device__ unsigned long long g_vstamps[16];
+extern "C" int rh_debug_vstamps(unsigned long long* out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_vstamps), sizeof(g_vstamps)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_vstamps), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#define RH_VSTAMP(k) do { if (MODE == 1 && CUT == (RH_VSTAMPS == 2) && threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_vstamps[k], t_ - t_prev_); t_prev_ = t_; } } while (0)
+#define RH_VSTAMP_BEGIN() unsigned long long t_prev_ = __builtin_amdgcn_s_memtime(); if (MODE == 1 && CUT == (RH_VSTAMPS == 2) && threadIdx.x == 0) atomicAdd(&g_vstamps[15], 1ull)
+#define RH_VPIN(x) asm volatile("" :: "v"(x))   // the phase's result exists before its stamp is taken
+#else
+#define RH_VPIN(x) do { } while (0)
+#define RH_VSTAMP(k) do { } while (0)
+#define RH_VSTAMP_BEGIN() do { } while (0)
+#endif
 #ifndef RH_VLA_WPE
 #define RH_VLA_WPE 4   // wavefronts/SIMD the look-ahead (MODE 1) kernel is compiled for
 #endif
@@ -355,6 +373,7 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) __attribute__((amdgpu_wave
         const int i0 = 1 + slot * 64, dd = MODE == 1 ? d + 1 : d;   // MODE 1 also feeds diagonal d+1; its MODE 2 launch tests the same dd
         if (i0 + 63 + dd + 1 <= cut || i0 > cut) return;
     }
+    RH_VSTAMP_BEGIN();
     const int i = 1 + slot * 64 + lane, j = i + d;
     const bool valid = i <= ncell;
     int s_im1 = 0, s_i = 0, s_ip1 = 0, s_j = 0, s_jp1 = 0, s_jp2 = 0;
@@ -382,6 +401,7 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) __attribute__((amdgpu_wave
     // seen from outside; a neighbour on the other molecule gives no dangle (letter code 0)
     const int idd = 25 * (5 * s_jp1 + (GAPOK(j + 1) ? s_jp2 : 0)) + 5 * s_i + (GAPOK(i - 1) ? s_im1 : 0);
     const int idx_raw = 25 * (5 * s_jp1 + s_jp2) + 5 * s_i + s_im1;
+    RH_VPIN(type); RH_VSTAMP(0);   // letters and pair type
     // ---- FM2[i,d] = sum_{m=1}^{d-1} FM1[m][i] * FM[d-m][i+m]: near terms here, far blocks from FM2F
     double acc2 = 0.0, acc2n = 0.0;
     {
@@ -440,6 +460,7 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) __attribute__((amdgpu_wave
         }
     }
 
+    RH_VPIN(acc2); RH_VPIN(acc2n); RH_VSTAMP(1);   // FM2 near terms
     // ---- generic interior loops (LDS-staged filters over FCX) and long bulges (two taps per length over FCB)
     double accc = 0.0, accb = 0.0, acccn = 0.0, accbn = 0.0;
     if constexpr (MODE == 2) {
@@ -494,6 +515,7 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) __attribute__((amdgpu_wave
                 bA[q] = (a0 ? x0[q] : 0.0) + (a1 ? xa[q] : 0.0);
                 bB[q] = (b0 ? x0[q] : 0.0) + (b1 ? xb[q] : 0.0);
             }
+            RH_VSTAMP(2);   // staging loads arrived, rows in LDS
 #pragma unroll
             for (int q = 0; q < NSEG; q++)
                 if (rseg[q] >= 0) {
@@ -555,6 +577,7 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) __attribute__((amdgpu_wave
         if (!pairable) { accc = 0.0; accb = 0.0; }
     }
 
+    RH_VPIN(accc); RH_VPIN(acccn); RH_VSTAMP(3);   // filters
     if constexpr (MODE != 2) {
         part[0][w][lane] = acc2;
         part[1][w][lane] = accc;
@@ -570,6 +593,7 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) __attribute__((amdgpu_wave
             }
         }
     }
+    RH_VSTAMP(4);   // partial sums exchanged (barrier)
     if (w != 0 || !valid) return;
     double e_txo = 0, e_tmc = 0, e_tmh = 0, e_txi = 0, e_tsa = 0, e_tau = 1, e_tet = 1, nick = 0.0;
     double o_fca = 0, o_fm1 = 0, o_fms = 0, sm7 = 0.0;
@@ -622,6 +646,7 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) __attribute__((amdgpu_wave
         for (int k = 0; k < 7; k++) sm7 = fma(sok[k] ? sv[k] : 0.0, sw[k], sm7);
     }
 
+    RH_VPIN(sm7); RH_VSTAMP(5);   // epilogue operands
     double fm2 = acc2, g = accc, gb = accb;
     if constexpr (MODE != 2) {
         fm2 = 0.0; g = 0.0; gb = 0.0;
@@ -650,6 +675,7 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) __attribute__((amdgpu_wave
     tab[VL_FM1 * ts + at] = fm1v;
     tab[VL_FMS * ts + at] = fmsv;
     tab[VL_FM * ts + at] = fmv;
+    RH_VSTAMP(6);   // epilogue arithmetic and stores
 }
 
 // ---------------------------------------------------------------------------------
