@@ -208,7 +208,9 @@ int rh_set_overlap(rh_ctx* ctx, int on);
  * log-space kernels (rh_last_path / rh_last_hybrid_path == 3): which = 0: sequence indices (2p = s1 of pair p), 1: pair
  * indices of the duplex.  Only those problems are recomputed; every other problem keeps its linear-path result.  Writes at
  * most `cap` indices, returns how many there are.  (The reference's log-space arithmetic, LogSpace.hpp:232-244, never
- * leaves its range; this is how the fast path keeps that guarantee.) */
+ * leaves its range; this is how the fast path keeps that guarantee.)
+ * which = 2: the sequence indices that left the range with the default scale exponent and were recomputed on the linear kernels
+ * with another one (CONTRAfold model: 0.45, 1.5 or 0 per unit span instead of 0.12) -- they are NOT in the list of which = 0. */
 int rh_batch_fallbacks(rh_ctx* ctx, int which, int* out, int cap);
 
 /* Device pointers of the last batch (for callers that keep results on the GPU):

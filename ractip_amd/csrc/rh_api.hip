@@ -253,6 +253,15 @@ struct rh_ctx {
     ScoreModel* d_model = nullptr;
     LinModel* d_lin = nullptr;
     LinModel h_lin;
+    // other scale exponents of the linear McCaskill path, tried on the problems that leave the double range before the log-space
+    // kernels are (retry_mc_lin_rungs): built on first use from the host copy of the score model
+    static constexpr int kRungs = 3;
+    ScoreModel* h_score = nullptr;
+    LinModel* h_lin_r = nullptr;               // [kRungs]
+    LinModel* d_lin_r[kRungs] = {nullptr, nullptr, nullptr};
+    double* d_wT_r[kRungs] = {nullptr, nullptr, nullptr};
+    int scale_ladder = 1;                      // RH_SCALE_LADDER=0: flagged problems go straight to the log-space kernels
+    std::vector<int> rescaled_mc;              // sequences the last compute recomputed on the linear path with another exponent (rh_batch_fallbacks which = 2)
     ViennaDx* d_vienna = nullptr;  // RH_MODEL_VIENNA_BL only
     int vienna_sem = 0;            // kViennaSem18 / kViennaSem20 (0: CONTRAfold model)
     VLinModel* d_vlin = nullptr;   // the same model in scaled linear space
@@ -1177,6 +1186,127 @@ int recompute_mc_subset_log(rh_ctx* c, const std::vector<int>& F)
     return RH_OK;
 }
 
+// single-branch weights of the strip kernels: wT[l1*40 + t+1] = shape_w(l1, t-l1), zero where the shape does not exist
+std::vector<double> strip_weights(const LinModel& L)
+{
+    std::vector<double> wT(31 * 40, 0.0);
+    for (int t = 0; t <= kMaxSingle; t++)
+        for (int l1 = 0; l1 <= t; l1++) wT[(size_t)l1 * 40 + t + 1] = L.shape_w[t * (t + 1) / 2 + l1];
+    return wT;
+}
+
+// ---- other scale exponents before the log-space kernels (CONTRAfold model).  The scaled linear path stores Q * exp(-s * span): with
+// s = 0.12 (random ACGU: log Z per nucleotide 0.11-0.13) a 1100-nt RNA made of stable hairpins (0.58 per nucleotide) passes 1e200.
+// Such a sequence is recomputed on the SAME kernels with a larger exponent -- rung 0: s = 0.45, rung 1: s = 1.5 -- and one whose
+// values vanish (log Z per nucleotide far below 0.12 on a long sequence) with rung 2: s = 0; only what leaves the range there too
+// goes to the log-space kernels (3x slower).  An exponent costs dynamic range only, never accuracy: a cell that underflows to 0
+// while Z~ stays inside (1e-200, 1e200) is below 1e-100 of the terms that make up Z.  Flagged sequences are compacted into a
+// sub-batch that reuses the (dead) tables of the main pass; results are scattered back into their slots.
+constexpr double kRungS[rh_ctx::kRungs] = {0.45, 1.5, 0.0};
+
+int ensure_rungs(rh_ctx* c)
+{
+    if (c->h_lin_r) return RH_OK;
+    c->h_lin_r = new LinModel[rh_ctx::kRungs];
+    for (int r = 0; r < rh_ctx::kRungs; r++) {
+        build_lin_model(*c->h_score, kRungS[r], &c->h_lin_r[r]);
+        const std::vector<double> wT = strip_weights(c->h_lin_r[r]);
+        HIP_TRY(c, hipMalloc((void**)&c->d_lin_r[r], sizeof(LinModel)));
+        HIP_TRY(c, hipMemcpy(c->d_lin_r[r], &c->h_lin_r[r], sizeof(LinModel), hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMalloc((void**)&c->d_wT_r[r], sizeof(double) * wT.size()));
+        HIP_TRY(c, hipMemcpy(c->d_wT_r[r], wT.data(), sizeof(double) * wT.size(), hipMemcpyHostToDevice));
+    }
+    return RH_OK;
+}
+
+// `rest`: the sequences the main pass flagged; on return those that no rung could hold (for the log-space kernels)
+int retry_mc_lin_rungs(rh_ctx* c, std::vector<int>* rest)
+{
+    if (!c->scale_ladder || rest->empty()) return RH_OK;
+    int rc;
+    if ((rc = ensure_rungs(c))) return rc;
+    const McBatch B = c->mc;
+    const size_t up_per = (size_t)B.ld * c->max_w;
+    // direction: log Z = log(Z~) + s n of the failed pass is +Inf / NaN / large after an overflow, -Inf or below s n after an underflow
+    std::vector<double> lz(B.ns);
+    HIP_TRY(c, hipMemcpyAsync(lz.data(), c->d_mclogz, sizeof(double) * B.ns, hipMemcpyDeviceToHost, c->s_mc));
+    HIP_TRY(c, hipStreamSynchronize(c->s_mc));
+    std::vector<int> over, under;
+    for (int k : *rest) ((lz[k] == lz[k] && lz[k] < c->h_lin.s * c->n[k]) ? under : over).push_back(k);
+    const LinModel saved_h = c->h_lin;
+    LinModel* const saved_d = c->d_lin;
+    double* const saved_wT = c->d_wT;
+    const int saved_nl[3] = {c->n_launch[0], c->n_launch[1], c->n_launch[2]}, saved_nf[3] = {c->n_far[0], c->n_far[1], c->n_far[2]};
+    const auto restore = [&] {
+        c->mc = B; c->h_lin = saved_h; c->d_lin = saved_d; c->d_wT = saved_wT;
+        for (int q = 0; q < 3; q++) { c->n_launch[q] = saved_nl[q]; c->n_far[q] = saved_nf[q]; }
+    };
+    for (int rung = 0; rung < rh_ctx::kRungs; rung++) {
+        std::vector<int>& F = rung == 2 ? under : over;
+        const int nsub = (int)F.size();
+        if (!nsub) continue;
+        std::vector<uint8_t> codes((size_t)nsub * B.lds);
+        std::vector<int> lens(nsub);
+        int nmax = 0;
+        for (int k = 0; k < nsub; k++) {
+            std::memcpy(codes.data() + (size_t)k * B.lds, c->h_codes.data() + (size_t)F[k] * B.lds, B.lds);
+            lens[k] = c->n[F[k]];
+            nmax = std::max(nmax, lens[k]);
+        }
+        if ((rc = ensure(c, &c->d_subseq, &c->cap_subseq, codes.size(), false))) return rc;
+        if ((rc = ensure(c, &c->d_subn, &c->cap_subn, sizeof(int) * nsub, false))) return rc;
+        if ((rc = ensure(c, &c->d_subbp, &c->cap_subbp, sizeof(double) * B.tri_stride * nsub, false))) return rc;
+        if ((rc = ensure(c, &c->d_subup, &c->cap_subup, sizeof(double) * (up_per + 1) * nsub, false))) return rc;
+        HIP_TRY(c, hipMemcpyAsync(c->d_subseq, codes.data(), codes.size(), hipMemcpyHostToDevice, c->s_mc));
+        HIP_TRY(c, hipMemcpyAsync(c->d_subn, lens.data(), sizeof(int) * nsub, hipMemcpyHostToDevice, c->s_mc));
+        HIP_TRY(c, hipMemsetAsync(c->d_subbp, 0, sizeof(double) * B.tri_stride * nsub, c->s_mc));
+        // the tables (and packed operand tiles) the sub-batch reuses hold Inf / NaN of the failed pass: the fast path masks operands by
+        // multiplying with 0 in places
+        HIP_TRY(c, hipMemsetAsync(c->d_mctab, 0, sizeof(double) * B.seq_stride * nsub, c->s_mc));
+        if (c->d_pk) HIP_TRY(c, hipMemsetAsync(c->d_pk, 0, sizeof(double) * B.pk_stride * kPkCopies * nsub, c->s_mc));
+        HIP_TRY(c, hipStreamSynchronize(c->s_mc));   // the host staging vectors die with this scope
+        McBatch S = B;                 // same ld / strides
+        S.ns = nsub; S.nmax = nmax;
+        S.seq = (const uint8_t*)c->d_subseq; S.n = (const int*)c->d_subn;
+        S.f5i = (double*)c->d_f5; S.f5o = (double*)c->d_f5 + (size_t)B.ld * nsub;
+        S.bp = (double*)c->d_subbp; S.up = (double*)c->d_subup;
+        c->mc = S; c->h_lin = c->h_lin_r[rung]; c->d_lin = c->d_lin_r[rung]; c->d_wT = c->d_wT_r[rung];
+        const int spin = nsub % 8 == 0 ? 1 : 0;
+        rc = launch_mc_lin_any(c, spin, 0);
+        if (!rc) rc = launch_mc_lin_any(c, spin, 1);
+        if (rc) { restore(); return rc; }
+        // flags and log Z of the sub-batch are the first nsub entries of d_bad / d_mclogz
+        std::vector<int> sbad(nsub);
+        std::vector<double> slz(nsub);
+        hipError_t e = hipMemcpyAsync(sbad.data(), c->d_bad, sizeof(int) * nsub, hipMemcpyDeviceToHost, c->s_mc);
+        if (e == hipSuccess) e = hipMemcpyAsync(slz.data(), c->d_mclogz, sizeof(double) * nsub, hipMemcpyDeviceToHost, c->s_mc);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->s_mc);
+        if (e != hipSuccess) { restore(); return fail(c, RH_ERR_HIP, "scale ladder: %s", hipGetErrorString(e)); }
+        std::vector<int> still;
+        for (int k = 0; k < nsub; k++) {
+            if (sbad[k]) { still.push_back(F[k]); continue; }
+            e = hipMemcpyAsync((double*)c->d_bp + (size_t)F[k] * B.tri_stride, (double*)c->d_subbp + (size_t)k * B.tri_stride,
+                               sizeof(double) * B.tri_stride, hipMemcpyDeviceToDevice, c->s_mc);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync((double*)c->d_up + (size_t)F[k] * up_per, (double*)c->d_subup + (size_t)k * up_per, sizeof(double) * up_per,
+                                   hipMemcpyDeviceToDevice, c->s_mc);
+            if (e != hipSuccess) { restore(); return fail(c, RH_ERR_HIP, "scale ladder: %s", hipGetErrorString(e)); }
+            lz[F[k]] = slz[k];
+            c->rescaled_mc.push_back(F[k]);
+        }
+        F.swap(still);
+        restore();   // (every early return below finds the context as it was)
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->d_mclogz, lz.data(), sizeof(double) * B.ns, hipMemcpyHostToDevice, c->s_mc));
+    HIP_TRY(c, hipStreamSynchronize(c->s_mc));   // (lz dies with this scope)
+    rest->clear();
+    rest->insert(rest->end(), over.begin(), over.end());
+    rest->insert(rest->end(), under.begin(), under.end());
+    std::sort(rest->begin(), rest->end());
+    std::sort(c->rescaled_mc.begin(), c->rescaled_mc.end());
+    return RH_OK;
+}
+
 int recompute_dx_subset_log(rh_ctx* c, const std::vector<int>& F)
 {
     const DxBatch& D = c->dx;
@@ -1331,7 +1461,7 @@ int compute(rh_ctx* c)
     c->n_launch[0] = c->n_launch[1] = c->n_launch[2] = 0;
     c->n_far[0] = c->n_far[1] = c->n_far[2] = 0;
     c->last_path = 0;
-    c->fallback_mc.clear(); c->fallback_dx.clear();
+    c->fallback_mc.clear(); c->fallback_dx.clear(); c->rescaled_mc.clear();
     // sequence -> XCD affinity only when the batch spreads evenly over the 8 XCDs (speed only)
     const int pin = (c->has_mc && c->mc.ns % 8 == 0) ? 1 : 0;
     int rc;
@@ -1436,7 +1566,9 @@ int compute(rh_ctx* c)
             if (!c->fallback_mc.empty()) {
                 c->last_path = 3;
                 c->tables_dirty = true;
-                if (2 * c->fallback_mc.size() > (size_t)c->mc.ns) need_log = true;   // most of the batch: redo it whole
+                if ((rc = retry_mc_lin_rungs(c, &c->fallback_mc))) return rc;   // another exponent first; what is left goes to log space
+                if (c->fallback_mc.empty()) { }
+                else if (2 * c->fallback_mc.size() > (size_t)c->mc.ns) need_log = true;   // most of the batch: redo it whole
                 else if ((rc = recompute_mc_subset_log(c, c->fallback_mc))) return rc;
             }
         }
@@ -1589,6 +1721,7 @@ static rh_ctx* create_ctx(int device, int model, const char* param_file, const c
     // scale exponent of the linear fast path: log Z per nucleotide of typical sequences under this model
     // (random ACGU: 0.107..0.129 for n = 200..2000); deviations only cost dynamic range, never accuracy
     build_lin_model(host_model, 0.12, &c->h_lin);
+    c->h_score = new ScoreModel(host_model);
     // duplex: log Z per unit of (i + L2+1-j) is 0.62..0.82 on the bundled pairs, 0.645 for random sequences
     build_dx_lin_model(host_model, 0.65, &c->h_dxlin);
     if (const char* e = std::getenv("RH_LIN_W")) c->lin_w = c->lin_w_in = std::atoi(e);
@@ -1604,6 +1737,7 @@ static rh_ctx* create_ctx(int device, int model, const char* param_file, const c
     if (const char* e = std::getenv("RH_STRIP_XCD")) c->strip_xcd = std::atoi(e);
     if (const char* e = std::getenv("RH_ACC_WIDE")) c->acc_wide = std::atoi(e);
     if (const char* e = std::getenv("RH_CO_WINDOW")) c->co_window = std::atoi(e);
+    if (const char* e = std::getenv("RH_SCALE_LADDER")) c->scale_ladder = std::atoi(e);
     if (const char* e = std::getenv("RH_CO_SEED")) c->co_seed = std::atoi(e);
     if (const char* e = std::getenv("RH_DX_W")) c->dx_w = std::atoi(e);
     if (const char* e = std::getenv("RH_DX_QUAD")) c->dx_quad = std::atoi(e) != 0;
@@ -1616,10 +1750,8 @@ static rh_ctx* create_ctx(int device, int model, const char* param_file, const c
               hipMemcpy(c->d_lin, &c->h_lin, sizeof(LinModel), hipMemcpyHostToDevice) == hipSuccess &&
               hipMalloc((void**)&c->d_dxlin, sizeof(DxLinModel)) == hipSuccess &&
               hipMemcpy(c->d_dxlin, &c->h_dxlin, sizeof(DxLinModel), hipMemcpyHostToDevice) == hipSuccess;
-    if (ok) {   // single-branch weights of the strip kernels: wT[l1*40 + t+1] = shape_w(l1, t-l1), zero where the shape does not exist
-        std::vector<double> wT(31 * 40, 0.0);
-        for (int t = 0; t <= kMaxSingle; t++)
-            for (int l1 = 0; l1 <= t; l1++) wT[(size_t)l1 * 40 + t + 1] = c->h_lin.shape_w[t * (t + 1) / 2 + l1];
+    if (ok) {
+        const std::vector<double> wT = strip_weights(c->h_lin);
         ok = hipMalloc((void**)&c->d_wT, sizeof(double) * wT.size()) == hipSuccess &&
              hipMemcpy(c->d_wT, wT.data(), sizeof(double) * wT.size(), hipMemcpyHostToDevice) == hipSuccess;
     }
@@ -1661,11 +1793,14 @@ void rh_destroy(rh_ctx* c)
     (void)hipSetDevice(c->device);
     void* bufs[] = {c->d_seq, c->d_n, c->d_mctab, c->d_f5, c->d_bp, c->d_up, c->d_dxtab, c->d_hp, c->d_logz, c->d_scal, c->d_mclogz, c->d_bad, c->d_cnt, c->d_cand, c->d_dxbad, c->d_zbar, c->d_zpart, c->d_gaps, c->d_coseq, c->d_con, c->d_cotab, c->d_pk, c->d_copk, c->d_rowp, c->d_corowp, c->d_cof5, c->d_cobp, c->d_cobad, c->d_allow, c->d_coallow, c->d_vlin, c->d_vdxl, c->d_vdx, c->d_hplen, c->d_model, c->d_lin, c->d_dxlin, c->d_vienna, c->d_wT, c->d_subseq, c->d_subn, c->d_subbp, c->d_subup, c->d_subdseq, c->d_subdn, c->d_subdx};
     for (void* b : bufs) if (b) (void)hipFree(b);
+    for (int r = 0; r < rh_ctx::kRungs; r++) { if (c->d_lin_r[r]) (void)hipFree(c->d_lin_r[r]); if (c->d_wT_r[r]) (void)hipFree(c->d_wT_r[r]); }
     for (GraphSlot* g : {&c->g_in, &c->g_out, &c->g_dx}) if (g->exec) (void)hipGraphExecDestroy(g->exec);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->s_mc) (void)hipStreamDestroy(c->s_mc);
     if (c->s_dx) (void)hipStreamDestroy(c->s_dx);
     delete c->h_vlin;
+    delete c->h_score;
+    delete[] c->h_lin_r;
     delete c;
 }
 
@@ -1998,9 +2133,9 @@ int rh_batch_kernels(rh_ctx* c, const char* fine[3], const char* far[3], int n_f
 
 int rh_batch_fallbacks(rh_ctx* c, int which, int* out, int cap)
 {
-    if (!c || (which != 0 && which != 1)) return RH_ERR_ARG;
+    if (!c || which < 0 || which > 2) return RH_ERR_ARG;
     if (!c->computed) return fail(c, RH_ERR_ARG, "no computed batch");
-    const std::vector<int>& F = which ? c->fallback_dx : c->fallback_mc;
+    const std::vector<int>& F = which == 2 ? c->rescaled_mc : (which ? c->fallback_dx : c->fallback_mc);
     for (int k = 0; k < (int)F.size() && k < cap; k++) out[k] = F[k];
     return (int)F.size();
 }

@@ -305,7 +305,8 @@ class Context:
         return bufs
 
     def batch_fallbacks(self, which=0):
-        """Indices of the sequences (which=0) / pairs (which=1) the last compute recomputed in log space."""
+        """Indices of the sequences (which=0) / pairs (which=1) the last compute recomputed in log space; which=2: the sequences it
+        recomputed on the linear kernels with another scale exponent."""
         buf = (ctypes.c_int * max(1, 2 * len(self._pairs)))()
         k = self._check(self.L.rh_batch_fallbacks(self.h, which, buf, len(buf)))
         return [buf[t] for t in range(min(k, len(buf)))]

@@ -212,7 +212,8 @@ def test_mixed_batch_only_the_flagged_problems_fall_back(ctx, oracle):
     mixed[3] = (helix, pairs[3][1])
     ctx.batch_upload(mixed)
     ctx.batch_compute()
-    assert ctx.last_path() == 3 and ctx.batch_fallbacks(0) == [6]
+    # (the helix is held by the third scale exponent of the linear path, 1.5 per unit span, or else goes to the log-space kernels)
+    assert ctx.last_path() == 3 and sorted(ctx.batch_fallbacks(0) + ctx.batch_fallbacks(2)) == [6]
     for p in range(len(pairs)):
         r = ctx.batch_results(p)
         if p != 3:   # untouched problems: bit for bit what the all-ordinary batch gave
@@ -235,6 +236,52 @@ def test_mixed_batch_only_the_flagged_problems_fall_back(ctx, oracle):
         od = oracle.duplex(a, b)
         assert_prob_close(ctx.batch_results(3)["hp"], od["post"], rel=REL, what="overflowing duplex via per-pair fallback")
         assert np.array_equal(ctx.batch_results(0)["hp"], base[0]["hp"])
+
+
+def test_scale_exponent_ladder(hotlib, monkeypatch):
+    """Sequences that leave the double range with the default scale exponent are recomputed on the LINEAR kernels with another
+    exponent before the log-space kernels are tried (rh_batch_fallbacks which = 2).  Three 1100-nt chains of stable hairpins (log Z
+    0.58 per nucleotide: 1e220 scaled with s = 0.12, in range with s = 0.45) among ordinary sequences: they are rescaled, nothing goes
+    to log space, every other problem keeps its bits, and the rescaled results equal those of the log-space path (RH_SCALE_LADDER=0)."""
+    import ractip_amd
+    rng = np.random.default_rng(5)
+    comp = {"G": "C", "C": "G"}
+
+    def hairpins(n):
+        s = ""
+        while len(s) < n:
+            stem = "".join(rng.choice(list("GC"), size=10))
+            s += stem + "AAAA" + "".join(comp[ch] for ch in reversed(stem)) + "AA"
+        return s[:n]
+    rnd = lambda n: "".join(rng.choice(list("ACGU"), size=n))
+    seqs = [rnd(1100), hairpins(1100), rnd(640), hairpins(1100), hairpins(1100), rnd(1100), rnd(300), rnd(900)]
+    pairs = list(zip(seqs[0::2], seqs[1::2]))
+
+    def run(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        c = ractip_amd.Context(device=0)
+        try:
+            c.batch_upload(pairs)
+            c.batch_compute()
+            return c.last_path(), c.batch_fallbacks(0), c.batch_fallbacks(2), [c.batch_results(p) for p in range(len(pairs))]
+        finally:
+            c.close()
+            for k in env:
+                monkeypatch.delenv(k)
+
+    path, logged, rescaled, res = run({})
+    assert path == 3 and logged == [] and rescaled == [1, 3, 4]
+    path0, logged0, rescaled0, ref = run({"RH_SCALE_LADDER": "0"})
+    assert path0 == 3 and logged0 == [1, 3, 4] and rescaled0 == []
+    for p, (r, r0) in enumerate(zip(res, ref)):
+        for which, key, up in ((0, "bp1", "up1"), (1, "bp2", "up2")):
+            if 2 * p + which in (1, 3, 4):
+                assert abs(r["logZ"][which] - r0["logZ"][which]) < 1e-9 * abs(r0["logZ"][which])
+                assert_prob_close(r[key], r0[key], rel=REL, what="rescaled sequence %d" % (2 * p + which))
+                assert np.abs(r[up] - r0[up]).max() < 1e-9
+            else:
+                assert np.array_equal(r[key], r0[key]) and np.array_equal(r[up], r0[up]) and r["logZ"][which] == r0["logZ"][which]
 
 
 def test_real_and_gc_rich_sequences_stay_on_the_linear_path(ctx, golden):
