@@ -210,7 +210,8 @@ int rh_set_overlap(rh_ctx* ctx, int on);
  * most `cap` indices, returns how many there are.  (The reference's log-space arithmetic, LogSpace.hpp:232-244, never
  * leaves its range; this is how the fast path keeps that guarantee.)
  * which = 2: the sequence indices that left the range with the default scale exponent and were recomputed on the linear kernels
- * with another one (CONTRAfold model: 0.45, 1.5 or 0 per unit span instead of 0.12) -- they are NOT in the list of which = 0. */
+ * with another one (CONTRAfold model: 0.45, 1.5 or 0 per unit span instead of 0.12) -- they are NOT in the list of which = 0.
+ * When one exponent held more than half of a batch of at least eight sequences, the next rh_batch_compute starts on it. */
 int rh_batch_fallbacks(rh_ctx* ctx, int which, int* out, int cap);
 
 /* Device pointers of the last batch (for callers that keep results on the GPU):

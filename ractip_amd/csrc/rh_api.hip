@@ -261,6 +261,14 @@ struct rh_ctx {
     LinModel* d_lin_r[kRungs] = {nullptr, nullptr, nullptr};
     double* d_wT_r[kRungs] = {nullptr, nullptr, nullptr};
     int scale_ladder = 1;                      // RH_SCALE_LADDER=0: flagged problems go straight to the log-space kernels
+    // the default exponent's model (what h_lin / d_lin / d_wT hold unless a pass runs on a rung) and the exponent the NEXT batch starts
+    // with: -1 = default, k = rung k -- the one that held more than half of the last batch (a stream of structured RNAs does not pay
+    // a failed first pass per batch)
+    LinModel h_lin0;
+    LinModel* d_lin0 = nullptr;
+    double* d_wT0 = nullptr;
+    int lin_primary = -1;
+    int rescued_by[kRungs + 1] = {0, 0, 0, 0};  // sequences the last ladder moved to the default exponent [0] / rung k [k + 1]
     std::vector<int> rescaled_mc;              // sequences the last compute recomputed on the linear path with another exponent (rh_batch_fallbacks which = 2)
     ViennaDx* d_vienna = nullptr;  // RH_MODEL_VIENNA_BL only
     int vienna_sem = 0;            // kViennaSem18 / kViennaSem20 (0: CONTRAfold model)
@@ -1236,13 +1244,26 @@ int retry_mc_lin_rungs(rh_ctx* c, std::vector<int>* rest)
     const LinModel saved_h = c->h_lin;
     LinModel* const saved_d = c->d_lin;
     double* const saved_wT = c->d_wT;
+    for (int& q : c->rescued_by) q = 0;
+    // the exponents to try: larger ones in ascending order for the overflows, smaller ones in descending order for the underflows
+    // (model -1 = the default exponent, when this pass ran on a rung)
+    struct Try { int model; bool up; };
+    std::vector<Try> tries;
+    {
+        std::vector<std::pair<double, int>> all = {{c->h_lin0.s, -1}};
+        for (int r = 0; r < rh_ctx::kRungs; r++) all.push_back({kRungS[r], r});
+        std::sort(all.begin(), all.end());
+        for (const auto& e : all) if (e.first > saved_h.s + 1e-12) tries.push_back({e.second, true});
+        for (auto it = all.rbegin(); it != all.rend(); ++it) if (it->first < saved_h.s - 1e-12) tries.push_back({it->second, false});
+    }
     const int saved_nl[3] = {c->n_launch[0], c->n_launch[1], c->n_launch[2]}, saved_nf[3] = {c->n_far[0], c->n_far[1], c->n_far[2]};
     const auto restore = [&] {
         c->mc = B; c->h_lin = saved_h; c->d_lin = saved_d; c->d_wT = saved_wT;
         for (int q = 0; q < 3; q++) { c->n_launch[q] = saved_nl[q]; c->n_far[q] = saved_nf[q]; }
     };
-    for (int rung = 0; rung < rh_ctx::kRungs; rung++) {
-        std::vector<int>& F = rung == 2 ? under : over;
+    for (const Try& t : tries) {
+        const int rung = t.model;
+        std::vector<int>& F = t.up ? over : under;
         const int nsub = (int)F.size();
         if (!nsub) continue;
         std::vector<uint8_t> codes((size_t)nsub * B.lds);
@@ -1270,7 +1291,9 @@ int retry_mc_lin_rungs(rh_ctx* c, std::vector<int>* rest)
         S.seq = (const uint8_t*)c->d_subseq; S.n = (const int*)c->d_subn;
         S.f5i = (double*)c->d_f5; S.f5o = (double*)c->d_f5 + (size_t)B.ld * nsub;
         S.bp = (double*)c->d_subbp; S.up = (double*)c->d_subup;
-        c->mc = S; c->h_lin = c->h_lin_r[rung]; c->d_lin = c->d_lin_r[rung]; c->d_wT = c->d_wT_r[rung];
+        c->mc = S;
+        if (rung < 0) { c->h_lin = c->h_lin0; c->d_lin = c->d_lin0; c->d_wT = c->d_wT0; }
+        else { c->h_lin = c->h_lin_r[rung]; c->d_lin = c->d_lin_r[rung]; c->d_wT = c->d_wT_r[rung]; }
         const int spin = nsub % 8 == 0 ? 1 : 0;
         rc = launch_mc_lin_any(c, spin, 0);
         if (!rc) rc = launch_mc_lin_any(c, spin, 1);
@@ -1293,6 +1316,7 @@ int retry_mc_lin_rungs(rh_ctx* c, std::vector<int>* rest)
             if (e != hipSuccess) { restore(); return fail(c, RH_ERR_HIP, "scale ladder: %s", hipGetErrorString(e)); }
             lz[F[k]] = slz[k];
             c->rescaled_mc.push_back(F[k]);
+            c->rescued_by[rung + 1]++;
         }
         F.swap(still);
         restore();   // (every early return below finds the context as it was)
@@ -1554,6 +1578,10 @@ int compute(rh_ctx* c)
             if (c->last_path == 0) c->last_path = 2;
         }
     } else if (c->has_mc && c->mode != RH_MODE_LOG) {
+        // the exponent most of the last batch needed (scale-exponent ladder); h_lin / d_lin / d_wT are the default's again afterwards
+        const bool on_rung = c->mode == RH_MODE_AUTO && c->scale_ladder && c->lin_primary >= 0 && c->h_lin_r;
+        if (on_rung) { c->h_lin = c->h_lin_r[c->lin_primary]; c->d_lin = c->d_lin_r[c->lin_primary]; c->d_wT = c->d_wT_r[c->lin_primary]; }
+        struct Back { rh_ctx* c; ~Back() { c->h_lin = c->h_lin0; c->d_lin = c->d_lin0; c->d_wT = c->d_wT0; } } back{c};
         if ((rc = run_graphed(c, c->g_in, shape_key(c, 0), c->s_mc, &c->n_launch[0], &c->n_far[0], [&] { return launch_mc_lin_any(c, pin, 0); }))) return rc;
         HIP_TRY(c, hipEventRecord(c->ev[1], c->s_mc));
         if ((rc = run_graphed(c, c->g_out, shape_key(c, 1), c->s_mc, &c->n_launch[1], &c->n_far[1], [&] { return launch_mc_lin_any(c, pin, 1); }))) return rc;
@@ -1567,6 +1595,8 @@ int compute(rh_ctx* c)
                 c->last_path = 3;
                 c->tables_dirty = true;
                 if ((rc = retry_mc_lin_rungs(c, &c->fallback_mc))) return rc;   // another exponent first; what is left goes to log space
+                for (int q = 0; q <= rh_ctx::kRungs; q++)   // more than half of the batch on one exponent: the next batch starts there
+                    if (c->mc.ns >= 8 && 2 * c->rescued_by[q] > c->mc.ns) c->lin_primary = q - 1;   // (a batch, not a single call)
                 if (c->fallback_mc.empty()) { }
                 else if (2 * c->fallback_mc.size() > (size_t)c->mc.ns) need_log = true;   // most of the batch: redo it whole
                 else if ((rc = recompute_mc_subset_log(c, c->fallback_mc))) return rc;
@@ -1755,6 +1785,7 @@ static rh_ctx* create_ctx(int device, int model, const char* param_file, const c
         ok = hipMalloc((void**)&c->d_wT, sizeof(double) * wT.size()) == hipSuccess &&
              hipMemcpy(c->d_wT, wT.data(), sizeof(double) * wT.size(), hipMemcpyHostToDevice) == hipSuccess;
     }
+    c->h_lin0 = c->h_lin; c->d_lin0 = c->d_lin; c->d_wT0 = c->d_wT;
     if (ok && host_vienna) {
         c->h_vlin = new VLinModel;
         // scale exponent: log Z per nucleotide of random ACGU under the BL* energies is 0.21..0.33 for n = 200..500 (up to 0.45 on the bundled RNAs)

@@ -284,6 +284,51 @@ def test_scale_exponent_ladder(hotlib, monkeypatch):
                 assert np.array_equal(r[key], r0[key]) and np.array_equal(r[up], r0[up]) and r["logZ"][which] == r0["logZ"][which]
 
 
+def test_scale_exponent_is_remembered(hotlib):
+    """A batch most of whose sequences needed another exponent moves the context there: the next batch of the kind runs on it
+    at once (path 1); a later batch of ordinary long sequences that vanish under that exponent moves it back."""
+    import ractip_amd
+    rng = np.random.default_rng(6)
+    comp = {"G": "C", "C": "G"}
+
+    def hairpins(n):
+        s = ""
+        while len(s) < n:
+            stem = "".join(rng.choice(list("GC"), size=10))
+            s += stem + "AAAA" + "".join(comp[ch] for ch in reversed(stem)) + "AA"
+        return s[:n]
+    rnd = lambda n: "".join(rng.choice(list("ACGU"), size=n))
+    structured = [(hairpins(1100), hairpins(1000)) for _ in range(4)]
+    ordinary = [(rnd(2000), rnd(1900)) for _ in range(4)]
+    c = ractip_amd.Context(device=0)
+    try:
+        c.batch_upload(structured); c.batch_compute()
+        assert c.last_path() == 3 and c.batch_fallbacks(2) == list(range(8)) and c.batch_fallbacks(0) == []
+        first = [c.batch_results(p) for p in range(4)]
+        c.batch_upload(structured); c.batch_compute()
+        assert c.last_path() == 1 and c.batch_fallbacks(2) == []          # straight on the exponent that worked
+        for r, r0 in zip([c.batch_results(p) for p in range(4)], first):
+            assert np.allclose(r["logZ"], r0["logZ"], rtol=1e-12, atol=0)
+            assert_prob_close(r["bp1"], r0["bp1"], rel=1e-9, what="second batch on the remembered exponent")
+        c.batch_upload(ordinary); c.batch_compute()                           # 0.12 per nucleotide under s = 0.45: 1e-280 scaled
+        assert c.last_path() == 3 and c.batch_fallbacks(2) == list(range(8)) and c.batch_fallbacks(0) == []
+        moved = [c.batch_results(p) for p in range(4)]
+        c.batch_upload(ordinary); c.batch_compute()
+        assert c.last_path() == 1                                            # back on the default exponent
+        fresh = ractip_amd.Context(device=0)
+        try:
+            fresh.batch_upload(ordinary); fresh.batch_compute()
+            assert fresh.last_path() == 1
+            for p in range(4):
+                r, r0, r1 = c.batch_results(p), fresh.batch_results(p), moved[p]
+                assert np.array_equal(r["bp1"], r0["bp1"]) and np.array_equal(r["logZ"], r0["logZ"])   # the same kernels, the same exponent
+                assert_prob_close(r1["bp2"], r0["bp2"], rel=1e-9, what="ordinary sequence through the ladder")
+        finally:
+            fresh.close()
+    finally:
+        c.close()
+
+
 def test_real_and_gc_rich_sequences_stay_on_the_linear_path(ctx, golden):
     """The scale exponent is tuned on random ACGU (log Z per nucleotide 0.11-0.13); the bundled RNAs sit at 0.13-0.23 and a
     70 % GC sequence higher still: all of them must stay inside the double range on the fast path, up to n = 2000."""
