@@ -211,7 +211,9 @@ int rh_set_overlap(rh_ctx* ctx, int on);
  * leaves its range; this is how the fast path keeps that guarantee.)
  * which = 2: the sequence indices that left the range with the default scale exponent and were recomputed on the linear kernels
  * with another one (CONTRAfold model: 0.45, 1.5 or 0 per unit span instead of 0.12) -- they are NOT in the list of which = 0.
- * When one exponent held more than half of a batch of at least eight sequences, the next rh_batch_compute starts on it. */
+ * When one exponent held more than half of a batch of at least eight sequences, the next rh_batch_compute starts on it.
+ * Vienna-BL model: the whole batch is run again with another exponent (0.7, 1.8 or 0 instead of 0.28); which = 2 then lists the
+ * sequences that made it necessary. */
 int rh_batch_fallbacks(rh_ctx* ctx, int which, int* out, int cap);
 
 /* Device pointers of the last batch (for callers that keep results on the GPU):

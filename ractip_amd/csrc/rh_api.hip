@@ -274,6 +274,16 @@ struct rh_ctx {
     int vienna_sem = 0;            // kViennaSem18 / kViennaSem20 (0: CONTRAfold model)
     VLinModel* d_vlin = nullptr;   // the same model in scaled linear space
     VLinModel* h_vlin = nullptr;
+    // Vienna-BL: other scale exponents of the linear path, tried on the WHOLE batch (single-molecule folds and two-molecule sweeps
+    // together: the latter are seeded from the former) before the log-space kernels; see compute().  Model -1 = the default exponent.
+    static constexpr int kVRungs = 3;
+    ViennaDx* h_vienna = nullptr;              // host copy of the energy tables the rung models are built from
+    VLinModel* h_vlin_m[kVRungs + 1] = {nullptr, nullptr, nullptr, nullptr};   // [0] = default, [k + 1] = rung k
+    VLinModel* d_vlin_m[kVRungs + 1] = {nullptr, nullptr, nullptr, nullptr};
+    int vlin_cur = -1, vlin_primary = -1;      // model selected now / the one a batch starts with
+    bool defer_log = false, deferred = false;  // compute_once: a flagged problem ends the attempt instead of starting the log-space kernels
+    bool went_log = false;                     // compute_once (Vienna-BL): the batch was recomputed by the log-space kernels
+    std::vector<int> flagged_mc;               // sequences the deferred attempts flagged
     VLinModel* d_vdxl = nullptr;   // the same tables at the duplex scale (duplex_vlin.hip)
     VDxLin* d_vdx = nullptr;
     double vdx_s = 0.27;           // log Z of pf_duplex per unit of a+b: 0.23 (random ACGU) .. 0.32 (70 % GC)
@@ -1461,14 +1471,14 @@ size_t shape_key(const rh_ctx* c, int which)
         for (size_t v : {(size_t)B.ns, (size_t)B.nmax, (size_t)B.ld, (size_t)B.lds, (size_t)B.tab, (size_t)B.seq, (size_t)B.n, (size_t)B.f5i,
                          (size_t)B.bp, (size_t)c->d_cobad, (size_t)c->lin_bs, (size_t)B.tri_stride, (size_t)c->dx.hp, (size_t)c->dx.logz,
                          (size_t)c->dx.ldd, (size_t)c->dx.tab_stride, (size_t)c->dx.n1max, (size_t)c->dx.n2max, (size_t)B.allow, (size_t)B.pk,
-                         (size_t)c->far_pk, (size_t)B.rowp, (size_t)c->lookahead, (size_t)B.seeded, (size_t)c->mc.tab, (size_t)c->mc.ld})
+                         (size_t)c->far_pk, (size_t)B.rowp, (size_t)c->lookahead, (size_t)B.seeded, (size_t)c->mc.tab, (size_t)c->mc.ld, (size_t)c->d_vlin})
             h = mix(h, v);
     } else if (which <= 1) {
         const McBatch& B = c->mc;
         for (size_t v : {(size_t)B.ns, (size_t)B.nmax, (size_t)B.ld, (size_t)B.lds, (size_t)B.tab, (size_t)B.seq, (size_t)B.n,
                          (size_t)B.f5i, (size_t)B.bp, (size_t)B.up, (size_t)c->d_bad, (size_t)c->d_mclogz, (size_t)c->lin_w, (size_t)c->lin_w_in,
                          (size_t)c->lin_bs, (size_t)B.tri_stride, (size_t)c->far_mfma, (size_t)c->max_w, (size_t)c->d_gaps,
-                         (size_t)c->d_hplen, (size_t)B.allow, (size_t)B.pk, (size_t)c->far_pk, (size_t)B.rowp, (size_t)c->lookahead, (size_t)c->strip, (size_t)c->d_wT, (size_t)c->strip_w, (size_t)c->strip_xcd, (size_t)(c->far2 + 2), (size_t)c->acc_wide, (size_t)c->co_window, (size_t)c->co_cut_min, (size_t)c->co_cut_max})
+                         (size_t)c->d_hplen, (size_t)B.allow, (size_t)B.pk, (size_t)c->far_pk, (size_t)B.rowp, (size_t)c->lookahead, (size_t)c->strip, (size_t)c->d_wT, (size_t)c->strip_w, (size_t)c->strip_xcd, (size_t)(c->far2 + 2), (size_t)c->acc_wide, (size_t)c->co_window, (size_t)c->co_cut_min, (size_t)c->co_cut_max, (size_t)c->d_vlin})
             h = mix(h, v);
     } else {
         const DxLinBatch& X = c->dxl;
@@ -1479,9 +1489,11 @@ size_t shape_key(const rh_ctx* c, int which)
     return h;
 }
 
-int compute(rh_ctx* c)
+int compute_once(rh_ctx* c)
 {
     HIP_TRY(c, hipSetDevice(c->device));
+    c->deferred = false;
+    c->went_log = false;
     c->n_launch[0] = c->n_launch[1] = c->n_launch[2] = 0;
     c->n_far[0] = c->n_far[1] = c->n_far[2] = 0;
     c->last_path = 0;
@@ -1566,9 +1578,15 @@ int compute(rh_ctx* c)
                 HIP_TRY(c, hipStreamSynchronize(c->s_mc));
                 for (int b : bad) log_path |= (b != 0);
                 if (log_path) { c->last_path = 3; c->tables_dirty = true; co_seed_bad = co_seed; }
+                if (log_path && c->defer_log) {   // another exponent first (compute): this attempt ends here
+                    for (int k = 0; k < c->mc.ns; k++) if (bad[k]) c->flagged_mc.push_back(k);
+                    c->deferred = true;
+                    log_path = false;
+                }
             }
         }
         if (log_path) {
+            c->went_log = true;
             out_from_ev5 = false;
             c->n_launch[0] = c->n_launch[1] = 0;
             c->n_far[0] = c->n_far[1] = 0;
@@ -1620,7 +1638,9 @@ int compute(rh_ctx* c)
         HIP_TRY(c, hipStreamSynchronize(c->s_dx));
         bool redo = co_seed_bad;   // a molecule left the double range on its own: what was copied from its fold is not usable
         for (int b : bad) redo |= (b != 0);
-        if (redo) {   // some pair left the double range: recompute the two-molecule sweeps in log space
+        if (redo && c->defer_log) { c->tables_dirty = true; c->deferred = true; }
+        else if (redo) {   // some pair left the double range: recompute the two-molecule sweeps in log space
+            c->went_log = true;
             c->tables_dirty = true;
             c->n_launch[2] = 0; c->n_far[2] = 0;
             HIP_TRY(c, hipEventRecord(c->ev[3], c->s_dx));
@@ -1663,6 +1683,80 @@ int compute(rh_ctx* c)
     c->ms[0] = t01; c->ms[1] = t12; c->ms[2] = t34; c->ms[3] = std::max(t02, t34);
     c->computed = true;
     return RH_OK;
+}
+
+// ---- Vienna-BL: other scale exponents before the log-space kernels.  The linear path stores Q * exp(-s * span) with s = 0.28 (random ACGU
+// under the BL* energies: 0.21-0.33 per nucleotide); a 900-nt chain of stable hairpins (0.87) or a ribosomal RNA (~0.6 at 1500 nt)
+// passes 1e200, and one such sequence used to send the whole batch -- single-molecule folds, accessibility and the two-molecule
+// sweeps -- to the log-space kernels.  Now the batch is run again on the linear kernels with s = 0.7, then 1.8, then 0 (models built
+// on first use), and goes to log space only when every exponent left some problem outside the range.  Whole batches, not problems
+// (the two-molecule sweeps are seeded from the single folds of the same pass); the exponent that worked is where the next batch of at
+// least eight sequences starts.  rh_last_path = 3 and rh_batch_fallbacks(which = 2) = the sequences the first attempts flagged.
+constexpr double kVRungS[rh_ctx::kVRungs] = {0.7, 1.8, 0.0};
+
+int select_vlin(rh_ctx* c, int model)
+{
+    if (model == c->vlin_cur) return RH_OK;
+    const int k = model + 1;
+    if (!c->h_vlin_m[k]) {
+        c->h_vlin_m[k] = new VLinModel;
+        build_vlin_model(*c->h_vienna, kVRungS[model], c->h_vlin_m[k]);
+        HIP_TRY(c, hipMalloc((void**)&c->d_vlin_m[k], sizeof(VLinModel)));
+        HIP_TRY(c, hipMemcpy(c->d_vlin_m[k], c->h_vlin_m[k], sizeof(VLinModel), hipMemcpyHostToDevice));
+    }
+    c->h_vlin = c->h_vlin_m[k];
+    c->d_vlin = c->d_vlin_m[k];
+    c->vlin_cur = model;
+    // hairpin length weights x lam^d (kernel arguments of the inside sweeps; the device copy serves the accessibility)
+    const VLinModel& H = *c->h_vlin;
+    for (size_t d = 0; d < c->h_hplen.size(); d++)
+        c->h_hplen[d] = (d <= 30 ? H.E_hairpin[d] : std::exp(H.hairpin30 - H.lxc * std::log(d / 30.0))) * std::exp(-H.s * (double)d);
+    if (c->d_hplen && c->has_mc) {
+        HIP_TRY(c, hipMemcpyAsync(c->d_hplen, c->h_hplen.data(), sizeof(double) * std::min((size_t)c->mc.ld, c->h_hplen.size()), hipMemcpyHostToDevice, c->s_mc));
+        HIP_TRY(c, hipStreamSynchronize(c->s_mc));
+    }
+    return RH_OK;
+}
+
+int compute(rh_ctx* c)
+{
+    c->defer_log = false;
+    c->flagged_mc.clear();
+    const bool ladder = c->model == RH_MODEL_VIENNA_BL && c->mode == RH_MODE_AUTO && c->scale_ladder && c->has_mc && c->h_vienna &&
+                        c->vienna_sem != kViennaSem20 && !std::getenv("RH_VLIN_S");
+    if (!ladder) return compute_once(c);
+    HIP_TRY(c, hipSetDevice(c->device));
+    // the exponent the batch starts with, then the others: larger ones ascending, smaller ones descending
+    std::vector<int> order = {c->vlin_primary};
+    {
+        std::vector<std::pair<double, int>> all = {{c->h_vlin_m[0]->s, -1}};
+        for (int r = 0; r < rh_ctx::kVRungs; r++) all.push_back({kVRungS[r], r});
+        std::sort(all.begin(), all.end());
+        const double s0 = c->vlin_primary < 0 ? c->h_vlin_m[0]->s : kVRungS[c->vlin_primary];
+        for (const auto& e : all) if (e.first > s0 + 1e-12) order.push_back(e.second);
+        for (auto it = all.rbegin(); it != all.rend(); ++it) if (it->first < s0 - 1e-12) order.push_back(it->second);
+    }
+    int rc = RH_OK;
+    for (size_t a = 0; a < order.size(); a++) {
+        if ((rc = select_vlin(c, order[a]))) break;
+        c->defer_log = a + 1 < order.size();
+        if ((rc = compute_once(c))) break;
+        if (!c->deferred) {
+            if (a > 0) {   // held by another exponent
+                c->last_path = 3;
+                std::sort(c->flagged_mc.begin(), c->flagged_mc.end());
+                c->flagged_mc.erase(std::unique(c->flagged_mc.begin(), c->flagged_mc.end()), c->flagged_mc.end());
+                if (!c->went_log) {   // (the last attempt may still have ended in log space)
+                    c->rescaled_mc = c->flagged_mc;
+                    if (c->mc.ns >= 8) c->vlin_primary = order[a];   // a batch, not a single call: the next one starts here
+                }
+            }
+            break;
+        }
+    }
+    c->defer_log = false;
+    const int back = select_vlin(c, c->vlin_primary);
+    return rc ? rc : back;
 }
 
 // copy one sequence's posterior out of the (nmax-strided) device buffer
@@ -1808,7 +1902,8 @@ static rh_ctx* create_ctx(int device, int model, const char* param_file, const c
             delete tmp;
         }
     }
-    delete host_vienna;
+    c->h_vienna = host_vienna;   // (kept: the rung models of the scale-exponent ladder are built from it)
+    c->h_vlin_m[0] = c->h_vlin; c->d_vlin_m[0] = c->d_vlin;
     for (int k = 0; ok && k < 6; k++) ok = hipEventCreate(&c->ev[k]) == hipSuccess;
     if (!ok) {
         fail(nullptr, RH_ERR_HIP, "context setup failed: %s", hipGetErrorString(hipGetLastError()));
@@ -1829,7 +1924,12 @@ void rh_destroy(rh_ctx* c)
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->s_mc) (void)hipStreamDestroy(c->s_mc);
     if (c->s_dx) (void)hipStreamDestroy(c->s_dx);
+    for (int k = 0; k <= rh_ctx::kVRungs; k++) {
+        if (c->d_vlin_m[k] && c->d_vlin_m[k] != c->d_vlin) (void)hipFree(c->d_vlin_m[k]);   // (the selected one went with `bufs`)
+        if (c->h_vlin_m[k] && c->h_vlin_m[k] != c->h_vlin) delete c->h_vlin_m[k];
+    }
     delete c->h_vlin;
+    delete c->h_vienna;
     delete c->h_score;
     delete[] c->h_lin_r;
     delete c;

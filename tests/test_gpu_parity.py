@@ -677,6 +677,54 @@ def test_vienna_bl_two_molecule_organisations_agree(hotlib, monkeypatch):
             assert_prob_close(r["hp"], r0["hp"], rel=1e-10, what="%r hp %d/%d" % (env, len(s1), len(s2)))
 
 
+def test_vienna_bl_scale_exponent_ladder(hotlib, monkeypatch):
+    """Vienna-BL model: a batch with sequences outside the double range of the default exponent (chains of stable hairpins, log Z
+    0.87 per nucleotide at 900 nt) is run again on the linear kernels with another exponent -- whole batch: folds, accessibility and
+    the two-molecule sweeps -- instead of the log-space kernels; results equal those of the log-space path (RH_SCALE_LADDER=0), and
+    the next batch of the kind starts on the exponent that worked."""
+    import ractip_amd
+    rng = np.random.default_rng(8)
+    comp = {"G": "C", "C": "G"}
+
+    def hairpins(n):
+        s = ""
+        while len(s) < n:
+            stem = "".join(rng.choice(list("GC"), size=10))
+            s += stem + "AAAA" + "".join(comp[ch] for ch in reversed(stem)) + "AA"
+        return s[:n]
+    rnd = lambda n: "".join(rng.choice(list("ACGU"), size=n))
+    pairs = [(hairpins(900), rnd(300)), (rnd(420), hairpins(800)), (rnd(350), rnd(500)), (hairpins(850), hairpins(700))]
+
+    def run(env, twice=False):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        c = ractip_amd.Context(device=0, model=ractip_amd.hot.RH_MODEL_VIENNA_BL)
+        try:
+            c.set_hybrid(True)
+            c.batch_upload(pairs); c.batch_compute()
+            out = (c.last_path(), c.batch_fallbacks(2), [c.batch_results(p) for p in range(len(pairs))])
+            if twice:
+                c.batch_upload(pairs); c.batch_compute()
+                out += (c.last_path(), c.batch_fallbacks(2))
+            return out
+        finally:
+            c.close()
+            for k in env:
+                monkeypatch.delenv(k)
+
+    path, rescaled, res, path2, rescaled2 = run({}, twice=True)
+    assert path == 3 and rescaled == [0, 3, 6]                 # (the 700-nt chain stays inside the range: 1e179 scaled)
+    assert path2 == 1 and rescaled2 == []                     # second batch: straight on the exponent that worked
+    path0, rescaled0, ref = run({"RH_SCALE_LADDER": "0"})
+    assert path0 == 3 and rescaled0 == []
+    for p, (r, r0) in enumerate(zip(res, ref)):
+        assert np.allclose(r["logZ"], r0["logZ"], rtol=1e-9, atol=0), p
+        assert_prob_close(r["bp1"], r0["bp1"], rel=REL, what="bp1 of pair %d" % p)
+        assert_prob_close(r["bp2"], r0["bp2"], rel=REL, what="bp2 of pair %d" % p)
+        assert_prob_close(r["hp"], r0["hp"], rel=REL, what="hp of pair %d" % p)
+        assert_prob_close(r["up1"], r0["up1"], rel=REL, abs_floor=1e-11, what="up1 of pair %d" % p)
+
+
 def test_vienna_bl_linear_path_falls_back_on_overflow(vctx):
     """A 1200-nt perfect GC helix has log Z ~ 2.5 per nucleotide: the scaled linear values leave the double range, the
     device flags it and the batch is recomputed in log space; results equal the log-space context's."""
@@ -690,7 +738,9 @@ def test_vienna_bl_linear_path_falls_back_on_overflow(vctx):
     ref.set_mode(1)
     bp2, z2 = ref.bpp(s)
     ref.close()
-    assert np.array_equal(bp, bp2) and z == z2 and np.isfinite(z) and z > 1000
+    # (recomputed in log space -- then bit for bit the log-space context's result -- or held by another scale exponent of the linear path)
+    assert np.isfinite(z) and z > 1000 and abs(z - z2) < 1e-9 * z2
+    assert_prob_close(bp, bp2, rel=REL, what="GC helix after the fallback")
     n = len(s)
     o = tri_offset(n, 300)
     assert bp[o + 301:o + n + 1].sum() > 0.99              # a G in the middle of the run is paired (the helix may slip)
