@@ -223,6 +223,7 @@ def main():
     ap.add_argument("--seqlen", "--n", dest="n", type=int, default=500,
                     help="sequence length of the synthetic pairs (BASELINE config 3: 500, config 4: 2000)")
     ap.add_argument("--batch", type=int, default=0, help="pairs per GPU per step (0 = auto)")
+    ap.add_argument("--contexts", type=int, default=0, help="contexts / host threads whose steps alternate on one GPU (0 = auto: 2 for n <= 1200 on one GPU, else 1)")
     ap.add_argument("--workload", default="pairs", choices=["pairs", "zscore"],
                     help="pairs: synthetic random pairs of one length; zscore: BASELINE config 5, the DP stage of the z-score loop "
                          "(src/ractip.cpp:1638-1657): 1000 dinucleotide shuffles of OxyS/fhlA per step")
@@ -297,7 +298,7 @@ def main():
     cofold = vienna and (args.hp or "cofold") == "cofold"
     # two contexts on one GPU: their steps alternate, so uploads / result copies of one overlap the kernels of the other.
     # Ranks of a multi-GPU run keep one context: the gather is a collective and stays on the main thread.
-    n_ctx = 2 if (world == 1 and n <= 1200) else 1
+    n_ctx = args.contexts or (2 if (world == 1 and n <= 1200) else 1)
     ctxs = [ractip_amd.Context(device=device_index, model=model_id) for _ in range(n_ctx)]
     for c in ctxs:
         if vienna:
