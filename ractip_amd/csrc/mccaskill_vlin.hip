@@ -1542,6 +1542,133 @@ __global__ __launch_bounds__(256) void vlin_acc_final(McBatch B, const VLinModel
     *up = acc > 1.0 ? 1.0 : acc;
 }
 
+// The same with one THREAD per letter and all widths w < 15 in it (vlin_acc_final has one thread per letter AND width: two loads per FMA,
+// fifteen times over).  The two multiloop streams are sums over a run of cells whose operands for the fifteen widths overlap:
+//   run before a branch: sum_r FM1o[r+w+1][a-1] * FM1[r][a+w]: rows r+1 .. r+15 of ONE column in a ring of 16 staged rows (read at lane),
+//     and ONE row of FM1 staged per step (read at lane + w);
+//   run after the last branch: sum_e FMSo[e+w+1][a-1-e] * FMS[e][a-1-e]: the second factor does not depend on w (a register), the first
+//     comes from a ring of 16 staged row segments (row R: columns a0-R .. a0-R+77 of the wavefront's 64 letters), again at lane + w.
+// Everything is private to a wavefront (LDS operations of one wavefront execute in order: no barriers).  The staged values are loaded
+// kPF steps before the step that stores them (registers), so that a step's loads have kPF steps of FMAs to arrive.  Cells outside the
+// triangle (stale bytes) and terms outside a width's range are zeroed where they are loaded, so the FMAs carry no masks; every width
+// adds its terms in the order of vlin_acc_final (plus exact zeros): the same bits.
+constexpr int kAccW = 15, kAccPF = 4;
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void vlin_acc_final_t(McBatch B, const VLinModel* __restrict__ L, const double* __restrict__ gaps, int max_w)
+{
+    __shared__ double ring_s[4][16][80];
+    __shared__ double yrow_s[4][2][80];
+    typedef const volatile __attribute__((address_space(3))) double* lds_vp;
+    const int sq = blockIdx.y;
+    const int n = B.n[sq], ld = B.ld;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int a0 = blockIdx.x * 256 + wv * 64 + 1, a = a0 + lane;
+    if (a0 > n) return;                                        // wave-uniform
+    const bool live = a <= n;
+    const double* __restrict__ tab = B.tab + (size_t)sq * B.seq_stride;
+    const size_t ts = B.tab_stride;
+    const double* __restrict__ f5i = B.f5i + (size_t)sq * ld;
+    const double* __restrict__ f5o = B.f5o + (size_t)sq * ld;
+    const double Z = f5i[n];
+    const auto clampi = [](int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); };
+    double (*ring)[80] = ring_s[wv];
+    double m[kAccW];
+#pragma unroll
+    for (int w = 0; w < kAccW; w++) m[w] = 0.0;
+    {   // ---- M, run before a branch: r = e - w = 2 .. n-1-a-w
+        const double* __restrict__ FM1O = tab + VL_FM1O * ts;
+        const double* __restrict__ FM1 = tab + VL_FM1 * ts;
+        const int ac = clampi(a - 1, ld - 1);
+        const auto xcell = [&](int R) -> double {              // FM1o[R][a-1] where the term exists (a >= 2, R <= n-a), else 0
+            const double v = FM1O[(size_t)clampi(R, ld - 1) * ld + ac];
+            return (live & (a >= 2) & (R <= n - a)) ? v : 0.0;
+        };
+        const auto ycell = [&](int r, int c) -> double {       // FM1[r][c] inside the triangle with b = c <= n-3, else 0
+            const double v = FM1[(size_t)clampi(r, ld - 1) * ld + clampi(c, ld - 1)];
+            return ((c <= n - 3) & (r + c <= n - 1)) ? v : 0.0;
+        };
+        const int rend = n - 1 - a0;
+        if (rend >= 2) {
+#pragma unroll
+            for (int R = 3; R <= 17; R++) ring[R & 15][lane] = xcell(R);      // rows r+1 .. r+15 of the first step r = 2
+        }
+        double px[kAccPF], py[kAccPF], py2[kAccPF];                           // loaded for the steps r .. r+kPF-1
+#pragma unroll
+        for (int k = 0; k < kAccPF; k++) { px[k] = xcell(2 + k + 16); py[k] = ycell(2 + k, a0 + lane); py2[k] = ycell(2 + k, a0 + 64 + (lane < 14 ? lane : 13)); }
+        for (int r0 = 2; r0 <= rend; r0 += 16) {
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                const int r = r0 + u;                                          // r & 15 = (u + 2) & 15
+                double* const yb = yrow_s[wv][u & 1];
+                yb[lane] = py[u % kAccPF];
+                if (lane < 14) yb[64 + lane] = py2[u % kAccPF];
+                const double xnew = px[u % kAccPF];
+                // the loads of step r + kPF
+                px[u % kAccPF] = xcell(r + kAccPF + 16); py[u % kAccPF] = ycell(r + kAccPF, a0 + lane); py2[u % kAccPF] = ycell(r + kAccPF, a0 + 64 + (lane < 14 ? lane : 13));
+                const lds_vp yr = (lds_vp)(yb + lane);
+#pragma unroll
+                for (int w = 0; w < kAccW; w++) m[w] = fma(((lds_vp)&ring[(u + 3 + w) & 15][lane])[0], yr[w], m[w]);
+                ring[(u + 2) & 15][lane] = xnew;                               // row r+16 takes the slot of row r
+                asm volatile("" : "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]), "+v"(m[6]), "+v"(m[7]), "+v"(m[8]), "+v"(m[9]), "+v"(m[10]), "+v"(m[11]), "+v"(m[12]), "+v"(m[13]), "+v"(m[14]) :: "memory");   // (steps stay in order: hoisted, a block's loads spill)
+            }
+        }
+    }
+    {   // ---- M, run after the last branch: e = 2 .. a-2
+        const double* __restrict__ FMSO = tab + VL_FMSO * ts;
+        const double* __restrict__ FMS = tab + VL_FMS * ts;
+        const auto xcell = [&](int R, int k) -> double {       // FMSo[R][a0-R+k] inside the triangle, else 0
+            const int C = a0 - R + k;
+            const double v = FMSO[(size_t)clampi(R, ld - 1) * ld + clampi(C, ld - 1)];
+            return ((C >= 1) & (R + C <= n - 1)) ? v : 0.0;
+        };
+        const auto ycell = [&](int e) -> double {              // FMS[e][a-1-e] where the term exists (a >= 4, a-1-e >= 1), else 0
+            const int i = a - 1 - e;
+            const double v = FMS[(size_t)clampi(e, ld - 1) * ld + clampi(i, ld - 1)];
+            return (live & (a >= 4) & (i >= 1)) ? v : 0.0;
+        };
+        const int amax = a0 + 63 < n ? a0 + 63 : n, eend = amax - 2;
+        const int l2 = lane < 14 ? lane : 13;
+        if (eend >= 2) {
+#pragma unroll
+            for (int R = 3; R <= 17; R++) { ring[R & 15][lane] = xcell(R, lane); if (lane < 14) ring[R & 15][64 + lane] = xcell(R, 64 + l2); }
+        }
+        double qx[kAccPF], qx2[kAccPF], qy[kAccPF];
+#pragma unroll
+        for (int k = 0; k < kAccPF; k++) { qx[k] = xcell(2 + k + 16, lane); qx2[k] = xcell(2 + k + 16, 64 + l2); qy[k] = ycell(2 + k); }
+        for (int e0 = 2; e0 <= eend; e0 += 16) {
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                const int e = e0 + u;                                          // e & 15 = (u + 2) & 15
+                const double y = qy[u % kAccPF], xnew = qx[u % kAccPF], xnew2 = qx2[u % kAccPF];
+                qx[u % kAccPF] = xcell(e + kAccPF + 16, lane); qx2[u % kAccPF] = xcell(e + kAccPF + 16, 64 + l2); qy[u % kAccPF] = ycell(e + kAccPF);
+#pragma unroll
+                for (int w = 0; w < kAccW; w++) m[w] = fma(((lds_vp)&ring[(u + 3 + w) & 15][lane + w])[0], y, m[w]);
+                ring[(u + 2) & 15][lane] = xnew;                               // row e+16 takes the slot of row e
+                if (lane < 14) ring[(u + 2) & 15][64 + lane] = xnew2;
+                asm volatile("" : "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]), "+v"(m[6]), "+v"(m[7]), "+v"(m[8]), "+v"(m[9]), "+v"(m[10]), "+v"(m[11]), "+v"(m[12]), "+v"(m[13]), "+v"(m[14]) :: "memory");
+            }
+        }
+    }
+    if (!live) return;
+    // ---- E, I, the multiloop sums and H (vlin_acc_hsum) per width
+    const double* __restrict__ gl = gaps + (size_t)(2 * sq) * 32 * ld;       // suffix sums over the gap length, [g][pos]
+    const double* __restrict__ gr = gaps + (size_t)(2 * sq + 1) * 32 * ld;
+    double lam_len = 1.0, mu_len = 1.0;
+#pragma unroll
+    for (int w = 0; w < kAccW; w++) {
+        if (w >= max_w) break;
+        lam_len *= L->lam; mu_len *= L->w_mu;
+        const int b = a + w;
+        double* __restrict__ up = B.up + ((size_t)sq * ld + (a - 1)) * max_w + w;
+        if (b > n) { *up = 0.0; continue; }
+        double acc = f5i[a - 1] * f5o[b] / Z * lam_len;                                          // E
+        for (int p = a - 1; p >= 1 && p >= b - kMaxSingle; p--) acc += gl[(size_t)(b - p) * ld + p];
+        for (int q = b + 1; q <= n && q <= a + kMaxSingle; q++) acc += gr[(size_t)(q - a) * ld + q];
+        acc += m[w] * mu_len / Z;
+        acc += *up;                                                                               // H (vlin_acc_hsum)
+        *up = acc > 1.0 ? 1.0 : acc;
+    }
+}
+
 #define RH_VINST(BS, CUT)                                                                                   \
     template __global__ void vlin_inside_diag<8, BS, CUT, 0>(McBatch, const VLinModel*, int, double, int);  \
     template __global__ void vlin_outside_diag<8, BS, CUT, 0>(McBatch, const VLinModel*, int, int, int*);

@@ -73,6 +73,7 @@ __global__ void vlin_acc_prep(McBatch B, const VLinModel* __restrict__ L, const 
 __global__ void vlin_acc_gaps(McBatch B, const VLinModel* __restrict__ L, double* __restrict__ gaps, int ng, int nchunk, double* __restrict__ part);
 __global__ void vlin_acc_gsum(McBatch B, double* __restrict__ gaps, const double* __restrict__ part, int ng, int nchunk);
 __global__ void vlin_acc_gaps_wide(McBatch B, const VLinModel* __restrict__ L, double* __restrict__ gaps);
+__global__ void vlin_acc_final_t(McBatch B, const VLinModel* __restrict__ L, const double* __restrict__ gaps, int max_w);
 __global__ void vlin_acc_hsum(McBatch B, int max_w);
 __global__ void vlin_acc_gsuf(McBatch B, double* __restrict__ gaps);
 __global__ void vlin_acc_final(McBatch B, const VLinModel* __restrict__ L, const double* __restrict__ gaps, int max_w);
@@ -306,6 +307,7 @@ struct rh_ctx {
     int strip_w = 8;               // wavefronts per strip workgroup (RH_STRIP_W = 4 | 8)
     int co_cut_min = 0, co_cut_max = 0;   // smallest / largest cut (length of s1) of the two-molecule batch: bounds of the groups its sweeps launch
     int co_window = 1;             // two-molecule sweeps launch only the groups around the cut (RH_CO_WINDOW=0: all groups, most of which return at once)
+    int acc_final_t = 1;           // Vienna-BL accessibility: vlin_acc_final_t (one thread per letter, all widths; RH_ACC_FINAL_T=0: one thread per letter and width)
     int acc_wide = 1;              // Vienna-BL accessibility: vlin_acc_gaps_wide for the gap lengths 3..30 (RH_ACC_WIDE=0: vlin_acc_gaps for all)
     int strip_xcd = 1;             // groups of one sequence consecutive on one XCD (RH_STRIP_XCD=0: sequence-major launch order only)
     double* d_wT = nullptr;        // transposed, zero-padded single-branch weights wT[l1][t+1] of the strip kernels
@@ -898,7 +900,10 @@ int launch_mc_vlin(rh_ctx* c, int pin, int phase, bool co)
     } else
         hipLaunchKernelGGL(vlin_acc_gaps, dim3((B.nmax + 255) / 256, B.ns, 60), dim3(256), 0, st, B, c->d_vlin, (double*)c->d_gaps, 30, 1, (double*)nullptr);
     hipLaunchKernelGGL(vlin_acc_gsuf, dim3((B.nmax + 255) / 256, B.ns, 2), dim3(256), 0, st, B, (double*)c->d_gaps);
-    hipLaunchKernelGGL(vlin_acc_final, dim3((B.nmax + 255) / 256, B.ns, c->max_w), dim3(256), 0, st, B, c->d_vlin, (const double*)c->d_gaps, c->max_w);
+    if (c->acc_final_t && c->max_w <= 15)   // one thread per letter, all widths (the operands of the fifteen widths overlap)
+        hipLaunchKernelGGL(vlin_acc_final_t, dim3((B.nmax + 255) / 256, B.ns), dim3(256), 0, st, B, c->d_vlin, (const double*)c->d_gaps, c->max_w);
+    else
+        hipLaunchKernelGGL(vlin_acc_final, dim3((B.nmax + 255) / 256, B.ns, c->max_w), dim3(256), 0, st, B, c->d_vlin, (const double*)c->d_gaps, c->max_w);
     c->n_launch[1] += 6;
     return RH_OK;
 }
@@ -1478,7 +1483,7 @@ size_t shape_key(const rh_ctx* c, int which)
         for (size_t v : {(size_t)B.ns, (size_t)B.nmax, (size_t)B.ld, (size_t)B.lds, (size_t)B.tab, (size_t)B.seq, (size_t)B.n,
                          (size_t)B.f5i, (size_t)B.bp, (size_t)B.up, (size_t)c->d_bad, (size_t)c->d_mclogz, (size_t)c->lin_w, (size_t)c->lin_w_in,
                          (size_t)c->lin_bs, (size_t)B.tri_stride, (size_t)c->far_mfma, (size_t)c->max_w, (size_t)c->d_gaps,
-                         (size_t)c->d_hplen, (size_t)B.allow, (size_t)B.pk, (size_t)c->far_pk, (size_t)B.rowp, (size_t)c->lookahead, (size_t)c->strip, (size_t)c->d_wT, (size_t)c->strip_w, (size_t)c->strip_xcd, (size_t)(c->far2 + 2), (size_t)c->acc_wide, (size_t)c->co_window, (size_t)c->co_cut_min, (size_t)c->co_cut_max, (size_t)c->d_vlin})
+                         (size_t)c->d_hplen, (size_t)B.allow, (size_t)B.pk, (size_t)c->far_pk, (size_t)B.rowp, (size_t)c->lookahead, (size_t)c->strip, (size_t)c->d_wT, (size_t)c->strip_w, (size_t)c->strip_xcd, (size_t)(c->far2 + 2), (size_t)c->acc_wide, (size_t)c->acc_final_t, (size_t)c->co_window, (size_t)c->co_cut_min, (size_t)c->co_cut_max, (size_t)c->d_vlin})
             h = mix(h, v);
     } else {
         const DxLinBatch& X = c->dxl;
@@ -1860,6 +1865,7 @@ static rh_ctx* create_ctx(int device, int model, const char* param_file, const c
     if (const char* e = std::getenv("RH_FAR2")) c->far2 = std::atoi(e);
     if (const char* e = std::getenv("RH_STRIP_XCD")) c->strip_xcd = std::atoi(e);
     if (const char* e = std::getenv("RH_ACC_WIDE")) c->acc_wide = std::atoi(e);
+    if (const char* e = std::getenv("RH_ACC_FINAL_T")) c->acc_final_t = std::atoi(e);
     if (const char* e = std::getenv("RH_CO_WINDOW")) c->co_window = std::atoi(e);
     if (const char* e = std::getenv("RH_SCALE_LADDER")) c->scale_ladder = std::atoi(e);
     if (const char* e = std::getenv("RH_CO_SEED")) c->co_seed = std::atoi(e);

@@ -636,6 +636,15 @@ def test_vienna_bl_accessibility_organisations_agree(hotlib, monkeypatch):
         for k, s in (("up1", s1), ("up2", s2)):
             assert x[k].shape == y[k].shape and x[k].shape[0] == len(s)
             assert np.abs(x[k] - y[k]).max() <= 1e-12, (k, len(s))
+    # the last step, E + I + multiloop streams per (letter, width): one thread per letter and width (RH_ACC_FINAL_T=0) or one thread
+    # per letter with the operands of its fifteen widths staged in LDS -- the same terms in the same order: the same bits
+    monkeypatch.setenv("RH_ACC_FINAL_T", "0")
+    try:
+        c0 = run("1")
+    finally:
+        monkeypatch.delenv("RH_ACC_FINAL_T")
+    for x, y in zip(c0, b):
+        assert np.array_equal(x["up1"], y["up1"]) and np.array_equal(x["up2"], y["up2"])
 
 
 def test_vienna_bl_two_molecule_organisations_agree(hotlib, monkeypatch):
