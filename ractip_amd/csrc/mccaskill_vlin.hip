@@ -1337,7 +1337,7 @@ __global__ __launch_bounds__(256) void vlin_acc_gsum(McBatch B, double* __restri
 __device__ const unsigned char kGapJob[64] = {   // g + 32 c: lane's own gap length and run of other gaps o = 8c .. 8c+7
     3, 35, 67, 99, 4, 36, 68, 100, 5, 37, 69, 101, 6, 38, 70, 102, 7, 39, 71, 8, 40, 72, 9, 41, 73, 10, 42, 74, 11, 43, 75, 12, 44, 76, 13, 45, 77, 14, 46, 78, 15, 47, 16, 48, 17, 49, 18, 50, 19, 51, 20, 52, 21, 53, 22, 54, 23, 24, 25, 26, 27, 28, 29, 30 };
 #ifndef RH_ACCW_PF
-#define RH_ACCW_PF 2
+#define RH_ACCW_PF 4
 #endif
 __global__ __launch_bounds__(256) void vlin_acc_gaps_wide(McBatch B, const VLinModel* __restrict__ L, double* __restrict__ gaps)
 {
@@ -1384,7 +1384,8 @@ __global__ __launch_bounds__(256) void vlin_acc_gaps_wide(McBatch B, const VLinM
     const bool feeder = lane < 2 * NO;
     const double* __restrict__ ftab = tab + (lane < NO ? VL_FCOX : VL_FCOB) * ts;
     double* const fdst = (lane < NO ? ring : ringb) + (lane & (NO - 1));
-    double fv = 0.0;
+    double fv = 0.0;     // (raw: selected where it is stored, one block after its load -- selected at once, the load is waited for at once)
+    bool fok = false;
     const int kl = right ? pos - 1 - g : pos + 1 + g;        // inner 3' letter l (right) resp. inner 5' letter k (left)
     const int rmax = right ? kl - 2 : n - 1 - kl;            // inner spans 0..rmax are interior
     const int rl = right ? pos - 6 : n - pos - 5;            // the largest of them in this wavefront (g = 3)
@@ -1420,12 +1421,11 @@ __global__ __launch_bounds__(256) void vlin_acc_gaps_wide(McBatch B, const VLinM
         if (feeder) {
             if (r0 > 0) {   // spans r0+48 .. r0+55 take the place of r0-8 .. r0-1
                 double* const d = fdst + (r0m == 0 ? RN - NO : r0m - NO);
-                d[0] = fv; d[RN] = fv;
+                const double v = fok ? fv : 0.0;
+                d[0] = v; d[RN] = v;
             }
-            bool ok;
-            const unsigned ix = outer_ix(r0 + RN + (lane & (NO - 1)), &ok);
-            const double v = ftab[ix];
-            fv = ok ? v : 0.0;
+            const unsigned ix = outer_ix(r0 + RN + (lane & (NO - 1)), &fok);
+            fv = ftab[ix];
         }
         int ba = r0m + c_a, bb = r0m + c_b;
         ba = ba >= RN ? ba - RN : ba; bb = bb >= RN ? bb - RN : bb;
@@ -1433,21 +1433,19 @@ __global__ __launch_bounds__(256) void vlin_acc_gaps_wide(McBatch B, const VLinM
 #pragma unroll
         for (int u = 0; u < NO; u++) {
             const int r = r0 + u;
-            const double xa0 = xa[u % PF], xb0 = xb[u % PF];
-            asm volatile("" : "+v"(xa[u % PF]), "+v"(xb[u % PF]));
-            // loads of step r+PF
-            { const unsigned o2 = off + stride8; off = o2 < offmax ? o2 : offmax; }
-            xa[u % PF] = *(const double*)(tab8 + off); xb[u % PF] = *(const double*)(tab8 + (off + d_b));
             const double nv = rpa[u + 2 + NO];                // span r+2+g+8c+8: other gap 8c+7 of the next step
             const double bv = rpb[u + 2];                     // bulge: own gap g, other gap 0, outer span r+2+g
             if (r <= last) {
                 double s = 0.0;
 #pragma unroll
                 for (int oo = 0; oo < NO; oo++) s = fma(wr[oo], win[(u + oo) % NO], s);
-                acc = fma(xa0, s, acc);
-                accb = fma(xb0, bv, accb);
+                acc = fma(xa[u % PF], s, acc);
+                accb = fma(xb[u % PF], bv, accb);
             }
             win[u % NO] = nv;
+            // loads of step r+PF, into the slots this step has just read (behind the FMAs: in front of them the compiler copies the operands)
+            { const unsigned o2 = off + stride8; off = o2 < offmax ? o2 : offmax; }
+            xa[u % PF] = *(const double*)(tab8 + off); xb[u % PF] = *(const double*)(tab8 + (off + d_b));
             asm volatile("" : "+v"(acc));   // (a step's FMAs stay in front of the next step's volatile ring reads)
         }
         r0m = r0m + NO == RN ? 0 : r0m + NO;

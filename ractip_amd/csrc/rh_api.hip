@@ -894,7 +894,8 @@ int launch_mc_vlin(rh_ctx* c, int pin, int phase, bool co)
         // spans in 8 chunks; 3..30: the lanes over the gap length (vlin_acc_gaps_wide)
         constexpr int NG = 2, NCH = 8;
         double* part = (double*)c->d_gaps + (size_t)2 * 32 * B.ld * B.ns;
-        hipLaunchKernelGGL(vlin_acc_gaps, dim3((B.nmax + 255) / 256, B.ns, 2 * NG * NCH), dim3(256), 0, st, B, c->d_vlin, (double*)c->d_gaps, NG, NCH, part);
+        // (one wavefront per workgroup: the loop runs to the longest inner span of the workgroup's letters, which differ by the block width)
+        hipLaunchKernelGGL(vlin_acc_gaps, dim3((B.nmax + 63) / 64, B.ns, 2 * NG * NCH), dim3(64), 0, st, B, c->d_vlin, (double*)c->d_gaps, NG, NCH, part);
         hipLaunchKernelGGL(vlin_acc_gsum, dim3((B.nmax + 255) / 256, B.ns, 2 * NG), dim3(256), 0, st, B, (double*)c->d_gaps, (const double*)part, NG, NCH);
         hipLaunchKernelGGL(vlin_acc_gaps_wide, dim3((B.nmax + 3) / 4, B.ns, 2), dim3(256), 0, st, B, c->d_vlin, (double*)c->d_gaps);
     } else
