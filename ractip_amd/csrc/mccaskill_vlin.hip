@@ -283,18 +283,23 @@ __global__ void vlin_init(McBatch B, int* __restrict__ bad)
 // both in scaled linear space with the same lam: a cell whose letters all lie on one strand has the value it has in that
 // molecule folded alone -- the same recurrences over the same letters, and at a strand end the neighbour letter is "none" in
 // both (FCX differs at the strand ends, where it looks across the gap, but only loops whose side crosses the gap read it there,
-// and those are excluded).  One launch copies the seven inside tables of both triangles.
+// and those are excluded).  One launch copies four inside tables of both triangles: FCA, FM1, FMS and FM, the multiloop and exterior
+// pieces a cell with letters on both strands is built from.  FC, FCX and FCB of a one-strand cell are never used by such a cell: the
+// inner pair of its interior loops, bulges and stacks has letters on both strands too (each side of the loop stays on its strand:
+// the per-lane limits l1max / l2max, and the strand mask of the staged rows), and every operand that might be one of them is
+// discarded by a select, never by a multiplication with 0.
 __global__ __launch_bounds__(256) void vlin_co_seed(McBatch B, McBatch S)
 {
     const int p = blockIdx.y, d = blockIdx.x;
     const int n = B.n[p], n1 = B.cut[p];
-    const int tabs[7] = {VL_FC, VL_FCX, VL_FCB, VL_FCA, VL_FM1, VL_FMS, VL_FM};
+    constexpr int NT = 4;
+    const int tabs[NT] = {VL_FCA, VL_FM1, VL_FMS, VL_FM};
     double* __restrict__ dst = B.tab + (size_t)p * B.seq_stride + (size_t)d * B.ld;
     for (int strand = 0; strand < 2; strand++) {
         const int cells = (strand ? n - n1 : n1) - 1 - d, off = strand ? n1 : 0;
         if (cells < 1) continue;
         const double* __restrict__ src = S.tab + (size_t)(2 * p + strand) * S.seq_stride + (size_t)d * S.ld;
-        for (int t = 0; t < 7; t++)
+        for (int t = 0; t < NT; t++)
             for (int i = 1 + threadIdx.x; i <= cells; i += 256) dst[tabs[t] * B.tab_stride + off + i] = src[tabs[t] * S.tab_stride + i];
     }
 }
