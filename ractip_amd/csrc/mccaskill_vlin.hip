@@ -321,11 +321,13 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) __attribute__((amdgpu_wave
     block_map_vl(pin, &sq, &slot);
     double* __restrict__ rowp = B.rowp + (size_t)sq * 3 * B.ld;   // look-ahead sums of the next diagonal
     if (sq >= B.ns) return;
-    const int n = B.n[sq];
+    // length and cut in ONE scalar round trip (behind the early return on the length, the cut was a second dependent one in front of
+    // every workgroup); CUT = false: one molecule per sequence, every gap test folds away
+    int n = B.n[sq], cut = CUT ? B.cut[sq] : 0;
+    if (CUT) asm volatile("" : "+s"(n), "+s"(cut));
     if (d > n - 1) return;
     const int ncell = n - 1 - d > 0 ? n - 1 - d : 0;
     const int ngroup = (ncell + 63) >> 6;
-    const int cut = CUT ? B.cut[sq] : 0;   // CUT = false: one molecule per sequence, every gap test folds away
     if (!window_slot_vl<CUT>(pin, ngroup, &slot)) return;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int ld = B.ld;
@@ -699,13 +701,13 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) __attribute__((amdgpu_wave
     block_map_vl(pin, &sq, &slot);
     if (sq >= B.ns) return;
     double* __restrict__ rowp = B.rowp + (size_t)sq * 4 * B.ld;   // look-ahead sums of the next diagonal
-    const int n = B.n[sq];
+    int n = B.n[sq], cut = CUT ? B.cut[sq] : 0;   // one scalar round trip (see vlin_inside_diag); CUT = false: every gap test folds away
+    if (CUT) asm volatile("" : "+s"(n), "+s"(cut));
     const int ncell = n - 1 - d > 0 ? n - 1 - d : 0;
     const int d1 = d - 1;
     const int ncell1 = MODE == 1 && d1 >= 0 ? n - 1 - d1 : 0;     // diagonal d-1 has one more cell
     if (ncell < 1 && ncell1 < 1) return;
     const int ngroup = ((ncell > ncell1 ? ncell : ncell1) + 63) >> 6;
-    const int cut = CUT ? B.cut[sq] : 0;   // CUT = false: one molecule per sequence, every gap test folds away
     if (!window_slot_vl<CUT>(pin, ngroup, &slot)) return;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int ld = B.ld;
