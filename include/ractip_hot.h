@@ -211,16 +211,38 @@ int rh_set_overlap(rh_ctx* ctx, int on);
  * leaves its range; this is how the fast path keeps that guarantee.)
  * which = 2: the sequence indices that left the range with the default scale exponent and were recomputed on the linear kernels
  * with another one (CONTRAfold model: 0.45, 1.5 or 0 per unit span instead of 0.12) -- they are NOT in the list of which = 0.
- * When one exponent held more than half of a batch of at least eight sequences, the next rh_batch_compute starts on it.
+ * With rh_set_scale_memory(ctx, 1): when one exponent held more than half of a batch of at least eight sequences, the next
+ * rh_batch_compute starts on it.
  * Vienna-BL model: the whole batch is run again with another exponent (0.7, 1.8 or 0 instead of 0.28); which = 2 then lists the
  * sequences that made it necessary. */
 int rh_batch_fallbacks(rh_ctx* ctx, int which, int* out, int cap);
+
+/* Scale-exponent memory (default OFF).  Off: every rh_batch_compute starts on the default exponent, so a sequence's result bits
+ * depend on its own letters only (the reference, src/ractip.cpp:195-245, is deterministic per input) and sharded + gathered
+ * results equal single-context results bit for bit whatever each context computed before.  On: a stream of batches of one kind
+ * (e.g. long, very stable RNAs) pays the failed first pass once instead of once per batch; results then differ by a few ulp
+ * with the context's history, which voids the bit-for-bit shard guarantee.  Turning it off also forgets the remembered exponent. */
+int rh_set_scale_memory(rh_ctx* ctx, int on);
 
 /* Device pointers of the last batch (for callers that keep results on the GPU):
  * bp tables [2*npairs][tri_stride] (sequence 2p = s1 of pair p, 2p+1 = s2),
  * hp tables [npairs][hp_stride]. */
 int rh_batch_device_views(rh_ctx* ctx, const double** bp, size_t* tri_stride,
                           const double** hp, size_t* hp_stride, int* hp_ld);
+
+/* ---- loader inspection (host only, no GPU, no context) ----
+ * What the parameter loader holds after binding its sources, for checks of the binding itself (tests/test_bl_cells.py,
+ * tests/test_vienna_par.py); not needed by a caller of the probability path.  Return 0, -1 (bad index / NULL) or
+ * RH_ERR_PARAM (-4: the files could not be loaded).
+ * rh_debug_vienna_cell: energy in the file's 10 cal/mol units of one cell of table 0 = stack[i][j], 1 = int11[i][j][k][l],
+ * 2 = int21[i][j][k][l][m], 3 = int22[i][j][k][l][m][n] (pair types 0..7, nucleotides 0..4) of a flat BL* dump or
+ * ViennaRNA parameter file (the conventions of src/boltzmann_param.c:5908-5971).
+ * rh_debug_vienna_value: one entry (log Boltzmann weight) of the model built from (defaults_file, use_bl_param, bl_path,
+ * param_file, semantics) in the install order of src/ractip.cpp:1563-1567; `table` codes 10..27 are listed next to the
+ * function in ractip_amd/csrc/vienna_loader.cpp. */
+int rh_debug_vienna_cell(const char* param_file, int table, int i, int j, int k, int l, int m, int n, double* energy);
+int rh_debug_vienna_value(const char* defaults_file, int use_bl_param, const char* bl_path, const char* param_file, int semantics,
+                          int table, int i, int j, int k, int l, double* out);
 
 /* ---- source-compatible pf_duplex surface (src/pf_duplex.h:25-28) ----
  * double pf_duplex(const char*, const char*); extern double** pr_duplex; void free_pf_duplex();

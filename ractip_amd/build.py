@@ -15,6 +15,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 HOT_SOURCES = ["rh_api.hip", "mccaskill.hip", "mccaskill_lin.hip", "mccaskill_far.hip", "mccaskill_strip.hip", "duplex.hip", "duplex_lin.hip", "duplex_vienna.hip", "duplex_vlin.hip", "mccaskill_vienna.hip", "mccaskill_vlin.hip", "param_loader.cpp", "vienna_loader.cpp"]
 HOT_LIB = os.path.join(PKG, "libractip_hot.so")
+LAST_BUILD = {"compiled": [], "reused": [], "linked": False}   # what the last build_hot() did (reported by __graft_entry__.build)
 
 
 def _hipcc():
@@ -38,10 +39,13 @@ def build_hot(force=False, verbose=True):
     hdrs = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
     hdrs.append(os.path.join(ROOT, "include", "ractip_hot.h"))
     if not force and not _stale(HOT_LIB, srcs + hdrs):
+        LAST_BUILD.update(compiled=[], reused=[os.path.basename(x) for x in srcs], linked=False)
         return HOT_LIB
     objdir = os.path.join(PKG, "build")
     os.makedirs(objdir, exist_ok=True)
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+    compiled, reused = [], []
 
     def compile_one(src):
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
@@ -50,6 +54,9 @@ def build_hot(force=False, verbose=True):
             if verbose:
                 print("[ractip_amd.build]", " ".join(cmd), flush=True)
             subprocess.check_call(cmd)
+            compiled.append(os.path.basename(src))
+        else:
+            reused.append(os.path.basename(src))
         return obj
 
     with ThreadPoolExecutor(max_workers=min(6, len(srcs))) as pool:
@@ -58,6 +65,7 @@ def build_hot(force=False, verbose=True):
     if verbose:
         print("[ractip_amd.build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    LAST_BUILD.update(compiled=sorted(compiled), reused=sorted(reused), linked=True)
     return HOT_LIB
 
 

@@ -262,6 +262,8 @@ struct rh_ctx {
     LinModel* d_lin_r[kRungs] = {nullptr, nullptr, nullptr};
     double* d_wT_r[kRungs] = {nullptr, nullptr, nullptr};
     int scale_ladder = 1;                      // RH_SCALE_LADDER=0: flagged problems go straight to the log-space kernels
+    int scale_memory = 0;                      // rh_set_scale_memory / RH_SCALE_MEMORY=1: the next batch starts on the exponent most of the last one needed
+                                               // (off by default: a sequence's bits then depend on its own letters only, never on the context's history)
     // the default exponent's model (what h_lin / d_lin / d_wT hold unless a pass runs on a rung) and the exponent the NEXT batch starts
     // with: -1 = default, k = rung k -- the one that held more than half of the last batch (a stream of structured RNAs does not pay
     // a failed first pass per batch)
@@ -302,7 +304,7 @@ struct rh_ctx {
                                    // (MODE 1/2), 0 = one full launch per diagonal; RH_LOOKAHEAD
     int strip = 3;                 // CONTRAfold linear path: KD = 8 diagonals per launch (mccaskill_strip.hip) with the banded near/far split;
                                    // RH_STRIP=0: the per-diagonal-pair kernels of mccaskill_lin.hip.  Bit 0 = inside sweep, bit 1 = outside sweep
-    int far2 = -1;                 // two-level block products: -1 = by size (nmax >= 768), 0 / 1 forced (RH_FAR2)
+    int far2 = -1;                 // two-level block products: -1 = by size (sequences of n >= 384), 0 / 1 forced (RH_FAR2)
     int far2_next = -1;            // launch-sequence state of far_outside_step
     int strip_w = 8;               // wavefronts per strip workgroup (RH_STRIP_W = 4 | 8)
     int co_cut_min = 0, co_cut_max = 0;   // smallest / largest cut (length of s1) of the two-molecule batch: bounds of the groups its sweeps launch
@@ -1477,14 +1479,16 @@ size_t shape_key(const rh_ctx* c, int which)
         for (size_t v : {(size_t)B.ns, (size_t)B.nmax, (size_t)B.ld, (size_t)B.lds, (size_t)B.tab, (size_t)B.seq, (size_t)B.n, (size_t)B.f5i,
                          (size_t)B.bp, (size_t)c->d_cobad, (size_t)c->lin_bs, (size_t)B.tri_stride, (size_t)c->dx.hp, (size_t)c->dx.logz,
                          (size_t)c->dx.ldd, (size_t)c->dx.tab_stride, (size_t)c->dx.n1max, (size_t)c->dx.n2max, (size_t)B.allow, (size_t)B.pk,
-                         (size_t)c->far_pk, (size_t)B.rowp, (size_t)c->lookahead, (size_t)B.seeded, (size_t)c->mc.tab, (size_t)c->mc.ld, (size_t)c->d_vlin})
+                         (size_t)c->far_pk, (size_t)B.rowp, (size_t)c->lookahead, (size_t)B.seeded, (size_t)c->mc.tab, (size_t)c->mc.ld, (size_t)c->d_vlin,
+                         // the windowed grid and its pin offset are baked into the captured launches (launch_mc_vlin)
+                         (size_t)c->co_window, (size_t)(c->co_cut_min + 1), (size_t)(c->co_cut_max + 1)})
             h = mix(h, v);
     } else if (which <= 1) {
         const McBatch& B = c->mc;
         for (size_t v : {(size_t)B.ns, (size_t)B.nmax, (size_t)B.ld, (size_t)B.lds, (size_t)B.tab, (size_t)B.seq, (size_t)B.n,
                          (size_t)B.f5i, (size_t)B.bp, (size_t)B.up, (size_t)c->d_bad, (size_t)c->d_mclogz, (size_t)c->lin_w, (size_t)c->lin_w_in,
                          (size_t)c->lin_bs, (size_t)B.tri_stride, (size_t)c->far_mfma, (size_t)c->max_w, (size_t)c->d_gaps,
-                         (size_t)c->d_hplen, (size_t)B.allow, (size_t)B.pk, (size_t)c->far_pk, (size_t)B.rowp, (size_t)c->lookahead, (size_t)c->strip, (size_t)c->d_wT, (size_t)c->strip_w, (size_t)c->strip_xcd, (size_t)(c->far2 + 2), (size_t)c->acc_wide, (size_t)c->acc_final_t, (size_t)c->co_window, (size_t)c->co_cut_min, (size_t)c->co_cut_max, (size_t)c->d_vlin})
+                         (size_t)c->d_hplen, (size_t)B.allow, (size_t)B.pk, (size_t)c->far_pk, (size_t)B.rowp, (size_t)c->lookahead, (size_t)c->strip, (size_t)c->d_wT, (size_t)c->strip_w, (size_t)c->strip_xcd, (size_t)(c->far2 + 2), (size_t)c->acc_wide, (size_t)c->acc_final_t, (size_t)c->d_vlin})
             h = mix(h, v);
     } else {
         const DxLinBatch& X = c->dxl;
@@ -1620,7 +1624,7 @@ int compute_once(rh_ctx* c)
                 c->tables_dirty = true;
                 if ((rc = retry_mc_lin_rungs(c, &c->fallback_mc))) return rc;   // another exponent first; what is left goes to log space
                 for (int q = 0; q <= rh_ctx::kRungs; q++)   // more than half of the batch on one exponent: the next batch starts there
-                    if (c->mc.ns >= 8 && 2 * c->rescued_by[q] > c->mc.ns) c->lin_primary = q - 1;   // (a batch, not a single call)
+                    if (c->scale_memory && c->mc.ns >= 8 && 2 * c->rescued_by[q] > c->mc.ns) c->lin_primary = q - 1;   // (a batch, not a single call)
                 if (c->fallback_mc.empty()) { }
                 else if (2 * c->fallback_mc.size() > (size_t)c->mc.ns) need_log = true;   // most of the batch: redo it whole
                 else if ((rc = recompute_mc_subset_log(c, c->fallback_mc))) return rc;
@@ -1754,7 +1758,7 @@ int compute(rh_ctx* c)
                 c->flagged_mc.erase(std::unique(c->flagged_mc.begin(), c->flagged_mc.end()), c->flagged_mc.end());
                 if (!c->went_log) {   // (the last attempt may still have ended in log space)
                     c->rescaled_mc = c->flagged_mc;
-                    if (c->mc.ns >= 8) c->vlin_primary = order[a];   // a batch, not a single call: the next one starts here
+                    if (c->scale_memory && c->mc.ns >= 8) c->vlin_primary = order[a];   // a batch, not a single call: the next one starts here
                 }
             }
             break;
@@ -1869,6 +1873,7 @@ static rh_ctx* create_ctx(int device, int model, const char* param_file, const c
     if (const char* e = std::getenv("RH_ACC_FINAL_T")) c->acc_final_t = std::atoi(e);
     if (const char* e = std::getenv("RH_CO_WINDOW")) c->co_window = std::atoi(e);
     if (const char* e = std::getenv("RH_SCALE_LADDER")) c->scale_ladder = std::atoi(e);
+    if (const char* e = std::getenv("RH_SCALE_MEMORY")) c->scale_memory = std::atoi(e);
     if (const char* e = std::getenv("RH_CO_SEED")) c->co_seed = std::atoi(e);
     if (const char* e = std::getenv("RH_DX_W")) c->dx_w = std::atoi(e);
     if (const char* e = std::getenv("RH_DX_QUAD")) c->dx_quad = std::atoi(e) != 0;
@@ -2274,8 +2279,17 @@ int rh_batch_fallbacks(rh_ctx* c, int which, int* out, int cap)
     if (!c || which < 0 || which > 2) return RH_ERR_ARG;
     if (!c->computed) return fail(c, RH_ERR_ARG, "no computed batch");
     const std::vector<int>& F = which == 2 ? c->rescaled_mc : (which ? c->fallback_dx : c->fallback_mc);
+    if (cap > 0 && !out) return fail(c, RH_ERR_ARG, "rh_batch_fallbacks: out is NULL with cap > 0");
     for (int k = 0; k < (int)F.size() && k < cap; k++) out[k] = F[k];
     return (int)F.size();
+}
+
+int rh_set_scale_memory(rh_ctx* c, int on)
+{
+    if (!c) return RH_ERR_ARG;
+    c->scale_memory = on != 0;
+    if (!on) { c->lin_primary = -1; c->vlin_primary = -1; }
+    return RH_OK;
 }
 
 int rh_set_overlap(rh_ctx* c, int on)

@@ -36,7 +36,14 @@ struct ViennaTables : ViennaInts {
     std::vector<std::pair<std::string, int>> tetra, tri, hexa;
     bool special_total;
     bool v20;   // a v2.0 parameter file was among the sources
+    unsigned provided;   // bit k: table kCore[k] was supplied by at least one source (completeness check of load_vienna_dx_ex)
 };
+// the tables every kernel family reads under either semantics; the 2.x-only mismatch tables and the special hairpins may be
+// absent (then zero / none: DESIGN.md section 2)
+const char* const kCore[] = {"stack", "mismatch_interior", "mismatch_hairpin", "dangle5", "dangle3", "int11", "int21", "int22",
+                             "bulge", "interior", "hairpin", "ML_params", "NINIO"};
+constexpr int kNCore = sizeof(kCore) / sizeof(kCore[0]);
+void mark(ViennaTables* T, const char* core) { for (int k = 0; k < kNCore; k++) if (!std::strcmp(kCore[k], core)) T->provided |= 1u << k; }
 
 void default_tables(ViennaTables* T)
 {
@@ -45,7 +52,7 @@ void default_tables(ViennaTables* T)
     T->lxc = 107.856;        // lxc37
     T->max_ninio = 300;
     T->tetra.clear(); T->tri.clear(); T->hexa.clear();
-    T->special_total = false; T->v20 = false;
+    T->special_total = false; T->v20 = false; T->provided = 0;
 }
 
 bool fail_msg(char* err, int errlen, const char* fmt, const char* a, const char* b = "")
@@ -90,6 +97,12 @@ bool read_flat(const char* path, ViennaTables* T, char* err, int errlen)
         {"int21_37", 6125}, {"int22_37", 12544}, {"bulge37", 31}, {"internal_loop37", 31}, {"hairpin37", 31}, {"MLparams", 4}, {"ninio", 2}};
     for (auto& t : sizes)
         if (tab.count(t.name) && tab[t.name].size() != t.n) return fail_msg(err, errlen, "table %s of wrong size in %s", t.name, path);
+    {
+        const struct { const char* flat; const char* core; } names[] = {{"stack37", "stack"}, {"mismatchI37", "mismatch_interior"}, {"mismatchH37", "mismatch_hairpin"},
+            {"dangle5_37", "dangle5"}, {"dangle3_37", "dangle3"}, {"int11_37", "int11"}, {"int21_37", "int21"}, {"int22_37", "int22"}, {"bulge37", "bulge"},
+            {"internal_loop37", "interior"}, {"hairpin37", "hairpin"}, {"MLparams", "ML_params"}, {"ninio", "NINIO"}};
+        for (auto& nm : names) if (tab.count(nm.flat)) mark(T, nm.core);
+    }
     auto mism = [&](const char* name, int (*dst)[5][5]) {
         if (!tab.count(name)) return;
         const std::vector<int>& v = tab[name];
@@ -264,6 +277,13 @@ bool read_par(const char* path, const std::string& text_in, ViennaTables* T, cha
         }
     }
     if (!ok) return false;
+    {
+        const struct { const char* a; const char* b; const char* core; } names[] = {{"stack", "stack_energies", "stack"},
+            {"mismatch_interior", "", "mismatch_interior"}, {"mismatch_hairpin", "", "mismatch_hairpin"}, {"dangle5", "", "dangle5"}, {"dangle3", "", "dangle3"},
+            {"int11", "int11_energies", "int11"}, {"int21", "int21_energies", "int21"}, {"int22", "int22_energies", "int22"}, {"bulge", "", "bulge"},
+            {"interior", "internal_loop", "interior"}, {"hairpin", "", "hairpin"}, {"ML_params", "", "ML_params"}, {"NINIO", "", "NINIO"}};
+        for (auto& nm : names) if (sec.count(nm.a) || sec.count(nm.b)) mark(T, nm.core);
+    }
     if (loops.count("Tetraloops")) T->tetra = loops["Tetraloops"];
     if (loops.count("Triloops")) T->tri = loops["Triloops"];
     if (loops.count("Hexaloops")) T->hexa = loops["Hexaloops"];
@@ -420,6 +440,12 @@ bool load_vienna_dx_ex(const char* defaults_file, bool use_bl, const char* bl_pa
     const bool v20_before = T->v20;
     if (ok && param_file) ok = read_any(param_file, T, err, errlen);
     (void)v20_before;
+    if (ok && T->provided != (1u << kNCore) - 1) {   // a truncated or edited file must not leave a table at zero energy silently
+        std::string missing;
+        for (int k = 0; k < kNCore; k++) if (!(T->provided >> k & 1)) missing += std::string(missing.empty() ? "" : ", ") + kCore[k];
+        snprintf(err, errlen, "Vienna parameter tables missing from every source (defaults, BL*, -P): %s", missing.c_str());
+        ok = false;
+    }
     if (ok) {
         if (semantics != 0 && semantics != kViennaSem18 && semantics != kViennaSem20) {
             snprintf(err, errlen, "unknown Vienna semantics %d", semantics);

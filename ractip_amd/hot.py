@@ -19,7 +19,8 @@ EXPORTS = [
     "rh_batch_upload", "rh_batch_compute", "rh_batch_results", "rh_batch_candidates",
     "rh_batch_timings", "rh_batch_device_views", "rh_batch_logz", "rh_batch_candidates_all", "rh_batch_layout",
     "rh_batch_results_all", "rh_set_max_w", "rh_get_max_w", "rh_set_overlap", "rh_batch_kernels", "rh_set_hybrid", "rh_last_hybrid_path", "rh_fold_constrained", "rh_cofold_constrained",
-    "rh_host_alloc", "rh_host_free", "rh_batch_fallbacks", "rh_create_vienna", "rh_vienna_semantics",
+    "rh_host_alloc", "rh_host_free", "rh_batch_fallbacks", "rh_create_vienna", "rh_vienna_semantics", "rh_set_scale_memory",
+    "rh_debug_vienna_cell", "rh_debug_vienna_value",   # loader inspection (host only; used by the CPU tests of the loader)
 ]
 
 
@@ -57,6 +58,8 @@ def load_library():
     L.rh_set_mode.restype = ci
     L.rh_last_path.argtypes = [vp]
     L.rh_set_overlap.argtypes = [vp, ci]
+    L.rh_set_scale_memory.argtypes = [vp, ci]
+    L.rh_set_scale_memory.restype = ci
     L.rh_last_hybrid_path.argtypes = [vp]
     L.rh_last_hybrid_path.restype = ci
     L.rh_set_hybrid.argtypes = [vp, ci]
@@ -282,7 +285,8 @@ class Context:
         return out
 
     def pinned_empty(self, shape, dtype=np.float64):
-        """numpy array over page-locked host memory (rh_host_alloc); freed with the context."""
+        """numpy array over page-locked host memory (rh_host_alloc).  The memory belongs to the context: it is released by
+        pinned_free(array) or close(), and the array must not be touched afterwards."""
         nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
         ptr = self.L.rh_host_alloc(self.h, max(nbytes, 8))
         if not ptr:
@@ -290,6 +294,14 @@ class Context:
         self._pinned = getattr(self, "_pinned", []) + [ptr]
         buf = (ctypes.c_char * max(nbytes, 8)).from_address(ptr)
         return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def pinned_free(self, arr):
+        """Release one pinned_empty array now (rh_host_free) instead of with the context."""
+        ptr = arr.ctypes.data
+        pinned = getattr(self, "_pinned", [])
+        if ptr in pinned:
+            pinned.remove(ptr)
+            self.L.rh_host_free(self.h, ptr)
 
     def batch_results_all_into(self, bufs=None):
         """Dense results of all pairs in the padded device layout (rh_batch_layout), three copies, no unpacking.  `bufs` =
@@ -300,6 +312,8 @@ class Context:
         np_ = len(self._pairs)
         shapes = ((2 * np_, ts.value), (2 * np_, uld.value), (np_, hs.value), (np_, 3))
         if bufs is None or tuple(b.shape for b in bufs) != shapes:
+            for b in bufs or ():          # the layout changed: the buffers this call replaces are released, not kept until close()
+                self.pinned_free(b)
             bufs = tuple(self.pinned_empty(sh) for sh in shapes)
         self._check(self.L.rh_batch_results_all(self.h, *[b.ctypes.data for b in bufs]))
         return bufs
@@ -310,6 +324,11 @@ class Context:
         buf = (ctypes.c_int * max(1, 2 * len(self._pairs)))()
         k = self._check(self.L.rh_batch_fallbacks(self.h, which, buf, len(buf)))
         return [buf[t] for t in range(min(k, len(buf)))]
+
+    def set_scale_memory(self, on):
+        """True: the next batch starts on the scale exponent most of the last one needed (faster on streams of one kind of input;
+        a sequence's bits then depend on the context's history).  Default off."""
+        self._check(self.L.rh_set_scale_memory(self.h, 1 if on else 0))
 
     def set_overlap(self, on):
         """False: phases run one after the other (isolated per-phase device times in batch_timings)."""

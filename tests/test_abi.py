@@ -26,6 +26,18 @@ def test_library_exports_every_declared_symbol(hotlib):
         assert hasattr(hotlib, name), "libractip_hot.so does not export " + name
 
 
+def test_library_exports_nothing_the_header_does_not_declare(hotlib):
+    """The converse: every rh_* function the product library exports is part of the declared C ABI (no stray debug or tuning
+    entry points in the shipped build; tuning builds -DRH_STAMPS add theirs and are not shipped)."""
+    import subprocess
+    import ractip_amd.hot as hot
+    out = subprocess.check_output(["nm", "-D", "--defined-only", hot.LIB_PATH], text=True)
+    exported = sorted({ln.split()[-1] for ln in out.splitlines() if len(ln.split()) >= 3 and ln.split()[-2] in "TtWw" and ln.split()[-1].startswith("rh_")})
+    assert exported, "nm found no rh_* symbols"
+    extra = [e for e in exported if e not in declared_symbols()]
+    assert not extra, "exported but not declared in include/ractip_hot.h: %r" % extra
+
+
 def test_python_binding_lists_the_same_symbols(hotlib):
     import ractip_amd.hot as hot
     assert sorted(hot.EXPORTS) == declared_symbols()

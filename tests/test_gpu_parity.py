@@ -302,9 +302,17 @@ def test_scale_exponent_is_remembered(hotlib):
     ordinary = [(rnd(2000), rnd(1900)) for _ in range(4)]
     c = ractip_amd.Context(device=0)
     try:
+        # default: no memory -- the second batch pays the failed pass again and returns the same bits (history-free results)
         c.batch_upload(structured); c.batch_compute()
         assert c.last_path() == 3 and c.batch_fallbacks(2) == list(range(8)) and c.batch_fallbacks(0) == []
         first = [c.batch_results(p) for p in range(4)]
+        c.batch_upload(structured); c.batch_compute()
+        assert c.last_path() == 3 and c.batch_fallbacks(2) == list(range(8))
+        for r, r0 in zip([c.batch_results(p) for p in range(4)], first):
+            assert np.array_equal(r["bp1"], r0["bp1"]) and np.array_equal(r["logZ"], r0["logZ"])
+        c.set_scale_memory(True)
+        c.batch_upload(structured); c.batch_compute()
+        assert c.last_path() == 3
         c.batch_upload(structured); c.batch_compute()
         assert c.last_path() == 1 and c.batch_fallbacks(2) == []          # straight on the exponent that worked
         for r, r0 in zip([c.batch_results(p) for p in range(4)], first):
@@ -686,6 +694,44 @@ def test_vienna_bl_two_molecule_organisations_agree(hotlib, monkeypatch):
             assert_prob_close(r["hp"], r0["hp"], rel=1e-10, what="%r hp %d/%d" % (env, len(s1), len(s2)))
 
 
+def test_vienna_bl_two_molecule_graph_is_rekeyed_when_the_shortest_cut_changes(hotlib):
+    """Round-2 advisor finding: the captured launch graph of the two-molecule sweeps bakes in the window of groups around the cut,
+    which follows from the SHORTEST s1 of the batch.  Two batches with the same count and maxima but another shortest s1 must
+    not replay the first batch's window: hp / log Z of the second batch equal those of a fresh context."""
+    import ractip_amd
+    rng = np.random.default_rng(79)
+    rs = lambda n: "".join(rng.choice(list("ACGU"), size=n))
+    first = [(rs(200), rs(200)), (rs(200), rs(200))]
+    second = [(rs(200), rs(200)), (rs(70), rs(200))]
+
+    def fresh(pairs):
+        c = ractip_amd.Context(device=0, model=ractip_amd.hot.RH_MODEL_VIENNA_BL)
+        try:
+            c.set_hybrid(True)
+            c.batch_upload(pairs)
+            c.batch_compute()
+            assert c.last_path() == 1
+            return [c.batch_results(p) for p in range(len(pairs))]
+        finally:
+            c.close()
+
+    want = fresh(second)
+    c = ractip_amd.Context(device=0, model=ractip_amd.hot.RH_MODEL_VIENNA_BL)
+    try:
+        c.set_hybrid(True)
+        for pairs in (first, second):
+            c.batch_upload(pairs)
+            c.batch_compute()
+            assert c.last_path() == 1
+        got = [c.batch_results(p) for p in range(len(second))]
+    finally:
+        c.close()
+    for r, r0 in zip(got, want):
+        assert abs(r["logZ"][2] - r0["logZ"][2]) < 1e-10
+        assert_prob_close(r["hp"], r0["hp"], rel=1e-10, what="hp after a batch with another shortest cut")
+        assert r["hp"].max() > 1e-3   # the short-cut pair's cross-strand cells were really computed
+
+
 def test_vienna_bl_scale_exponent_ladder(hotlib, monkeypatch):
     """Vienna-BL model: a batch with sequences outside the double range of the default exponent (chains of stable hairpins, log Z
     0.87 per nucleotide at 900 nt) is run again on the linear kernels with another exponent -- whole batch: folds, accessibility and
@@ -710,6 +756,7 @@ def test_vienna_bl_scale_exponent_ladder(hotlib, monkeypatch):
         c = ractip_amd.Context(device=0, model=ractip_amd.hot.RH_MODEL_VIENNA_BL)
         try:
             c.set_hybrid(True)
+            c.set_scale_memory(twice)
             c.batch_upload(pairs); c.batch_compute()
             out = (c.last_path(), c.batch_fallbacks(2), [c.batch_results(p) for p in range(len(pairs))])
             if twice:

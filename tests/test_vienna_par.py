@@ -183,7 +183,12 @@ def test_a_1x_layout_file_keeps_the_18_semantics(hook, tmp_path):
     f = tmp_path / "old.par"
     f.write_text("## RNAfold parameter file\n\n# stack_energies\n/*          CG     GC     GU     UG     AU     UA  */\n" +
                  "\n".join(" ".join(str(-100 - 10 * i - j) for j in range(7)) for i in range(7)) +
-                 "\n\n# ML_params\n/* cu cc ci TerminalAU */\n 0 340 40 50\n\n# NINIO\n/* m max */\n 50 300\n\n# Tetraloops\nGGGGAC -300\n\n# END\n")
+                 "\n\n# ML_params\n/* cu cc ci TerminalAU */\n 0 340 40 50\n\n# NINIO\n/* m max */\n 50 300\n\n# Tetraloops\nGGGGAC -300\n" +
+                 # the loader refuses a model in which a table the kernels read comes from no source: the rest of the core tables, all zero
+                 "".join("\n# %s\n%s\n" % (name, " ".join(["0"] * cnt)) for name, cnt in (
+                     ("mismatch_interior", 175), ("mismatch_hairpin", 175), ("dangle5", 35), ("dangle3", 35), ("int11_energies", 1225),
+                     ("int21_energies", 6125), ("int22_energies", 9216), ("bulge", 31), ("internal_loop", 31), ("hairpin", 31))) +
+                 "\n# END\n")
     assert hook(22, param=str(f)) == 1
     assert hook(24, 2, 3, param=str(f)) == pytest.approx(w(-100 - 10 * 1 - 2))
     assert hook(23, 0, param=str(f)) == pytest.approx(w(50))
@@ -201,6 +206,19 @@ def test_loader_reports_malformed_files(hotlib, tmp_path):
     assert lib.rh_debug_vienna_value(None, 0, BL.encode(), str(bad).encode(), 0, 22, 0, 0, 0, 0, ctypes.byref(out)) == -4
     assert lib.rh_debug_vienna_value(None, 0, BL.encode(), b"/nonexistent.par", 0, 22, 0, 0, 0, 0, ctypes.byref(out)) == -4
     assert lib.rh_debug_vienna_value(None, 1, BL.encode(), None, 7, 22, 0, 0, 0, 0, ctypes.byref(out)) == -4   # unknown semantics
+    # a file that leaves core tables to no source at all (no defaults, no BL*) is refused instead of computing with zero energies ...
+    part = tmp_path / "partial.par"
+    part.write_text("## RNAfold parameter file\n\n# stack_energies\n" + "\n".join(" ".join(["-100"] * 7) for _ in range(7)) + "\n\n# END\n")
+    assert lib.rh_debug_vienna_value(None, 0, BL.encode(), str(part).encode(), 0, 22, 0, 0, 0, 0, ctypes.byref(out)) == -4
+    # ... and accepted on top of the BL* tables, which supply the rest (install order of src/ractip.cpp:1563-1567)
+    assert lib.rh_debug_vienna_value(None, 1, BL.encode(), str(part).encode(), 0, 22, 0, 0, 0, 0, ctypes.byref(out)) == 0
+    # a truncated flat dump (a table cut out of the bundled BL* file) as the only source is refused too
+    lines = open(BL).read().splitlines()
+    k0 = next(k for k, l in enumerate(lines) if l.startswith("bulge37"))
+    k1 = next(k for k in range(k0 + 1, len(lines)) if lines[k] and not lines[k][0].isdigit() and lines[k][0] not in "-# ")
+    cut = tmp_path / "cut.params"
+    cut.write_text("\n".join(lines[:k0] + lines[k1:]) + "\n")
+    assert lib.rh_debug_vienna_value(None, 1, str(cut).encode(), None, 0, 22, 0, 0, 0, 0, ctypes.byref(out)) == -4
 
 
 @pytest.mark.parametrize("seed", range(4))

@@ -25,6 +25,7 @@ if len(sys.argv) > 1 and os.environ.get("RH_EXP_CHILD"):
         c.close()
         c = ractip_amd.Context(device=0, model=ractip_amd.hot.RH_MODEL_VIENNA_BL)
         c.set_hybrid(True)
+    c.set_scale_memory(True)
     c.batch_upload(pairs); c.batch_compute()
     t0 = time.perf_counter()
     for _ in range(3):

@@ -30,6 +30,8 @@ plain = {"cf": ractip_amd.Context(device=0), "vi": ractip_amd.Context(device=0, 
 del os.environ["RH_SCALE_LADDER"]
 for c in (ladder["vi"], plain["vi"]):
     c.set_hybrid(True)
+for c in ladder.values():
+    c.set_scale_memory(True)   # the remembered exponent is what this tool exercises (off by default)
 t0, batches, rescaled_total, moved = time.time(), 0, 0, 0
 while time.time() - t0 < budget:
     model = "cf" if rng.random() < 0.6 else "vi"
