@@ -91,6 +91,93 @@ extern "C" int rh_debug_stamps(unsigned long long* out, int reset)
 
 enum StripTable { S_FC = 0, S_FCX, S_FCA, S_FM1, S_FM, S_FCO, S_FCOX, S_FM2O, S_FMO, S_FM1O, S_FM2F, S_FMOF, S_FM1OF };
 
+// ---------------------------------------------------------------------------------------------------------------
+// FACTORED single-branch filter (FILT = 1; host side: strip_weights in rh_api.hip).  The weight of an interior loop (l1, l2), t = l1+l2,
+// is A(t) * B(|l1-l2|) up to a sparse residual (bulge ends, centre tap, a few shapes with l1, l2 <= 4: cache_score_single,
+// InferenceEngine.ipp:1161-1197).  For one staged table row x (row rho of the strip: t = rho-1+k on diagonal k) the B-weighted sum
+//   S_t[i] = sum_{l1=1}^{t-1} B(|2 l1 - t|) x[i+1+l1]      obeys      S_{t+2}[i-1] = S_t[i] + B(t) (x[i+1] + x[i+1+t]),
+// and x[i+1], x[i+1+t] are also the two bulge taps of (t, i).  So a wavefront takes the diagonals of ONE parity (k = k0, k0+2, k0+4,
+// k0+6), computes S once per row by a full pass for k0 and then walks: per row and diagonal 2 LDS reads, 1 add, 3-4 FMAs instead of
+// t+1 FMAs.  The lane that holds column i at k0 holds column i-m at diagonal k0+2m (inside; i+m outside): S never moves between
+// lanes, and the shift is undone for free by the index the partial sum is written to.  Lanes that drop off the group's edge hold
+// garbage; they are exactly lanes the trapezoid does not store (m <= k).
+// Wavefront w: rows rho = (w & 3) + 4 q, q = 0..7, parity k0 = w >> 2.  U = (w & 3) + k0 fixes every length (t0 = U-1+4q), so the
+// pass is compiled for U = 0..4 with all lengths, table offsets and LDS offsets as immediates.
+//   F[(t+1)*4 + {0,1,2,3}] = A(t), wb(t), Bstep(t), Rc(t);  F[160 + 16 p + j] = B(p + 2j);  F[192 + 4 t + l1-1] = explicit residuals
+template <int U, bool OUTSIDE, int CE>
+__device__ __forceinline__ void filt_factored(lds_vp xb, lds_vp fw, const double* __restrict__ F, double (&g)[4])
+{
+    // xb: inside  = &LE[(w & 3) * CE + lane - 3]: tap l1 of the cell in lane L at step m is xb[3 - m + l1]
+    //     outside = &LE[(w & 3) * CE + lane]    : tap l1 is xb[31 + m - l1]      (every offset a non-negative immediate)
+    // fw: W4 in LDS (A, wb, -, Rc per length): wave-uniform addresses, i.e. broadcast reads that return in order with the taps --
+    //     scalar loads would share lgkmcnt with the LDS reads and force a full drain at every use (SMEM returns out of order)
+    auto X = [&](int row_off, int m, int l1) -> double { return OUTSIDE ? xb[row_off + 31 + m - l1] : xb[row_off + 3 - m + l1]; };
+    constexpr int par = (U + 1) & 1;   // parity of every length this wavefront meets: t0 = U-1+4q
+    double bw[15];                     // B(par + 2j): the only scalar operands of the pass, requested once
+#pragma unroll
+    for (int j = 0; j < 15; j++) bw[j] = F[160 + 16 * par + j];
+    static_for<8>([&](auto QC) {
+        constexpr int q = decltype(QC)::value, t0 = U - 1 + 4 * q, ro = q * 4 * CE;
+        if constexpr (t0 + 6 >= 2 && t0 <= 30) {
+            double S = 0.0, xc = 0.0;
+            if constexpr (t0 >= 3) {   // full pass for the first diagonal of this parity: taps l1 = 1 .. t0-1 (the centre tap below)
+                double S2 = 0.0;       // two accumulators: the pass is a dependent FMA chain otherwise
+                static_for<t0 - 1>([&](auto LC) {
+                    constexpr int l1 = decltype(LC)::value + 1, dist = (2 * l1 - t0) < 0 ? (t0 - 2 * l1) : (2 * l1 - t0);
+                    if constexpr (2 * l1 != t0) {
+                        const double x = X(ro, 0, l1);
+                        if constexpr (l1 & 1) S = fma(bw[dist / 2], x, S); else S2 = fma(bw[dist / 2], x, S2);
+                    }
+                });
+                S += S2;
+            }
+            if constexpr (par == 0 && t0 >= 0) {   // centre tap: the same LDS word for every step of the chain
+                xc = X(ro, 0, t0 / 2);
+                if constexpr (t0 >= 2) S = fma(bw[0], xc, S);
+            }
+            static_for<4>([&](auto MC) {
+                constexpr int m = decltype(MC)::value, t = t0 + 2 * m;
+                if constexpr (t >= 0 && t <= 30) {
+                    const double xl = X(ro, m, 0);
+                    if constexpr (t == 0) {
+                        S = fma(bw[0], xl, S);   // S_2[i-1] = B(0) x[i+1]: the two end taps of t = 0 are one tap
+                    } else {
+                        const double e = xl + X(ro, m, t);
+                        if constexpr (t >= 2) {
+                            double a = g[m];
+                            a = fma(fw[(t + 1) * 4 + 0], S, a);
+                            a = fma(fw[(t + 1) * 4 + 1], e, a);
+                            if constexpr (par == 0) a = fma(fw[(t + 1) * 4 + 3], xc, a);
+                            if constexpr (t >= 3 && t <= 7)   // explicit shapes (l1, l2 <= 4): symmetric pairs share their residual
+                                static_for<2>([&](auto LC) {
+                                    constexpr int l1 = decltype(LC)::value + (t - 4 > 1 ? t - 4 : 1), l2 = t - l1;
+                                    if constexpr (l1 < l2 && l2 <= 4) a = fma(F[192 + 4 * t + l1 - 1], X(ro, m, l1) + X(ro, m, l2), a);
+                                });
+                            g[m] = a;
+                        }
+                        if constexpr (m < 3 && t + 2 <= 30) S = fma(bw[t / 2], e, S);
+                    }
+                }
+            });
+#pragma unroll
+            for (int m = 0; m < 4; m++) asm volatile("" : "+v"(g[m]));   // one row's arithmetic before the next row's (volatile) reads
+        }
+    });
+}
+
+template <bool OUTSIDE, int CE>
+__device__ __forceinline__ void filt_factored_any(int u, lds_vp xb, lds_vp fw, const double* __restrict__ F, double (&g)[4])
+{
+    switch (u) {
+        case 0: filt_factored<0, OUTSIDE, CE>(xb, fw, F, g); break;
+        case 1: filt_factored<1, OUTSIDE, CE>(xb, fw, F, g); break;
+        case 2: filt_factored<2, OUTSIDE, CE>(xb, fw, F, g); break;
+        case 3: filt_factored<3, OUTSIDE, CE>(xb, fw, F, g); break;
+        default: filt_factored<4, OUTSIDE, CE>(xb, fw, F, g); break;
+    }
+}
+constexpr int kStripFiltOffD = 31 * 40;   // offset of the factored tables behind the dense wT (kWTS = 40 columns, 31 rows)
+
 // LDS plan of the inside strip kernel (doubles)
 template <int KD, int W>
 struct InStripPlan {
@@ -114,7 +201,7 @@ struct InStripPlan {
 // wT[l1*kWTS + t + 1] = shape_w(l1, t-l1) for 0 <= l1 <= t <= 30, else 0.
 constexpr int kWTS = 40;
 
-template <int KD, int W>
+template <int KD, int W, int FILT>
 __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_inside_strip(McBatch B, const LinModel* __restrict__ L, const double* __restrict__ wT, int d0, int f5_lo,
                                                               double lam_d0, int pin)
 {
@@ -125,6 +212,8 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_inside_strip(McB
     static_assert(KD % W == 0 && KD <= 8 && W % TS == 0 && KD % (W / TS) == 0 && (NM + 1) % W == 0, "8 terms per end and term set, 32/W staged rows per wavefront and region");
     __shared__ double lds[P::SZ];
     __shared__ double red[W];
+    constexpr bool FACT = FILT != 0 && W == 8 && KD == 8;
+    __shared__ double fw[FACT ? 160 : 1];   // factored filter: W4[t+1][4] (A, wb, -, Rc), read by wave-uniform (broadcast) LDS loads
     // pin = 2 (batch size a multiple of 8): workgroups are dealt round-robin to the 8 XCDs in launch order, so sequence sq is
     // pinned to XCD sq % 8 AND the groups of one sequence are consecutive on that XCD: neighbouring groups share 40 % of their
     // staged columns, which then come out of that XCD's L2 instead of HBM.  (Placement only: any mapping gives the same result.)
@@ -241,6 +330,8 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_inside_strip(McB
         a_lo[q] = i <= n - 1 - m ? v : 0.0;
         a_hi[q] = i <= n - 1 - R ? u : 0.0;
     }
+    double fwv = 0.0;
+    if constexpr (FACT) fwv = wT[kStripFiltOffD + (threadIdx.x < 160 ? threadIdx.x : 159)];   // (with the staging loads: no round trip of its own)
     // the letters are first touched HERE, behind the staging loads (fence + pins: their wait must not move above those loads)
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("" : "+v"(rb0)); asm volatile("" : "+v"(rb1)); asm volatile("" : "+v"(rb2));
@@ -316,6 +407,7 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_inside_strip(McB
     }
     for (int k = threadIdx.x; k < (P::RA - NM) * CA; k += 64 * W) LA[NM * CA + k] = 0.0;
     for (int k = threadIdx.x; k < (P::RD - NM) * CD; k += 64 * W) LDm[NM * CD + k] = 0.0;
+    if constexpr (FACT) { asm volatile("" : "+v"(fwv)); if (threadIdx.x < 160) fw[threadIdx.x] = fwv; }
     RH_STAMPI(0);
     __syncthreads();
     RH_STAMPI(1);
@@ -365,7 +457,11 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_inside_strip(McB
     // the shape does not exist), so for one tap the 8 rows x 8 diagonals of this wavefront are 36 consecutive entries of the
     // transposed table: wave-uniform scalar loads, 20 doubles per half (rows q = 0..3 / 4..7) and 32 FMAs behind each.
     // The first half of the term set's rows (rho <= wt + TS*3) has no tap beyond l1 = rho+kb+KH-2: skipped for larger l1.
-    {
+    if constexpr (FACT) {
+        // factored filter (see filt_factored): this wavefront takes the diagonals k0, k0+2, k0+4, k0+6 of rows rho = wt + 4q; accg[m] is
+        // the sum of diagonal k0+2m for the cell in column i-m
+        filt_factored_any<false, CE>(wt + w / TS, (lds_vp)LE + wt * CE + lane - 3, (lds_vp)fw, wT + kStripFiltOffD, accg);
+    } else {
         constexpr int HR = NT / 2;
         const lds_vp xrow = (lds_vp)LE + wt * CE + lane;
 #pragma unroll 1
@@ -421,7 +517,11 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_inside_strip(McB
 #pragma unroll
     for (int k = 0; k < KH; k++) {
         PART[((wt * KD + kb + k) * 2 + 0) * 64 + lane] = acc2[k];
-        PART[((wt * KD + kb + k) * 2 + 1) * 64 + lane] = accg[k];
+        if constexpr (FACT) {   // accg[k]: diagonal k0+2k of column i-k (k0 = w / TS); lanes < k hold cells of the group to the left
+            if (lane >= k) PART[((wt * KD + w / TS + 2 * k) * 2 + 1) * 64 + lane - k] = accg[k];
+        } else {
+            PART[((wt * KD + kb + k) * 2 + 1) * 64 + lane] = accg[k];
+        }
     }
     __syncthreads();
 
@@ -588,7 +688,7 @@ __global__ __launch_bounds__(256) void lin_f5o_head(McBatch B, const LinModel* _
     f5o_range<4>(B.tab + (size_t)sq * B.seq_stride + S_FCA * B.tab_stride, B.f5o + (size_t)sq * B.ld, L, B.n[sq], B.ld, khi, klo, red);
 }
 
-template <int KD, int W>
+template <int KD, int W, int FILT>
 __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_outside_strip(McBatch B, const LinModel* __restrict__ L, const double* __restrict__ wT, int d0, int f5_hi,
                                                                               int f5_lo, int pin, int* __restrict__ bad)
 {
@@ -599,6 +699,8 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_outside_strip(Mc
     static_assert(KD % W == 0 && KD <= 8 && W % TS == 0 && KD % (W / TS) == 0 && (NM + 1) % W == 0, "8 terms per end and term set, 32/W staged rows per wavefront and region");
     __shared__ double lds[P::SZ];
     __shared__ double red[W];
+    constexpr bool FACT = FILT != 0 && W == 8 && KD == 8;
+    __shared__ double fw[FACT ? 160 : 1];   // factored filter: W4[t+1][4] (A, wb, -, Rc), read by wave-uniform (broadcast) LDS loads
     // pin = 2 (batch size a multiple of 8): workgroups are dealt round-robin to the 8 XCDs in launch order, so sequence sq is
     // pinned to XCD sq % 8 AND the groups of one sequence are consecutive on that XCD: neighbouring groups share 40 % of their
     // staged columns, which then come out of that XCD's L2 instead of HBM.  (Placement only: any mapping gives the same result.)
@@ -698,6 +800,8 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_outside_strip(Mc
         a_lo[q] = ((i - e >= 1) & (i <= n - 1)) ? v : 0.0;       // cell (i-e, i)
         a_hi[q] = ((i >= 1) & (i <= n - 1 - R)) ? u : 0.0;       // cell (i, i+R)
     }
+    double fwv = 0.0;
+    if constexpr (FACT) fwv = wT[kStripFiltOffD + (threadIdx.x < 160 ? threadIdx.x : 159)];   // (with the staging loads: no round trip of its own)
     // the letters are first touched HERE, behind the staging loads
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("" : "+v"(rb0)); asm volatile("" : "+v"(rb1)); asm volatile("" : "+v"(rb2));
@@ -773,6 +877,7 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_outside_strip(Mc
     }
     for (int k = threadIdx.x; k < KD * CA; k += 64 * W) LA[k] = 0.0;
     for (int k = threadIdx.x; k < (P::RD - NM) * CD; k += 64 * W) LDm[NM * CD + k] = 0.0;
+    if constexpr (FACT) { asm volatile("" : "+v"(fwv)); if (threadIdx.x < 160) fw[threadIdx.x] = fwv; }
     RH_STAMPO(0);
     __syncthreads();
     RH_STAMPO(1);
@@ -835,7 +940,10 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_outside_strip(Mc
     RH_STAMPO(3);
     // enclosing single-branch loops: staged row rho is table row d0+1+rho = d+2+t with t = rho-1+k for diagonal d0-k; tap l1 reads column
     // i-1-l1 of it (index lane+31-l1).  Weights as in the inside strip: wT[l1][rho+k].
-    {
+    if constexpr (FACT) {
+        // factored filter (see filt_factored), mirrored: accg[m] is the sum of diagonal d0-(k0+2m) for the cell in column i+m
+        filt_factored_any<true, CE>(wt + w / TS, (lds_vp)LE + wt * CE + lane, (lds_vp)fw, wT + kStripFiltOffD, accg);
+    } else {
         constexpr int HR = NT / 2;
         const lds_vp xrow = (lds_vp)LE + wt * CE + lane + 31;
 #pragma unroll 1
@@ -892,7 +1000,11 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_outside_strip(Mc
     for (int k = 0; k < KH; k++) {
         PART[((wt * KD + kb + k) * 3 + 0) * 64 + lane] = accm[k];
         PART[((wt * KD + kb + k) * 3 + 1) * 64 + lane] = acc1[k];
-        PART[((wt * KD + kb + k) * 3 + 2) * 64 + lane] = accg[k];
+        if constexpr (FACT) {   // accg[k]: diagonal d0-(k0+2k) of column i+k; lanes > 63-k hold cells of the group to the right
+            if (lane + k <= 63) PART[((wt * KD + w / TS + 2 * k) * 3 + 2) * 64 + lane + k] = accg[k];
+        } else {
+            PART[((wt * KD + kb + k) * 3 + 2) * 64 + lane] = accg[k];
+        }
     }
     for (int k = threadIdx.x; k < 5 * KD; k += 64 * W) {   // the left pad of the strip rows (read by lanes < 8 only)
 #pragma unroll
@@ -1007,9 +1119,11 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_outside_strip(Mc
     RH_STAMPO(8);
 }
 
-template __global__ void lin_inside_strip<8, 4>(McBatch, const LinModel*, const double*, int, int, double, int);
-template __global__ void lin_inside_strip<8, 8>(McBatch, const LinModel*, const double*, int, int, double, int);
-template __global__ void lin_outside_strip<8, 4>(McBatch, const LinModel*, const double*, int, int, int, int, int*);
-template __global__ void lin_outside_strip<8, 8>(McBatch, const LinModel*, const double*, int, int, int, int, int*);
+template __global__ void lin_inside_strip<8, 4, 0>(McBatch, const LinModel*, const double*, int, int, double, int);
+template __global__ void lin_inside_strip<8, 8, 0>(McBatch, const LinModel*, const double*, int, int, double, int);
+template __global__ void lin_inside_strip<8, 8, 1>(McBatch, const LinModel*, const double*, int, int, double, int);
+template __global__ void lin_outside_strip<8, 4, 0>(McBatch, const LinModel*, const double*, int, int, int, int, int*);
+template __global__ void lin_outside_strip<8, 8, 0>(McBatch, const LinModel*, const double*, int, int, int, int, int*);
+template __global__ void lin_outside_strip<8, 8, 1>(McBatch, const LinModel*, const double*, int, int, int, int, int*);
 
 }  // namespace rh

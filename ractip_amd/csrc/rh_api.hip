@@ -40,8 +40,8 @@ template <int BS> __global__ void lin_far_outside(McBatch B, int D);
 __global__ void lin_far_inside_mfma(McBatch B, int D);
 __global__ void lin_far_outside_mfma(McBatch B, int D);
 __global__ void lin_pack_tiles(McBatch B, int Dblk, int outside, int banded);
-template <int KD, int W> __global__ void lin_inside_strip(McBatch B, const LinModel* __restrict__ L, const double* __restrict__ wT, int d0, int f5_lo, double lam_d0, int pin);
-template <int KD, int W> __global__ void lin_outside_strip(McBatch B, const LinModel* __restrict__ L, const double* __restrict__ wT, int d0, int f5_hi, int f5_lo, int pin, int* __restrict__ bad);
+template <int KD, int W, int FILT> __global__ void lin_inside_strip(McBatch B, const LinModel* __restrict__ L, const double* __restrict__ wT, int d0, int f5_lo, double lam_d0, int pin);
+template <int KD, int W, int FILT> __global__ void lin_outside_strip(McBatch B, const LinModel* __restrict__ L, const double* __restrict__ wT, int d0, int f5_hi, int f5_lo, int pin, int* __restrict__ bad);
 __global__ void lin_f5i_tail(McBatch B, const LinModel* __restrict__ L, int jlo);
 __global__ void lin_f5o_head(McBatch B, const LinModel* __restrict__ L, int khi, int klo);
 __global__ void lin_far_inside_pk(McBatch B, int D, int l2);
@@ -307,6 +307,8 @@ struct rh_ctx {
     int far2 = -1;                 // two-level block products: -1 = by size (sequences of n >= 384), 0 / 1 forced (RH_FAR2)
     int far2_next = -1;            // launch-sequence state of far_outside_step
     int strip_w = 8;               // wavefronts per strip workgroup (RH_STRIP_W = 4 | 8)
+    int strip_filt = 1;            // single-branch filter of the strip kernels: 1 = factored (A(t) B(|l1-l2|) + sparse residual), 0 = dense (RH_STRIP_FILT)
+    bool strip_filt_ok = false;    // the model's weights have the factored form (strip_weights verifies it entry by entry)
     int co_cut_min = 0, co_cut_max = 0;   // smallest / largest cut (length of s1) of the two-molecule batch: bounds of the groups its sweeps launch
     int co_window = 1;             // two-molecule sweeps launch only the groups around the cut (RH_CO_WINDOW=0: all groups, most of which return at once)
     int acc_final_t = 1;           // Vienna-BL accessibility: vlin_acc_final_t (one thread per letter, all widths; RH_ACC_FINAL_T=0: one thread per letter and width)
@@ -963,10 +965,13 @@ int launch_mc_lin(rh_ctx* c, int pin, int phase)
             for (; d0 <= B.nmax - 2; d0 += KD) {
                 const int groups = (std::max(B.nmax - 1 - d0, 0) + GS - 1) / GS + 1;
                 if (c->strip_w == 4)
-                    KLAUNCH(c, 0, (lin_inside_strip<KD, 4>), pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(256), c->s_mc, B, c->d_lin, c->d_wT, d0,
+                    KLAUNCH(c, 0, (lin_inside_strip<KD, 4, 0>), pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(256), c->s_mc, B, c->d_lin, c->d_wT, d0,
+                            d0 == 32 ? 32 : d0 - KD + 2, std::exp(-c->h_lin.s * d0), (pin && c->strip_xcd) ? 2 : pin);
+                else if (c->strip_filt && c->strip_filt_ok)
+                    KLAUNCH(c, 0, (lin_inside_strip<KD, 8, 1>), pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(512), c->s_mc, B, c->d_lin, c->d_wT, d0,
                             d0 == 32 ? 32 : d0 - KD + 2, std::exp(-c->h_lin.s * d0), (pin && c->strip_xcd) ? 2 : pin);
                 else
-                    KLAUNCH(c, 0, (lin_inside_strip<KD, 8>), pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(512), c->s_mc, B, c->d_lin, c->d_wT, d0,
+                    KLAUNCH(c, 0, (lin_inside_strip<KD, 8, 0>), pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(512), c->s_mc, B, c->d_lin, c->d_wT, d0,
                             d0 == 32 ? 32 : d0 - KD + 2, std::exp(-c->h_lin.s * d0), (pin && c->strip_xcd) ? 2 : pin);
                 c->n_launch[0]++;
                 if ((d0 + KD) % BS == 0) {
@@ -1038,10 +1043,13 @@ int launch_mc_lin(rh_ctx* c, int pin, int phase)
                 }
                 const int groups = (std::max(B.nmax - 1 - (d0 - (KD - 1)), 0) + GS - 1) / GS + 1;
                 if (c->strip_w == 4)
-                    KLAUNCH(c, 2, (lin_outside_strip<KD, 4>), pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(256), c->s_mc, B, c->d_lin, c->d_wT, d0,
+                    KLAUNCH(c, 2, (lin_outside_strip<KD, 4, 0>), pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(256), c->s_mc, B, c->d_lin, c->d_wT, d0,
+                            d0 - 6, d0 - 13, (pin && c->strip_xcd) ? 2 : pin, bad);
+                else if (c->strip_filt && c->strip_filt_ok)
+                    KLAUNCH(c, 2, (lin_outside_strip<KD, 8, 1>), pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(512), c->s_mc, B, c->d_lin, c->d_wT, d0,
                             d0 - 6, d0 - 13, (pin && c->strip_xcd) ? 2 : pin, bad);
                 else
-                    KLAUNCH(c, 2, (lin_outside_strip<KD, 8>), pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(512), c->s_mc, B, c->d_lin, c->d_wT, d0,
+                    KLAUNCH(c, 2, (lin_outside_strip<KD, 8, 0>), pin ? dim3(B.ns, groups) : dim3(groups, B.ns), dim3(512), c->s_mc, B, c->d_lin, c->d_wT, d0,
                             d0 - 6, d0 - 13, (pin && c->strip_xcd) ? 2 : pin, bad);
                 c->n_launch[1]++;
             }
@@ -1212,12 +1220,61 @@ int recompute_mc_subset_log(rh_ctx* c, const std::vector<int>& F)
     return RH_OK;
 }
 
-// single-branch weights of the strip kernels: wT[l1*40 + t+1] = shape_w(l1, t-l1), zero where the shape does not exist
-std::vector<double> strip_weights(const LinModel& L)
+// single-branch weights of the strip kernels: wT[l1*40 + t+1] = shape_w(l1, t-l1), zero where the shape does not exist (the dense
+// filter, FILT = 0), followed by the FACTORED form of the same weights at offset kStripFiltOff (FILT = 1, mccaskill_strip.hip):
+// cache_score_single[l1][l2] (InferenceEngine.ipp:1161-1197) of an interior loop is length term(l1+l2) + asymmetry term(|l1-l2|)
+// plus corrections on a sparse set (bulges l1 = 0 | l2 = 0, the symmetric term on l1 == l2, the explicit terms for l1, l2 <= 4), so
+//   w(l1, t-l1) = A(t) * B(|2 l1 - t|) + R(l1, t),   R != 0 only for bulge ends, the centre tap and a few (l1, l2 <= 4) shapes,
+// and the B-weighted row sums obey S_{t+2}[i-1] = S_t[i] + B(t) (x[i+1] + x[i+t+1]): two diagonals later the same table row needs
+// two more taps instead of a whole pass.  A, B (any gauge) and R are taken from the weights themselves and the reconstruction is
+// verified entry by entry; a weight set without this structure keeps the dense filter (`*ok` = false).
+//   F[0..159]   W4[t+1][4] = {A(t), bulge weight wb(t), Bstep(t), centre residual Rc(t)}, t = -1..38 (zero outside 0..30)
+//   F[160..191] Bp[parity][j] = B(parity + 2j)
+//   F[192..231] Rx[t][l1-1], t = 0..9, l1 = 1..4: residuals of the shapes with 1 <= l1 <= 4 that are neither bulge end nor centre
+constexpr int kStripFiltOff = 31 * 40, kStripFiltLen = 232;
+std::vector<double> strip_weights(const LinModel& L, bool* ok_out = nullptr)
 {
-    std::vector<double> wT(31 * 40, 0.0);
+    std::vector<double> wT(kStripFiltOff + kStripFiltLen, 0.0);
+    double W[31][31] = {};
     for (int t = 0; t <= kMaxSingle; t++)
-        for (int l1 = 0; l1 <= t; l1++) wT[(size_t)l1 * 40 + t + 1] = L.shape_w[t * (t + 1) / 2 + l1];
+        for (int l1 = 0; l1 <= t; l1++) { W[t][l1] = L.shape_w[t * (t + 1) / 2 + l1]; wT[(size_t)l1 * 40 + t + 1] = W[t][l1]; }
+    double* F = wT.data() + kStripFiltOff;
+    double B[40] = {}, A[40] = {};
+    bool ok = W[30][14] > 0.0 && W[29][14] > 0.0;
+    if (ok) {
+        for (int k = 2; k <= 28; k += 2) B[k] = W[30][15 - k / 2] / W[30][14];     // gauge B(2) = 1 on the even, B(1) = 1 on the odd differences
+        B[0] = B[2];                                                                  // (the centre tap carries the symmetric term: residual)
+        for (int k = 1; k <= 27; k += 2) B[k] = W[29][(29 - k) / 2] / W[29][14];
+        for (int t = 3; t <= 30; t++) A[t] = B[t - 2] > 0.0 ? W[t][1] / B[t - 2] : 0.0;
+    }
+    for (int t = 0; ok && t <= 30; t++) {
+        for (int l1 = 0; l1 <= t; l1++) {
+            const int l2 = t - l1;
+            const double ab = (l1 >= 1 && l2 >= 1) ? A[t] * B[std::abs(l1 - l2)] : 0.0;
+            double R = W[t][l1] - ab;
+            if (std::fabs(R) <= 1e-13 * std::fabs(W[t][l1])) R = 0.0;
+            if (R == 0.0) continue;
+            if (l1 == 0 || l2 == 0) { if (W[t][0] != W[t][t]) ok = false; F[(t + 1) * 4 + 1] = W[t][0]; }   // one bulge weight per length
+            else if (l1 == l2) F[(t + 1) * 4 + 3] = R;
+            else if (l1 <= 4 && l2 <= 4) F[192 + t * 4 + (l1 - 1)] = R;                                      // (t <= 8)
+            else ok = false;
+        }
+        F[(t + 1) * 4 + 0] = A[t];
+        F[(t + 1) * 4 + 2] = t == 0 ? 0.5 * B[0] : (t <= 28 ? B[t] : 0.0);
+    }
+    for (int j = 0; j < 16; j++) { F[160 + j] = 2 * j <= 28 ? B[2 * j] : 0.0; F[176 + j] = 2 * j + 1 <= 27 ? B[2 * j + 1] : 0.0; }
+    // verification: the factored form reproduces every weight
+    for (int t = 0; ok && t <= 30; t++)
+        for (int l1 = 0; l1 <= t; l1++) {
+            const int l2 = t - l1;
+            double w = (l1 >= 1 && l2 >= 1) ? A[t] * B[std::abs(l1 - l2)] : 0.0;
+            if (l1 == 0 || l2 == 0) w += t >= 1 ? F[(t + 1) * 4 + 1] : 0.0;
+            else if (l1 == l2) w += F[(t + 1) * 4 + 3];
+            else if (l1 <= 4 && l2 <= 4) w += F[192 + t * 4 + (l1 - 1)];
+            if (std::fabs(w - W[t][l1]) > 1e-12 * std::fabs(W[t][l1])) ok = false;
+        }
+    if (ok && (F[(0 + 1) * 4 + 1] != 0.0 || F[(1 + 1) * 4 + 1] != 0.0)) ok = false;   // shapes (0,0), (0,1), (1,0) are not filter taps (weight 0 here)
+    if (ok_out) *ok_out = ok;
     return wT;
 }
 
@@ -1236,7 +1293,9 @@ int ensure_rungs(rh_ctx* c)
     c->h_lin_r = new LinModel[rh_ctx::kRungs];
     for (int r = 0; r < rh_ctx::kRungs; r++) {
         build_lin_model(*c->h_score, kRungS[r], &c->h_lin_r[r]);
-        const std::vector<double> wT = strip_weights(c->h_lin_r[r]);
+        bool fok = false;
+        const std::vector<double> wT = strip_weights(c->h_lin_r[r], &fok);
+        if (!fok) c->strip_filt_ok = false;   // (the structure does not depend on the exponent; kept as a guard)
         HIP_TRY(c, hipMalloc((void**)&c->d_lin_r[r], sizeof(LinModel)));
         HIP_TRY(c, hipMemcpy(c->d_lin_r[r], &c->h_lin_r[r], sizeof(LinModel), hipMemcpyHostToDevice));
         HIP_TRY(c, hipMalloc((void**)&c->d_wT_r[r], sizeof(double) * wT.size()));
@@ -1488,7 +1547,7 @@ size_t shape_key(const rh_ctx* c, int which)
         for (size_t v : {(size_t)B.ns, (size_t)B.nmax, (size_t)B.ld, (size_t)B.lds, (size_t)B.tab, (size_t)B.seq, (size_t)B.n,
                          (size_t)B.f5i, (size_t)B.bp, (size_t)B.up, (size_t)c->d_bad, (size_t)c->d_mclogz, (size_t)c->lin_w, (size_t)c->lin_w_in,
                          (size_t)c->lin_bs, (size_t)B.tri_stride, (size_t)c->far_mfma, (size_t)c->max_w, (size_t)c->d_gaps,
-                         (size_t)c->d_hplen, (size_t)B.allow, (size_t)B.pk, (size_t)c->far_pk, (size_t)B.rowp, (size_t)c->lookahead, (size_t)c->strip, (size_t)c->d_wT, (size_t)c->strip_w, (size_t)c->strip_xcd, (size_t)(c->far2 + 2), (size_t)c->acc_wide, (size_t)c->acc_final_t, (size_t)c->d_vlin})
+                         (size_t)c->d_hplen, (size_t)B.allow, (size_t)B.pk, (size_t)c->far_pk, (size_t)B.rowp, (size_t)c->lookahead, (size_t)c->strip, (size_t)c->d_wT, (size_t)c->strip_w, (size_t)(c->strip_filt && c->strip_filt_ok), (size_t)c->strip_xcd, (size_t)(c->far2 + 2), (size_t)c->acc_wide, (size_t)c->acc_final_t, (size_t)c->d_vlin})
             h = mix(h, v);
     } else {
         const DxLinBatch& X = c->dxl;
@@ -1867,6 +1926,7 @@ static rh_ctx* create_ctx(int device, int model, const char* param_file, const c
     if (const char* e = std::getenv("RH_LOOKAHEAD")) c->lookahead = std::atoi(e);
     if (const char* e = std::getenv("RH_STRIP")) c->strip = std::atoi(e);
     if (const char* e = std::getenv("RH_STRIP_W")) c->strip_w = std::atoi(e) == 4 ? 4 : 8;
+    if (const char* e = std::getenv("RH_STRIP_FILT")) c->strip_filt = std::atoi(e) != 0;
     if (const char* e = std::getenv("RH_FAR2")) c->far2 = std::atoi(e);
     if (const char* e = std::getenv("RH_STRIP_XCD")) c->strip_xcd = std::atoi(e);
     if (const char* e = std::getenv("RH_ACC_WIDE")) c->acc_wide = std::atoi(e);
@@ -1887,7 +1947,7 @@ static rh_ctx* create_ctx(int device, int model, const char* param_file, const c
               hipMalloc((void**)&c->d_dxlin, sizeof(DxLinModel)) == hipSuccess &&
               hipMemcpy(c->d_dxlin, &c->h_dxlin, sizeof(DxLinModel), hipMemcpyHostToDevice) == hipSuccess;
     if (ok) {
-        const std::vector<double> wT = strip_weights(c->h_lin);
+        const std::vector<double> wT = strip_weights(c->h_lin, &c->strip_filt_ok);
         ok = hipMalloc((void**)&c->d_wT, sizeof(double) * wT.size()) == hipSuccess &&
              hipMemcpy(c->d_wT, wT.data(), sizeof(double) * wT.size(), hipMemcpyHostToDevice) == hipSuccess;
     }
@@ -2255,9 +2315,9 @@ int rh_batch_kernels(rh_ctx* c, const char* fine[3], const char* far[3], int n_f
     const std::string targs = vienna ? bs + ", false" : bs;
     names[0] = !c->has_mc ? "" : lin ? pre + "inside_diag<" + (vienna ? "8" : w_in) + ", " + targs + (vienna ? "" : (pairs && c->lin_w_in == 4) ? ", 3" : (c->lookahead == 1 && c->lin_w_in == 4 && c->lin_bs == 16) ? ", 1" : ", 0") + ">"
                                      : vienna ? "mcv_inside_diag" : "mc_inside_diag";
-    if (c->has_mc && lin && !vienna && strip_inside(c, c->mc)) names[0] = c->strip_w == 4 ? "lin_inside_strip<8, 4>" : "lin_inside_strip<8, 8>";
+    if (c->has_mc && lin && !vienna && strip_inside(c, c->mc)) names[0] = c->strip_w == 4 ? "lin_inside_strip<8, 4, 0>" : ((c->strip_filt && c->strip_filt_ok) ? "lin_inside_strip<8, 8, 1>" : "lin_inside_strip<8, 8, 0>");
     const bool ostrip = c->has_mc && lin && !vienna && strip_outside(c, c->mc);
-    names[1] = ostrip ? (c->strip_w == 4 ? "lin_outside_strip<8, 4>" : "lin_outside_strip<8, 8>") : !c->has_mc ? "" : lin ? ((pairs && (c->lin_w == 4 || c->lin_w == 8)) ? "lin_outside_pair<" + w + ", " + targs + ">" : pre + "outside_diag<" + (vienna ? "8" : w) + ", " + targs + ">")
+    names[1] = ostrip ? (c->strip_w == 4 ? "lin_outside_strip<8, 4, 0>" : ((c->strip_filt && c->strip_filt_ok) ? "lin_outside_strip<8, 8, 1>" : "lin_outside_strip<8, 8, 0>")) : !c->has_mc ? "" : lin ? ((pairs && (c->lin_w == 4 || c->lin_w == 8)) ? "lin_outside_pair<" + w + ", " + targs + ">" : pre + "outside_diag<" + (vienna ? "8" : w) + ", " + targs + ">")
                                      : vienna ? "mcv_outside_diag" : "mc_outside_diag";
     names[2] = !c->has_dx ? "" : vienna ? (c->hybrid == RH_HYBRID_COFOLD ? (c->last_dx_path == 1 ? "vlin_inside_diag<8, 16, true> + vlin_outside_diag<8, 16, true> (s1+s2)"
                                                                                          : "mcv_inside_diag + mcv_outside_diag (s1+s2)") : (c->last_dx_path == 1 ? "dxvl_sweep4" : "dxv_sweep_diag")) : c->last_dx_path == 1 ? ((c->dx_quad && c->dx_w != 2 && c->dx_w != 8) ? std::string(c->dx_strip ? "dxl_strip8" : "dxl_sweep4") : "dxl_sweep<" + std::to_string(c->dx_w == 2 || c->dx_w == 8 ? c->dx_w : 4) + ">") : "dx_sweep_diag";

@@ -940,7 +940,8 @@ def test_sweep_organisations_agree(hotlib, oracle, monkeypatch):
         o = oracle.inference(s)
         assert abs(z - o["logZ"]) < 1e-9
         assert_prob_close(bp, o["post"], rel=REL, what="default n=%d" % len(s))
-    for env in ({"RH_STRIP": "0"}, {"RH_STRIP": "1"}, {"RH_STRIP": "2"}, {"RH_STRIP_W": "4"}, {"RH_STRIP_XCD": "0"}, {"RH_FAR2": "1"},
+    # (RH_STRIP_FILT=0: the dense single-branch filter instead of the factored one, A(t) B(|l1-l2|) + sparse residual)
+    for env in ({"RH_STRIP_FILT": "0"}, {"RH_STRIP": "0"}, {"RH_STRIP": "1"}, {"RH_STRIP": "2"}, {"RH_STRIP_W": "4"}, {"RH_STRIP_XCD": "0"}, {"RH_FAR2": "1"},
                 {"RH_STRIP": "0", "RH_FAR2": "1"}, {"RH_STRIP": "0", "RH_LOOKAHEAD": "1"}, {"RH_STRIP": "0", "RH_LOOKAHEAD": "0"}, {"RH_FAR_PK": "0"},
                 {"RH_STRIP": "0", "RH_LOOKAHEAD": "0", "RH_LIN_W": "8"}, {"RH_STRIP": "0", "RH_LIN_W": "8"}, {"RH_DX_W": "8"}, {"RH_DX_QUAD": "0"}):
         got, got_pairs = run(env)
