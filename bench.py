@@ -160,6 +160,145 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
+def sweep_of(kernel):
+    """Which sweep of a step a kernel name (as a kernel trace prints it) belongs to."""
+    k = kernel
+    if "pack_tiles<0>" in k:
+        return "inside"
+    if "pack_tiles<1>" in k:
+        return "outside"
+    if any(t in k for t in ("dxl_", "dxvl_", "dxv_", "dx_sweep", "dx_logz", "dx_posterior")):
+        return "duplex"
+    if any(t in k for t in ("inside", "lin_init", "f5i", "co_seed")):
+        return "inside"
+    if any(t in k for t in ("outside", "lin_finish", "vlin_finish", "f5o", "mc_unpaired", "_acc_")):
+        return "outside"
+    return "other"
+
+
+def load_traffic(model, n, batch, hp=None):
+    """Counter traffic of (model, n, pairs per step) from profiles/pmc_traffic.json -- only if it was measured on the current kernel
+    sources.  Returns (kernels dict or None, note)."""
+    key = "%s_n%d_b%d" % (model, n, batch) + ("_duplex" if hp == "duplex" else "")
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(key)
+    except (OSError, ValueError):
+        return None, "profiles/pmc_traffic.json unreadable"
+    if not tj:
+        return None, "not profiled (no entry %s in profiles/pmc_traffic.json)" % key
+    if tj.get("source_hash") != source_hash():
+        return None, "profiles/pmc_traffic.json: entry %s was measured on other kernel sources" % key
+    return tj.get("kernels") or None, None
+
+
+def measure_roofline(ctx, pairs, model, n, batch, vienna, cofold, hp, resident_ms, torch, with_copy):
+    """The roofline object of one workload, from one context that has `pairs` uploaded and computed.
+    * isolated sweeps: rh_set_overlap(0), HIP events around each sweep on its own stream (3 passes);
+    * the dominant sweep's KERNEL: average launch duration measured live by event pairs around every launch of that kernel class
+      (rh_set_kernel_timing; 2 passes) -- what a kernel trace of `bench.py --isolate` reports for it;
+    * traffic: calibrated counter bytes (profiles/pmc_traffic.json, stamped with the kernel-source hash) of that kernel per launch, of
+      EVERY kernel of the sweep, and of every kernel of the step; null when these sources were not profiled -- then `frac` is null too:
+      the algorithmic figure (operand touches of the reference recurrences) exceeds the peak as soon as operands are reused on chip
+      and is reported under alg_* only;
+    * fp64: FLOP = algorithmic bytes / 8 (one FMA per two operand touches), and the block products' share measured on their own."""
+    from ractip_amd import balg
+    ctx.set_overlap(False)
+    iso = np.zeros(4)
+    nl = [0, 0, 0]
+    for _ in range(3):
+        ctx.batch_compute()
+        ms, nl = ctx.batch_timings()
+        iso += np.array(ms) / 3
+    ctx.set_overlap(True)
+    names = ctx.batch_kernels()
+    # algorithmic bytes (counted exactly on the first pairs and scaled: the pairs are i.i.d. sequences of one length)
+    b = {"mc_inside": 0.0, "mc_outside": 0.0, "duplex": 0.0, "total": 0.0}
+    bk = {"inside": 0.0, "inside_far": 0.0, "outside": 0.0, "outside_far": 0.0}
+    counted = pairs if len(pairs[0][0]) < 200 else pairs[:max(1, min(len(pairs), 8 if n <= 600 else 2))]
+    scale = len(pairs) / len(counted)
+    for s1, s2 in counted:
+        pb = balg.pair_bytes(s1, s2)
+        for k in b:
+            b[k] += pb[k] * scale
+        pk = balg.pair_bytes_by_kernel(s1, s2)
+        for k in bk:
+            bk[k] += pk[k] * scale
+    if cofold:
+        sample = pairs[:2] if n <= 600 else pairs[:1]
+        co = sum(8 * sum(sum(v) for v in balg.mccaskill_counts(s1 + s2).values()) for s1, s2 in sample) * len(pairs) / len(sample)
+        b["total"] += co - b["duplex"]
+        b["duplex"] = co
+    sweeps = {}
+    for idx, (sname, bytes_) in enumerate((("inside", b["mc_inside"]), ("outside", b["mc_outside"]), ("duplex", b["duplex"]))):
+        fine, far, n_far = names[idx]
+        if not fine or nl[idx] == 0 or iso[idx] <= 0:
+            continue
+        sweeps[sname] = {"kernel": fine, "block_product_kernel": far or None, "launches_per_step": int(nl[idx]), "of_which_block_product": int(n_far),
+                         "isolated_ms_per_step": float(iso[idx]), "alg_GB_per_step": bytes_ / 1e9,
+                         "fp64_TFLOPs": bytes_ / 8.0 / (iso[idx] / 1e3) / 1e12}
+    dom = max(sweeps, key=lambda k: sweeps[k]["isolated_ms_per_step"])
+    sd = sweeps[dom]
+    cls = {"inside": 0, "outside": 2, "duplex": 4}[dom]
+    k_us, k_launches = ctx.kernel_class_times(cls, computes=2)
+    far_us = far_launches = None
+    if sd["of_which_block_product"] and dom != "duplex":   # (the two-molecule sweeps of the Vienna-BL model share classes 0-3 with the folds)
+        far_us, far_launches = ctx.kernel_class_times(cls + 1, computes=2)
+    alg_fine = bk.get(dom, sd["alg_GB_per_step"] * 1e9) if dom != "duplex" else b["duplex"]
+    kern, note = load_traffic(model, n, batch, hp)
+    per = lambda name: next((v for k2, v in (kern or {}).items() if name and name.split("(")[0] in k2), None)
+    kt = per(sd["kernel"])
+    traffic = kt["bytes_per_dispatch"] if kt else None
+    sweep_bytes = step_bytes = None
+    by_kernel = {}
+    if kern:
+        step_bytes = sum(v["bytes_per_dispatch"] * v["dispatches_per_step"] for v in kern.values())
+        sweep_bytes = sum(v["bytes_per_dispatch"] * v["dispatches_per_step"] for k2, v in kern.items() if sweep_of(k2) == dom)
+        by_kernel = {k2.replace("void ", "").replace("rh::", ""): {"sweep": sweep_of(k2), "MB_per_dispatch": round(v["bytes_per_dispatch"] / 1e6, 3),
+                                                                      "dispatches_per_step": round(v["dispatches_per_step"], 2)} for k2, v in kern.items()}
+    launch_s = k_us * 1e-6
+    ach = traffic / 1e9 / launch_s if traffic else None
+    comp_step = compulsory_bytes(pairs, vienna, cofold)
+    fp64_whole = b["total"] / 8.0 / (resident_ms / 1e3) / 1e12
+    hbm_whole = (step_bytes / 1e9 / (resident_ms / 1e3)) if step_bytes else None
+    far_flops = None
+    if far_us:
+        # block products of the dominant sweep: FLOP = 2 x (k-terms the product kernels take over), time = their launches alone (live events)
+        far_bytes = bk.get(dom + "_far", 0.0)
+        far_flops = {"GFLOP_per_step": far_bytes / 8.0 / 1e9, "ms_per_step": far_us * far_launches / 1e3, "launches_per_step": far_launches,
+                     "TFLOPs": far_bytes / 8.0 / (far_us * far_launches * 1e-6) / 1e12}
+        far_flops["fp64_frac"] = far_flops["TFLOPs"] / FP64_PEAK_TFLOPS
+    hbm_frac = ach / HBM_PEAK_GBS if ach else None
+    fp_frac_k = alg_fine / 8.0 / (k_us * 1e-6 * k_launches) / 1e12 / FP64_PEAK_TFLOPS if k_launches else None
+    bound = "hbm"
+    if hbm_whole is not None and fp64_whole / FP64_PEAK_TFLOPS > hbm_whole / HBM_PEAK_GBS:
+        bound = "fp64"
+    r = {"bound": bound, "kernel": sd["kernel"], "sweep": dom,
+         "avg_launch_us": k_us, "launches_per_step": k_launches,
+         "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_frac, "traffic": traffic, "traffic_note": note,
+         "achieved_basis": "calibrated rocprofv3 counter bytes of this kernel per launch (profiles/pmc_traffic.json) / its live event-pair launch duration" if traffic
+                           else "no counter profile of these kernel sources: achieved and frac are null (the algorithmic figure is under alg_*)",
+         "alg_bytes_per_launch": alg_fine / k_launches if k_launches else None,
+         "alg_GBs": alg_fine / 1e9 / (k_us * 1e-6 * k_launches) if k_launches else None,
+         "alg_over_peak": alg_fine / 1e9 / (k_us * 1e-6 * k_launches) / HBM_PEAK_GBS if k_launches else None,
+         "fp64_frac": fp_frac_k,
+         "sweep_level": {"isolated_ms_per_step": sd["isolated_ms_per_step"], "launches_per_step": sd["launches_per_step"],
+                         "traffic_GB_per_step": sweep_bytes / 1e9 if sweep_bytes else None,
+                         "achieved_GBs": sweep_bytes / 1e9 / (sd["isolated_ms_per_step"] / 1e3) if sweep_bytes else None,
+                         "frac": sweep_bytes / 1e9 / (sd["isolated_ms_per_step"] / 1e3) / HBM_PEAK_GBS if sweep_bytes else None,
+                         "block_products": far_flops},
+         "whole_path": {"ms_per_step_device_resident": resident_ms, "traffic_GB_per_step": step_bytes / 1e9 if step_bytes else None,
+                        "achieved_GBs": hbm_whole, "hbm_frac": hbm_whole / HBM_PEAK_GBS if hbm_whole else None,
+                        "compulsory_GB_per_step": comp_step / 1e9, "traffic_over_compulsory": step_bytes / comp_step if step_bytes else None,
+                        "alg_GB_per_pair": b["total"] / 1e9 / max(1, len(pairs)), "fp64_TFLOPs": fp64_whole, "fp64_frac": fp64_whole / FP64_PEAK_TFLOPS},
+         "peak_fp64_TFLOPs": FP64_PEAK_TFLOPS,
+         "peak_copy_measured": copy_bandwidth_GBs(torch) if with_copy else None,
+         "timing": "avg_launch_us: HIP event pairs around every launch of the kernel, sweeps not overlapping (2 passes after the timed region) = "
+                   "the per-kernel average of `rocprofv3 --kernel-trace --stats -- python3 bench.py --isolate` (profiles/*_kernel_stats.txt); "
+                   "sweeps: HIP events around each whole sweep, 3 passes",
+         "sweeps": sweeps, "traffic_by_kernel": by_kernel}
+    return r
+
+
 def timed_steps(ctxs, pairs, steps, body, fence):
     """`steps` steps, step k on context k % len(ctxs), one host thread per context; wall time of all of them."""
     import threading
@@ -193,23 +332,34 @@ def step_candidates(ctx, pairs):
         ctx.batch_candidates_all(which, th)
 
 
-def quick_rates(ractip_amd, torch, device_index, pairs, steps, model=0):
-    """device-resident and end-to-end (upload -> compute -> 5 scans on the host, two contexts) rates of one more workload"""
-    ctxs = [ractip_amd.Context(device=device_index, model=model) for _ in range(2)]
+def quick_rates(ractip_amd, torch, device_index, pairs, steps, model="contrafold", hp=None):
+    """device-resident and end-to-end (upload -> compute -> 5 scans on the host, two contexts) rates of one more workload, with its
+    own roofline object"""
+    vienna = model == "vienna"
+    cofold = vienna and (hp or "cofold") == "cofold"
+    mid = ractip_amd.hot.RH_MODEL_VIENNA_BL if vienna else ractip_amd.hot.RH_MODEL_CONTRAFOLD
+    ctxs = [ractip_amd.Context(device=device_index, model=mid) for _ in range(2)]
     try:
         for c in ctxs:
+            if vienna:
+                c.set_hybrid(cofold)
             c.batch_upload(pairs)
             c.batch_compute()
         fence = torch.cuda.synchronize
         dt_res = timed_steps(ctxs[:1], pairs, steps, lambda c, p: c.batch_compute(), fence)
         ms, nl = ctxs[0].batch_timings()
         dt_e2e = timed_steps(ctxs, pairs, 2 * steps, step_candidates, fence)
-        names = ctxs[0].batch_kernels()
-        return {"pairs_per_step": len(pairs), "steps": steps,
-                "device_resident_pairs_per_s": len(pairs) * steps / dt_res, "ms_per_step_device_resident": dt_res / steps * 1e3,
-                "value_pairs_per_s": len(pairs) * 2 * steps / dt_e2e,
-                "phase_ms": {"mccaskill_inside": ms[0], "mccaskill_outside": ms[1], "duplex": ms[2]},
-                "kernels": [k[0] for k in names], "path": ctxs[0].last_path()}
+        n = max(len(pairs[0][0]), len(pairs[0][1]))
+        out = {"pairs_per_step": len(pairs), "steps": steps, "model": model,
+               "device_resident_pairs_per_s": len(pairs) * steps / dt_res, "ms_per_step_device_resident": dt_res / steps * 1e3,
+               "value_pairs_per_s": len(pairs) * 2 * steps / dt_e2e,
+               "phase_ms": {"mccaskill_inside": ms[0], "mccaskill_outside": ms[1], "duplex": ms[2]},
+               "path": ctxs[0].last_path()}
+        try:
+            out["roofline"] = measure_roofline(ctxs[0], pairs, model, n, len(pairs), vienna, cofold, hp, dt_res / steps * 1e3, torch, False)
+        except Exception as e:   # noqa: BLE001 -- the rates above stay
+            out["roofline_error"] = repr(e)
+        return out
     finally:
         for c in ctxs:
             c.close()
@@ -235,7 +385,9 @@ def main():
     ap.add_argument("--hp", default=None, choices=["duplex", "cofold"],
                     help="vienna only: hp from pf_duplex (the --duplex branch) or from the two-molecule ensemble (default branch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-also", action="store_true", help="skip the extra n=2000 / z-score measurements of the default run")
+    ap.add_argument("--no-also", action="store_true", help="skip the extra n=2000 / z-score / Vienna-BL measurements of the default run")
+    ap.add_argument("--isolate", action="store_true", help="profiling runs: the sweeps of every step run one after the other (no stream overlap), so a "
+                    "kernel trace of this command reports the isolated per-kernel durations that roofline.avg_launch_us measures live")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only for "
                     "rehearsing the multi-rank path on a one-GPU box, where all ranks share cuda:0)")
     args = ap.parse_args()
@@ -298,13 +450,15 @@ def main():
     cofold = vienna and (args.hp or "cofold") == "cofold"
     # two contexts on one GPU: their steps alternate, so uploads / result copies of one overlap the kernels of the other.
     # Ranks of a multi-GPU run keep one context: the gather is a collective and stays on the main thread.
-    n_ctx = args.contexts or (2 if (world == 1 and n <= 1200) else 1)
+    n_ctx = args.contexts or (2 if (world == 1 and n <= 1200 and not args.isolate) else 1)   # (--isolate: nothing may overlap a timed kernel)
     ctxs = [ractip_amd.Context(device=device_index, model=model_id) for _ in range(n_ctx)]
     for c in ctxs:
         if vienna:
             c.set_hybrid(cofold)
         c.batch_upload(pairs)   # tables allocated, launch graphs captured: outside the timed region
         c.batch_compute()
+        if args.isolate:
+            c.set_overlap(False)
     ctx = ctxs[0]
 
     from ractip_amd import shard
@@ -339,89 +493,14 @@ def main():
         ms_acc[:] += np.array(ms)
     dt_res = timed_steps(ctxs[:1], pairs, args.steps, resident, fence)
 
-    # isolated phase timings (outside the timed region): the duplex sweeps, the McCaskill inside sweep and the outside sweep
-    # run one after the other, each bracketed by HIP events on its own stream, with nothing else on the device --
-    # the per-kernel durations a kernel trace of this command reports (profiles/*_kernel_stats.txt)
-    ctx.set_overlap(False)
-    iso_ms = np.zeros(4)
-    ISO = 3
-    for _ in range(ISO):
-        ctx.batch_compute()
-        iso_ms += np.array(ctx.batch_timings()[0]) / ISO
-    ctx.set_overlap(True)
-    kernel_names = ctx.batch_kernels()
-
     if rank == 0:
         total_pairs = total_per_step * args.steps
-        # algorithmic bytes of rank 0's batch, split by kernel (ractip_amd/balg.py)
-        # (random-pair workload: counted exactly on the first pairs and scaled -- the pairs are i.i.d. sequences of one length;
-        #  the z-score workload is counted in full)
-        b = {"mc_inside": 0, "mc_outside": 0, "duplex": 0, "total": 0}
-        counted = pairs if args.workload == "zscore" else pairs[:max(1, min(len(pairs), 8 if n <= 600 else 2))]
-        scale = len(pairs) / len(counted)
-        for s1, s2 in counted:
-            pb = balg.pair_bytes(s1, s2)
-            for k in b:
-                b[k] += pb[k] * scale
-        if cofold:
-            # hp comes from the McCaskill recurrences over s1+s2: count those instead of the duplex sweeps (first two
-            # pairs counted exactly, scaled to the batch: the pairs are i.i.d. random sequences of one length)
-            sample = pairs[:2] if n <= 600 else pairs[:1]
-            co = sum(8 * sum(sum(v) for v in balg.mccaskill_counts(s1 + s2).values()) for s1, s2 in sample) * len(pairs) / len(sample)
-            b["total"] += co - b["duplex"]
-            b["duplex"] = co
-        ms_mean = ms_acc / args.steps  # HIP-event ms per step: inside sweep, outside sweep, duplex, whole
-        phases = {}
-        for key, bytes_, ms_k, launches in (("mccaskill_inside_phase", b["mc_inside"], ms_mean[0], nl[0]),
-                                            ("mccaskill_outside_phase", b["mc_outside"], ms_mean[1], nl[1]),
-                                            ("duplex_phase", b["duplex"], ms_mean[2], nl[2])):
-            phases[key] = {"alg_GB_per_step": bytes_ / 1e9, "ms_per_step": float(ms_k), "launches": int(launches),
-                           "avg_launch_us": float(ms_k) * 1e3 / max(1, launches)}
-        kernels = {}
-        for idx, (pname, bytes_) in enumerate((("mccaskill_inside_phase", b["mc_inside"]), ("mccaskill_outside_phase", b["mc_outside"]),
-                                               ("duplex_phase", b["duplex"]))):
-            fine, far, n_far = kernel_names[idx]
-            launches = int(nl[idx])
-            if not fine or launches == 0 or iso_ms[idx] <= 0:
-                continue
-            kernels[fine] = {"phase": pname, "launches_per_step": launches, "of_which_block_product": n_far,
-                             "block_product_kernel": far or None, "isolated_ms_per_step": float(iso_ms[idx]),
-                             "avg_launch_us": iso_ms[idx] * 1e3 / launches, "alg_bytes_per_launch": bytes_ / launches,
-                             # one FMA per two operand loads of the reference recurrences: FLOP = algorithmic bytes / 8
-                             "fp64_TFLOPs": bytes_ / 8.0 / (iso_ms[idx] / 1e3) / 1e12}
-        dom = max(kernels, key=lambda k: kernels[k]["isolated_ms_per_step"])
-        kd = kernels[dom]
-        # HBM-side traffic of that sweep: rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, gfx950 correction), collected by
-        # tools/profile_gpu.sh -> tools/pmc_traffic_json.py into profiles/pmc_traffic.json (bytes per dispatch by kernel
-        # name), stamped with the hash of the kernel sources: an entry measured on other kernels is not reported (null)
-        traffic, traffic_note = None, None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("%s_n%d_b%d" % (args.model, n, batch), {})
-            if tj.get("source_hash") != source_hash():
-                traffic_note = "profiles/pmc_traffic.json has no entry measured on these kernel sources" if tj else "not profiled"
-                tj = {}
-
-            def per_dispatch(name):
-                hits = [v for k2, v in tj.items() if name and isinstance(v, float) and name.split("(")[0] in k2]
-                return hits[0] if hits else None
-            tf, tb = per_dispatch(dom), per_dispatch(kd["block_product_kernel"])
-            if tb is not None and (kd["block_product_kernel"] or "").endswith("_pk"):
-                tb += per_dispatch("lin_pack_tiles") or 0.0   # the operand-packing launch that precedes each product
-            if tf is not None and (tb is not None or not kd["of_which_block_product"]):
-                nfine = kd["launches_per_step"] - kd["of_which_block_product"]
-                traffic = (tf * nfine + (tb or 0.0) * kd["of_which_block_product"]) / kd["launches_per_step"]
-            if traffic is None and traffic_note is None:
-                traffic_note = ("this sweep is several kernels (look-ahead pairs + block products shared with the single-molecule folds): "
-                                "per-kernel counter bytes per dispatch are in profiles/pmc_traffic.json under %s_n%d_b%d" % (args.model, n, batch))
-        except (OSError, ValueError):
-            traffic_note = "profiles/pmc_traffic.json unreadable"
-        launch_s = kd["avg_launch_us"] * 1e-6
-        alg_GBs = kd["alg_bytes_per_launch"] / 1e9 / launch_s
-        # `achieved` is what the HBM interface delivered (counter bytes per launch / launch duration) whenever the counters
-        # are known for these kernels: a fraction that can fail.  The algorithmic figure (SURVEY 8d's B_alg per launch /
-        # duration) exceeds the peak as soon as operands are reused on chip and is kept as information only.
-        ach = traffic / 1e9 / launch_s if traffic else alg_GBs
-        comp_step = compulsory_bytes(pairs, vienna, cofold)
+        roof = measure_roofline(ctx, pairs, args.model, n, batch, vienna, cofold, args.hp, dt_res / args.steps * 1e3, torch, world == 1)
+        if args.isolate:
+            ctx.set_overlap(False)
+        ms_mean = ms_acc / args.steps  # HIP-event ms per step inside the device-resident loop: inside sweep, outside sweep, duplex, whole
+        roof["phases_in_loop"] = {"mccaskill_inside_ms": float(ms_mean[0]), "mccaskill_outside_ms": float(ms_mean[1]), "duplex_ms": float(ms_mean[2]),
+                                  "launches": [int(x) for x in nl], "note": "the duplex stream overlaps the McCaskill stream here"}
         line = {
             "metric": ("sequence-pairs/sec (incl. bp+hp+ap DP; host strings in, thresholded matrices out) at n=%d" % n) if args.workload == "pairs"
                       else "z-score DP stage: shuffled pairs/sec (OxyS/fhlA, bp+hp+ap DP per shuffle; host strings in, thresholded matrices out)",
@@ -448,25 +527,7 @@ def main():
                        "scoring": ("Vienna-BL (BL* tables, ViennaRNA-1.8 semantics, up width 15, hp from %s; parity unpinned)"
                                    % ("co_pf_fold(s1+s2)" if cofold else "pf_duplex")) if vienna
                                   else "CONTRAfold complementary (708 weights)"},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "achieved_basis": "pmc counters (FETCH_SIZE x2 + WRITE_SIZE) per launch / HIP-event launch duration" if traffic
-                                           else "algorithmic bytes (no counter profile of these kernel sources): NOT a bound, may exceed 1",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
-                         "traffic_frac": (traffic / 1e9 / launch_s / HBM_PEAK_GBS) if traffic else None,
-                         "traffic_over_compulsory": (traffic * kd["launches_per_step"] / comp_step) if traffic else None,
-                         "alg_over_peak": alg_GBs / HBM_PEAK_GBS, "alg_GBs": alg_GBs,
-                         "fp64_frac": kd["fp64_TFLOPs"] / FP64_PEAK_TFLOPS,
-                         "peak_copy_measured": copy_bandwidth_GBs(torch) if world == 1 else None,
-                         "alg_bytes_per_launch": kd["alg_bytes_per_launch"],
-                         "avg_launch_us": kd["avg_launch_us"],
-                         "timing": "HIP events around the whole sweep on its own stream, sweeps run one after the other "
-                                   "(3 passes after the timed region); 'phases' below = the same events inside the device-resident loop, "
-                                   "where the duplex stream overlaps the McCaskill stream",
-                         "kernels": kernels,
-                         "whole_path": {"alg_GB_per_pair": b["total"] / 1e9 / max(1, len(pairs)),
-                                        # every DP table written once and read once (SURVEY 8d's "compulsory bytes")
-                                        "compulsory_GB_per_pair": comp_step / 1e9 / max(1, len(pairs))},
-                         "phases": phases},
+            "roofline": roof,
         }
         if world == 1:
             # dense results instead of the thresholded lists: all five matrices into page-locked host buffers, two contexts
@@ -494,6 +555,9 @@ def main():
                 from ractip_amd import shard as _shard
                 fa = [l.strip() for l in open(os.path.join(ROOT, "ractip_amd", "data", "config5_OxyS_fhlA.fa")) if not l.startswith(">")]
                 also["zscore_1000_shuffles"] = quick_rates(ractip_amd, torch, device_index, _shard.zscore_shuffles(fa[0], fa[1], 12, 1000, 1), 10)
+                # the reference's DEFAULT path (Vienna-BL model, parity unpinned): rnafold x2 + accessibility + hp from co_pf_fold / pf_duplex
+                also["vienna_n500_cofold"] = quick_rates(ractip_amd, torch, device_index, random_pairs(256, 500, seed=12345), 3, model="vienna", hp="cofold")
+                also["vienna_n500_duplex"] = quick_rates(ractip_amd, torch, device_index, random_pairs(256, 500, seed=12345), 3, model="vienna", hp="duplex")
             except Exception as e:   # noqa: BLE001 -- the headline line must still be printed
                 also["error"] = repr(e)
             line["also"] = also

@@ -204,6 +204,14 @@ int rh_batch_kernels(rh_ctx* ctx, const char* fine[3], const char* far[3], int n
  * kernel).  Results are unchanged.  Default: overlap on. */
 int rh_set_overlap(rh_ctx* ctx, int on);
 
+/* Measurement aid: rh_set_kernel_timing(ctx, cls) brackets every launch of ONE class of sweep kernels by a HIP event pair on its
+ * stream (cls 0 = McCaskill inside sweep kernel, 1 = its block products incl. operand packing, 2 = outside sweep kernel, 3 = its
+ * block products, 4 = duplex sweep kernel; -1 = off, the default) -- launch graphs are bypassed meanwhile.  After rh_batch_compute,
+ * rh_kernel_times returns how many launches of that class ran and the sum of their durations: the live counterpart of the
+ * per-kernel average of a rocprofv3 kernel trace (bench.py: roofline.avg_launch_us).  Results are unchanged. */
+int rh_set_kernel_timing(rh_ctx* ctx, int cls);
+int rh_kernel_times(rh_ctx* ctx, int* n_launches, double* total_ms);
+
 /* Which problems of the last rh_batch_compute left the double range on the scaled linear path and were recomputed by the
  * log-space kernels (rh_last_path / rh_last_hybrid_path == 3): which = 0: sequence indices (2p = s1 of pair p), 1: pair
  * indices of the duplex.  Only those problems are recomputed; every other problem keeps its linear-path result.  Writes at

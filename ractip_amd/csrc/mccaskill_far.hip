@@ -265,6 +265,8 @@ __device__ __forceinline__ size_t pk_tile(int nb, int P, int Q) { return ((size_
 // blocks are the tiles of block diagonal 2 with the entries (first index u, second index v), v < u, removed -- the same mask
 // whichever product uses the tile (FM1 as the K = I+2 operand inside / the K = I-2 operand of FMOF, FM as K = J-2 / K = J+2),
 // and such a tile is used by no other product, so it is simply packed masked.
+// SWEEP only names the launch (0: issued by the inside sweep, 1: by the outside sweep), so that a kernel trace / counter pass attributes it
+template <int SWEEP>
 __global__ __launch_bounds__(256) void lin_pack_tiles(McBatch B, int Dblk, int outside, int banded)
 {
     __shared__ double T[16][17];
@@ -472,6 +474,8 @@ __global__ __launch_bounds__(256) void lin_far2_outside(McBatch B, int D2, int l
     }
 }
 
+template __global__ void lin_pack_tiles<0>(McBatch, int, int, int);
+template __global__ void lin_pack_tiles<1>(McBatch, int, int, int);
 template __global__ void lin_far_inside<16>(McBatch, int);
 template __global__ void lin_far_inside<32>(McBatch, int);
 template __global__ void lin_far_outside<16>(McBatch, int);

@@ -39,7 +39,7 @@ template <int BS> __global__ void lin_far_inside(McBatch B, int D);
 template <int BS> __global__ void lin_far_outside(McBatch B, int D);
 __global__ void lin_far_inside_mfma(McBatch B, int D);
 __global__ void lin_far_outside_mfma(McBatch B, int D);
-__global__ void lin_pack_tiles(McBatch B, int Dblk, int outside, int banded);
+template <int SWEEP> __global__ void lin_pack_tiles(McBatch B, int Dblk, int outside, int banded);
 template <int KD, int W, int FILT> __global__ void lin_inside_strip(McBatch B, const LinModel* __restrict__ L, const double* __restrict__ wT, int d0, int f5_lo, double lam_d0, int pin);
 template <int KD, int W, int FILT> __global__ void lin_outside_strip(McBatch B, const LinModel* __restrict__ L, const double* __restrict__ wT, int d0, int f5_hi, int f5_lo, int pin, int* __restrict__ bad);
 __global__ void lin_f5i_tail(McBatch B, const LinModel* __restrict__ L, int jlo);
@@ -383,6 +383,9 @@ struct rh_ctx {
     int n_launch[3] = {0, 0, 0};
     int n_far[3] = {0, 0, 0};      // of which block-product launches (mccaskill_far.hip)
     bool overlap = true;           // false: duplex, inside and outside sweeps run one after the other (isolated phase timings)
+    int time_cls = -1;             // rh_set_kernel_timing: sweep-kernel class whose launches are bracketed by event pairs (-1: none)
+    std::vector<hipEvent_t> tev;   // event pool of the timed class (pairs), tev_n used by the last compute
+    size_t tev_n = 0;
 };
 
 namespace {
@@ -407,7 +410,15 @@ int fail(rh_ctx* c, int code, const char* fmt, ...)
     } while (0)
 
 // launch of one sweep kernel (class = 0 inside, 1 inside block products, 2 outside, 3 outside block products, 4 duplex)
-#define KLAUNCH(c, cls, kern, grid, block, stream, ...) hipLaunchKernelGGL(kern, grid, block, 0, stream, __VA_ARGS__)
+// Measurement aid (rh_set_kernel_timing): launches of class `time_cls` are bracketed by a HIP event pair on their stream, so that
+// bench.py can report the average duration of ONE kernel class live (what a kernel trace reports per kernel); off by default.
+#define KLAUNCH(c, cls, kern, grid, block, stream, ...)                                                   \
+    do {                                                                                                  \
+        const bool timed_ = (c)->time_cls == (cls) && (c)->tev_n + 2 <= (c)->tev.size();                  \
+        if (timed_) (void)hipEventRecord((c)->tev[(c)->tev_n++], stream);                                 \
+        hipLaunchKernelGGL(kern, grid, block, 0, stream, __VA_ARGS__);                                    \
+        if (timed_) (void)hipEventRecord((c)->tev[(c)->tev_n++], stream);                                 \
+    } while (0)
 
 // grow-only device buffer
 int ensure(rh_ctx* c, void** p, size_t* cap, size_t bytes, bool zero)
@@ -752,7 +763,7 @@ static int far_inside_step(rh_ctx* c, const McBatch& B, hipStream_t st, int D, i
 {
     if (!c->far_pk) { KLAUNCH(c, 1, lin_far_inside_mfma, dim3(last_block - D + 1, B.ns), dim3(256), st, B, D); return 1; }
     const int l2 = far_two_level(c, B);
-    KLAUNCH(c, 1, lin_pack_tiles, dim3(B.nb - (D - 2), B.ns, 2), dim3(256), st, B, D - 2, 0, banded);
+    KLAUNCH(c, 1, lin_pack_tiles<0>, dim3(B.nb - (D - 2), B.ns, 2), dim3(256), st, B, D - 2, 0, banded);
     if (l2 && (D + 3) % 4 == 0) {   // D = 4*D2-3: every operand tile of macro block diagonal D2 is packed now
         const int D2 = (D + 3) / 4, last2 = (B.nmax - 1) / 64;
         if (D2 >= 4 && D2 <= last2) KLAUNCH(c, 1, lin_far2_inside, dim3(last2 - D2 + 1, B.ns), dim3(256), st, B, D2, l2);
@@ -765,16 +776,16 @@ static int far_outside_begin(rh_ctx* c, const McBatch& B, hipStream_t st, int la
 {
     if (!c->far_pk) return 0;
     c->far2_next = (B.nmax - 1) / 64;   // macro block diagonals whose 64-block products are still to be launched (descending)
-    if (repack2 && last_block - 1 > 2) KLAUNCH(c, 3, lin_pack_tiles, dim3(B.nb - 2, B.ns, 2), dim3(256), st, B, 2, 0, banded);
+    if (repack2 && last_block - 1 > 2) KLAUNCH(c, 3, lin_pack_tiles<1>, dim3(B.nb - 2, B.ns, 2), dim3(256), st, B, 2, 0, banded);
     for (int Dblk = std::max(2, last_block - 1); Dblk <= last_block; Dblk++)
-        KLAUNCH(c, 3, lin_pack_tiles, dim3(B.nb - Dblk, B.ns, 2), dim3(256), st, B, Dblk, 0, banded);
+        KLAUNCH(c, 3, lin_pack_tiles<1>, dim3(B.nb - Dblk, B.ns, 2), dim3(256), st, B, Dblk, 0, banded);
     return 0;
 }
 static int far_outside_step(rh_ctx* c, const McBatch& B, hipStream_t st, int D, int last_block)
 {
     if (!c->far_pk) { KLAUNCH(c, 3, lin_far_outside_mfma, dim3(last_block - D + 1, B.ns, 2), dim3(256), st, B, D); return 1; }
     const int l2 = far_two_level(c, B);
-    if (D + 2 <= last_block) KLAUNCH(c, 3, lin_pack_tiles, dim3(B.nb - (D + 2), B.ns, 1), dim3(256), st, B, D + 2, 1, 0);
+    if (D + 2 <= last_block) KLAUNCH(c, 3, lin_pack_tiles<1>, dim3(B.nb - (D + 2), B.ns, 1), dim3(256), st, B, D + 2, 1, 0);
     if (l2) {   // macro block diagonal D2 holds tile block diagonals 4*D2-3 .. 4*D2+3: its products go first, their FM2o tiles (block diagonals >= 4*D2+5) are packed
         const int last2 = (B.nmax - 1) / 64;
         for (; c->far2_next >= 0 && 4 * c->far2_next + 3 >= D; c->far2_next--)
@@ -1136,7 +1147,7 @@ size_t shape_key(const rh_ctx* c, int which);
 template <class F>
 int run_graphed(rh_ctx* c, GraphSlot& g, size_t key, hipStream_t stream, int* launch_counter, int* far_counter, F&& launch)
 {
-    if (!c->use_graphs) return launch();
+    if (!c->use_graphs || c->time_cls >= 0) return launch();   // (timed launches are host launches: events between graph nodes would be captured)
     if (!g.exec || g.key != key) {
         if (g.exec) { HIP_TRY(c, hipGraphExecDestroy(g.exec)); g.exec = nullptr; }
         hipGraph_t graph = nullptr;
@@ -1563,6 +1574,7 @@ int compute_once(rh_ctx* c)
     HIP_TRY(c, hipSetDevice(c->device));
     c->deferred = false;
     c->went_log = false;
+    c->tev_n = 0;
     c->n_launch[0] = c->n_launch[1] = c->n_launch[2] = 0;
     c->n_far[0] = c->n_far[1] = c->n_far[2] = 0;
     c->last_path = 0;
@@ -1994,6 +2006,7 @@ void rh_destroy(rh_ctx* c)
     for (int r = 0; r < rh_ctx::kRungs; r++) { if (c->d_lin_r[r]) (void)hipFree(c->d_lin_r[r]); if (c->d_wT_r[r]) (void)hipFree(c->d_wT_r[r]); }
     for (GraphSlot* g : {&c->g_in, &c->g_out, &c->g_dx}) if (g->exec) (void)hipGraphExecDestroy(g->exec);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : c->tev) if (e) (void)hipEventDestroy(e);
     if (c->s_mc) (void)hipStreamDestroy(c->s_mc);
     if (c->s_dx) (void)hipStreamDestroy(c->s_dx);
     for (int k = 0; k <= rh_ctx::kVRungs; k++) {
@@ -2349,6 +2362,37 @@ int rh_set_scale_memory(rh_ctx* c, int on)
     if (!c) return RH_ERR_ARG;
     c->scale_memory = on != 0;
     if (!on) { c->lin_primary = -1; c->vlin_primary = -1; }
+    return RH_OK;
+}
+
+int rh_set_kernel_timing(rh_ctx* c, int cls)
+{
+    if (!c || cls < -1 || cls > 4) return RH_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (cls >= 0 && c->tev.empty()) {
+        c->tev.resize(8192);
+        for (auto& e : c->tev) HIP_TRY(c, hipEventCreate(&e));
+    }
+    c->time_cls = cls;
+    c->tev_n = 0;
+    return RH_OK;
+}
+
+int rh_kernel_times(rh_ctx* c, int* n_launches, double* total_ms)
+{
+    if (!c || !n_launches || !total_ms) return RH_ERR_ARG;
+    if (!c->computed) return fail(c, RH_ERR_ARG, "no computed batch");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->s_mc));
+    HIP_TRY(c, hipStreamSynchronize(c->s_dx));
+    double tot = 0.0;
+    for (size_t k = 0; k + 1 < c->tev_n; k += 2) {
+        float ms = 0.f;
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->tev[k], c->tev[k + 1]));
+        tot += ms;
+    }
+    *n_launches = (int)(c->tev_n / 2);
+    *total_ms = tot;
     return RH_OK;
 }
 

@@ -19,7 +19,7 @@ EXPORTS = [
     "rh_batch_upload", "rh_batch_compute", "rh_batch_results", "rh_batch_candidates",
     "rh_batch_timings", "rh_batch_device_views", "rh_batch_logz", "rh_batch_candidates_all", "rh_batch_layout",
     "rh_batch_results_all", "rh_set_max_w", "rh_get_max_w", "rh_set_overlap", "rh_batch_kernels", "rh_set_hybrid", "rh_last_hybrid_path", "rh_fold_constrained", "rh_cofold_constrained",
-    "rh_host_alloc", "rh_host_free", "rh_batch_fallbacks", "rh_create_vienna", "rh_vienna_semantics", "rh_set_scale_memory",
+    "rh_host_alloc", "rh_host_free", "rh_batch_fallbacks", "rh_create_vienna", "rh_vienna_semantics", "rh_set_scale_memory", "rh_set_kernel_timing", "rh_kernel_times",
     "rh_debug_vienna_cell", "rh_debug_vienna_value",   # loader inspection (host only; used by the CPU tests of the loader)
 ]
 
@@ -59,6 +59,10 @@ def load_library():
     L.rh_last_path.argtypes = [vp]
     L.rh_set_overlap.argtypes = [vp, ci]
     L.rh_set_scale_memory.argtypes = [vp, ci]
+    L.rh_set_kernel_timing.argtypes = [vp, ci]
+    L.rh_set_kernel_timing.restype = ci
+    L.rh_kernel_times.argtypes = [vp, vp, vp]
+    L.rh_kernel_times.restype = ci
     L.rh_set_scale_memory.restype = ci
     L.rh_last_hybrid_path.argtypes = [vp]
     L.rh_last_hybrid_path.restype = ci
@@ -329,6 +333,25 @@ class Context:
         """True: the next batch starts on the scale exponent most of the last one needed (faster on streams of one kind of input;
         a sequence's bits then depend on the context's history).  Default off."""
         self._check(self.L.rh_set_scale_memory(self.h, 1 if on else 0))
+
+    def kernel_class_times(self, cls, computes=1):
+        """Average duration (us) and launches per compute of ONE class of sweep kernels (rh_set_kernel_timing: 0 inside sweep kernel,
+        1 its block products + packing, 2 outside sweep kernel, 3 its block products, 4 duplex sweep kernel), measured live with HIP
+        event pairs around every launch of that class over `computes` passes of the current batch, phases not overlapping."""
+        self._check(self.L.rh_set_kernel_timing(self.h, cls))
+        self._check(self.L.rh_set_overlap(self.h, 0))
+        n_tot, ms_tot = 0, 0.0
+        try:
+            for _ in range(computes):
+                self.batch_compute()
+                n, ms = ctypes.c_int(), ctypes.c_double()
+                self._check(self.L.rh_kernel_times(self.h, ctypes.byref(n), ctypes.byref(ms)))
+                n_tot += n.value
+                ms_tot += ms.value
+        finally:
+            self.L.rh_set_kernel_timing(self.h, -1)
+            self.L.rh_set_overlap(self.h, 1)
+        return (ms_tot * 1e3 / n_tot if n_tot else 0.0), n_tot / float(computes)
 
     def set_overlap(self, on):
         """False: phases run one after the other (isolated per-phase device times in batch_timings)."""

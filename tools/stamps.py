@@ -5,7 +5,7 @@ average ticks per workgroup between consecutive RH_STAMP sites (mccaskill_strip.
 import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["RACTIP_HOT_LIB"] = os.path.join(ROOT, "ractip_amd", "libractip_hot_stamps.so")
+os.environ["RACTIP_HOT_LIB"] = os.environ.get("RH_STAMPS_LIB") or os.path.join(ROOT, "ractip_amd", "libractip_hot_stamps.so")   # RH_STAMPS_LIB: another tuning build
 import numpy as np
 import ractip_amd
 from ractip_amd import hot
