@@ -330,24 +330,39 @@ __global__ __launch_bounds__(256) void mc_outside_diag(McBatch B, const ScoreMod
 // ---------------------------------------------------------------------------------
 // width-1 accessibility, /root/reference/src/ractip.cpp:213-222:
 //   up[i] = max(0, 1 - sum_{j<i} bp(j,i) - sum_{j>i} bp(i,j)),  letters 1-based
-// one wavefront per letter.
+// One workgroup per 64 letters a0+1 .. a0+64.  Column part (pairs (b, a), b < a): lane <-> column a, the four wavefronts take the
+// rows b = 1+w, 5+w, ..: every load is a contiguous 512-byte run of a row of the triangular table (the per-letter form read the
+// column with a stride of a row: one 128-byte line per element).  Row part (pairs (a, b), b > a): wavefront w takes the letters
+// a0+1+w, +4, ..; lanes run along the row.  Fixed summation order: the bits of up do not depend on the batch.
 __global__ __launch_bounds__(256) void mc_unpaired(McBatch B)
 {
+    __shared__ double colsum[4][64];
+    __shared__ double rowsum[64];
     const int sq = blockIdx.y;
     const int n = B.n[sq];
-    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (wave >= n) return;
-    const int a = wave + 1;
+    const int a0 = blockIdx.x * 64;
+    if (a0 >= n) return;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const double* __restrict__ bp = B.bp + (size_t)sq * B.tri_stride;
-    double acc = 0.0;
-    for (int b = 1 + lane; b <= n; b += 64) {
-        if (b == a) continue;
-        const int lo = b < a ? b : a, hi = b < a ? a : b;
-        acc += bp[tri_offset(n, lo) + hi];
+    {
+        const int a = a0 + 1 + lane;
+        double acc = 0.0;
+        const int bmax = a0 + 64 < n ? a0 + 64 : n;   // rows b < a <= bmax
+        for (int b = 1 + w; b < bmax; b += 4)
+            if (b < a && a <= n) acc += bp[tri_offset(n, b) + a];
+        colsum[w][lane] = acc;
     }
-    acc = wave_sum(acc);
-    if (lane == 0) B.up[(size_t)sq * B.ld + wave] = fmax(0.0, 1.0 - acc);
+    for (int q = w; q < 64; q += 4) {
+        const int a = a0 + 1 + q;
+        double acc = 0.0;
+        if (a <= n)
+            for (int b2 = a + 1 + lane; b2 <= n; b2 += 64) acc += bp[tri_offset(n, a) + b2];
+        acc = wave_sum(acc);
+        if (lane == 0) rowsum[q] = acc;
+    }
+    __syncthreads();
+    if (w == 0 && a0 + 1 + lane <= n)
+        B.up[(size_t)sq * B.ld + a0 + lane] = fmax(0.0, 1.0 - (((colsum[0][lane] + colsum[1][lane]) + (colsum[2][lane] + colsum[3][lane])) + rowsum[lane]));
 }
 
 }  // namespace rh

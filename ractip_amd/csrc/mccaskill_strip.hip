@@ -69,9 +69,25 @@ extern "C" int rh_debug_stamps(unsigned long long* out, int reset)
     if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)) != hipSuccess) return -1; }
     return 0;
 }
+// -DRH_STAMPS=3: per-workgroup timeline of ONE inside launch (d0 == 256): {XCC id << 32 | HW id, realtime at start, after the staging
+// barrier, after the pre-phase barrier, at the end} per workgroup, s_memrealtime (100 MHz, one clock for the whole device)
+__device__ unsigned long long g_trace[5 * 16384];
+extern "C" int rh_debug_trace(unsigned long long* out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), sizeof(g_trace)) == hipSuccess ? 0 : -1;
+}
+#if RH_STAMPS == 3
+#define RH_TRACE(slot) do { if (threadIdx.x == 0 && d0 == 256) { const unsigned lin_ = blockIdx.x + blockIdx.y * gridDim.x; if (lin_ < 16384) g_trace[5 * lin_ + (slot)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#define RH_TRACE_ID() do { if (threadIdx.x == 0 && d0 == 256) { const unsigned lin_ = blockIdx.x + blockIdx.y * gridDim.x; if (lin_ < 16384) g_trace[5 * lin_] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) | __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); } } while (0)
+#endif
 #define RH_NOSTAMP(k) do { } while (0)
 #define RH_NOSTAMP_BEGIN() do { } while (0)
-#if RH_STAMPS == 2   // -DRH_STAMPS=2: the outside kernel's phases, -DRH_STAMPS=1: the inside kernel's
+#if RH_STAMPS == 3
+#define RH_STAMPO(k) RH_NOSTAMP(k)
+#define RH_STAMPO_BEGIN() RH_NOSTAMP_BEGIN()
+#define RH_STAMPI(k) RH_NOSTAMP(k)
+#define RH_STAMPI_BEGIN() RH_NOSTAMP_BEGIN()
+#elif RH_STAMPS == 2   // -DRH_STAMPS=2: the outside kernel's phases, -DRH_STAMPS=1: the inside kernel's
 #define RH_STAMPO(k) RH_STAMP(k)
 #define RH_STAMPO_BEGIN() RH_STAMP_BEGIN()
 #define RH_STAMPI(k) RH_NOSTAMP(k)
@@ -87,6 +103,10 @@ extern "C" int rh_debug_stamps(unsigned long long* out, int reset)
 #define RH_STAMPI_BEGIN() do { } while (0)
 #define RH_STAMPO(k) do { } while (0)
 #define RH_STAMPO_BEGIN() do { } while (0)
+#endif
+#ifndef RH_TRACE
+#define RH_TRACE(slot) do { } while (0)
+#define RH_TRACE_ID() do { } while (0)
 #endif
 
 enum StripTable { S_FC = 0, S_FCX, S_FCA, S_FM1, S_FM, S_FCO, S_FCOX, S_FM2O, S_FMO, S_FM1O, S_FM2F, S_FMOF, S_FM1OF };
@@ -263,6 +283,7 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_inside_strip(McB
     }
 #endif
     RH_STAMPI_BEGIN();
+    RH_TRACE_ID(); RH_TRACE(1);
     const int i0 = 1 + slot * GS;
     const int i = i0 + lane;
     const int ic = i < ld ? i : ld - 1;
@@ -411,6 +432,7 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_inside_strip(McB
     RH_STAMPI(0);
     __syncthreads();
     RH_STAMPI(1);
+    RH_TRACE(2);
 
     // ---- pre-phase: the terms whose operands were final before the launch, all KD diagonals
     double acc2[KH], accg[KH];
@@ -508,6 +530,7 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_inside_strip(McB
     RH_STAMPI(4);
     __syncthreads();   // every wavefront is done with the staged rows: the region behind the first KD fixed rows is reused
     RH_STAMPI(5);
+    RH_TRACE(3);
     double* const PART = lds + P::OFF_PART;
     double* const SFM = lds + P::OFF_S;
     double* const SFM1 = SFM + KD * CS;
@@ -607,6 +630,7 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_inside_strip(McB
         }
     }
     RH_STAMPI(8);
+    RH_TRACE(4);
 }
 
 // F5i[jj], jj = jlo .. n, once every row of FCA is final (after the last strip)

@@ -712,7 +712,7 @@ int launch_mc_log(rh_ctx* c, int pin, const McBatch& B, double* logz_out)
         c->n_launch[1]++;
     }
     hipLaunchKernelGGL(log_finish, dim3((B.ns + 63) / 64), dim3(64), 0, c->s_mc, B, logz_out);
-    hipLaunchKernelGGL(mc_unpaired, dim3((B.nmax + 3) / 4, B.ns), dim3(256), 0, c->s_mc, B);
+    hipLaunchKernelGGL(mc_unpaired, dim3((B.nmax + 63) / 64, B.ns), dim3(256), 0, c->s_mc, B);
     return RH_OK;
 }
 int launch_mc_log(rh_ctx* c, int pin) { return launch_mc_log(c, pin, c->mc, (double*)c->d_mclogz); }
@@ -1065,7 +1065,7 @@ int launch_mc_lin(rh_ctx* c, int pin, int phase)
                 c->n_launch[1]++;
             }
             hipLaunchKernelGGL(lin_finish, dim3((B.ns + 63) / 64), dim3(64), 0, c->s_mc, B, c->d_lin, (double*)c->d_mclogz, bad);
-            hipLaunchKernelGGL(mc_unpaired, dim3((B.nmax + 3) / 4, B.ns), dim3(256), 0, c->s_mc, B);
+            hipLaunchKernelGGL(mc_unpaired, dim3((B.nmax + 63) / 64, B.ns), dim3(256), 0, c->s_mc, B);
             return RH_OK;
         }
     }
@@ -1095,7 +1095,7 @@ int launch_mc_lin(rh_ctx* c, int pin, int phase)
                 c->n_launch[1]++;
             }
             hipLaunchKernelGGL(lin_finish, dim3((B.ns + 63) / 64), dim3(64), 0, c->s_mc, B, c->d_lin, (double*)c->d_mclogz, bad);
-            hipLaunchKernelGGL(mc_unpaired, dim3((B.nmax + 3) / 4, B.ns), dim3(256), 0, c->s_mc, B);
+            hipLaunchKernelGGL(mc_unpaired, dim3((B.nmax + 63) / 64, B.ns), dim3(256), 0, c->s_mc, B);
             return RH_OK;
         }
     }
@@ -1117,7 +1117,7 @@ int launch_mc_lin(rh_ctx* c, int pin, int phase)
         c->n_launch[1]++;
     }
     hipLaunchKernelGGL(lin_finish, dim3((B.ns + 63) / 64), dim3(64), 0, c->s_mc, B, c->d_lin, (double*)c->d_mclogz, bad);
-    hipLaunchKernelGGL(mc_unpaired, dim3((B.nmax + 3) / 4, B.ns), dim3(256), 0, c->s_mc, B);
+    hipLaunchKernelGGL(mc_unpaired, dim3((B.nmax + 63) / 64, B.ns), dim3(256), 0, c->s_mc, B);
     return RH_OK;
 }
 
