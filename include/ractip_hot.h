@@ -222,7 +222,10 @@ int rh_kernel_times(rh_ctx* ctx, int* n_launches, double* total_ms);
  * With rh_set_scale_memory(ctx, 1): when one exponent held more than half of a batch of at least eight sequences, the next
  * rh_batch_compute starts on it.
  * Vienna-BL model: the whole batch is run again with another exponent (0.7, 1.8 or 0 instead of 0.28); which = 2 then lists the
- * sequences that made it necessary. */
+ * sequences that made it necessary.
+ * which = 3: the pair indices whose DUPLEX sweeps left the range with the default exponent (0.65 per unit of i + (L2+1-j)) and were
+ * recomputed on the linear duplex kernels with another one (1.3, 2.2, 0.3 or 0; CONTRAfold model) -- they are NOT in the list of
+ * which = 1. */
 int rh_batch_fallbacks(rh_ctx* ctx, int which, int* out, int cap);
 
 /* Scale-exponent memory (default OFF).  Off: every rh_batch_compute starts on the default exponent, so a sequence's result bits

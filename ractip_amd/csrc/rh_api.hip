@@ -292,6 +292,9 @@ struct rh_ctx {
     double vdx_s = 0.27;           // log Z of pf_duplex per unit of a+b: 0.23 (random ACGU) .. 0.32 (70 % GC)
     DxLinModel* d_dxlin = nullptr;
     DxLinModel h_dxlin;
+    DxLinModel* d_dxlin_r[4] = {nullptr, nullptr, nullptr, nullptr};   // duplex scale-exponent ladder (retry_dx_lin_rungs), built on first use
+    DxLinModel h_dxlin_r[4];
+    std::vector<int> rescaled_dx;              // pairs the last compute recomputed on the linear duplex kernels with another exponent (rh_batch_fallbacks which = 3)
     DxLinBatch dxl = {};
     size_t dxl_layout = 0;         // (lda, rows) signature of the zero-padded table image currently in HBM
     int co_seed = 1;               // Vienna-BL, hp from the two-molecule ensemble: copy the one-strand cells from the single folds (RH_CO_SEED=0: sweep them again)
@@ -1457,19 +1460,20 @@ int recompute_dx_subset_log(rh_ctx* c, const std::vector<int>& F)
 }
 
 // ---- duplex sweeps, scaled linear path
+// X: the batch (the whole one, or a compacted sub-batch of the scale-exponent ladder with its own tables); dm / hm: the model at the
+// scale exponent of this pass; logz_out / bad: per pair of X
 template <int W>
-int launch_dx_lin(rh_ctx* c)
+int launch_dx_lin_on(rh_ctx* c, DxLinBatch X, const DxLinModel* dm, const DxLinModel& hm, double* logz_out, int* bad)
 {
-    DxLinBatch X = c->dxl;
     const int smax = X.n1max + X.n2max;
     const int steps = smax / 2;
     const int groups = (X.n1max + 2 + 63) / 64;
-    const double leu = c->h_dxlin.lam_eu, l2 = c->h_dxlin.lam_pow[2];
+    const double leu = hm.lam_eu, l2 = hm.lam_pow[2];
     if (W == 4 && c->dx_quad && c->dx_strip) {   // eight anti-diagonals per launch (dxl_strip8)
         const int groups8 = (X.n1max + 2 + 57) / 58;
         for (int t = 0; 8 * t < smax - 1; t++) {
             for (int k = 0; k < 8; k++) X.pw8[k] = std::pow(leu, 8.0 * t + k) * l2;
-            KLAUNCH(c, 4, dxl_strip8, dim3(groups8, X.np, 2), dim3(512), c->s_dx, X, c->d_dxlin, t);
+            KLAUNCH(c, 4, dxl_strip8, dim3(groups8, X.np, 2), dim3(512), c->s_dx, X, dm, t);
             c->n_launch[2]++;
         }
     } else
@@ -1477,7 +1481,7 @@ int launch_dx_lin(rh_ctx* c)
         const int groups4 = (X.n1max + 2 + 61) / 62;
         for (int t = 0; 4 * t < smax - 1; t++) {
             for (int k = 0; k < 4; k++) X.pw4[k] = std::pow(leu, 4.0 * t + k) * l2;
-            KLAUNCH(c, 4, dxl_sweep4, dim3(groups4, X.np, 2), dim3(256), c->s_dx, X, c->d_dxlin, t, groups4);
+            KLAUNCH(c, 4, dxl_sweep4, dim3(groups4, X.np, 2), dim3(256), c->s_dx, X, dm, t, groups4);
             c->n_launch[2]++;
         }
     } else
@@ -1485,16 +1489,93 @@ int launch_dx_lin(rh_ctx* c)
         // inside diagonal sd = 2+2t+k: (lam e^eu)^(sd-2) lam^2 ; outside sd = Smax-2t-1+k: (lam e^eu)^(2t+1-k) lam^2
         X.pw_in[0] = std::pow(leu, 2.0 * t) * l2;      X.pw_in[1] = X.pw_in[0] * leu;
         X.pw_out[1] = std::pow(leu, 2.0 * t) * l2;     X.pw_out[0] = X.pw_out[1] * leu;
-        KLAUNCH(c, 4, dxl_sweep<W>, dim3(groups, X.np, 2), dim3(64 * W), c->s_dx, X, c->d_dxlin, t, groups);
+        KLAUNCH(c, 4, dxl_sweep<W>, dim3(groups, X.np, 2), dim3(64 * W), c->s_dx, X, dm, t, groups);
         c->n_launch[2]++;
     }
     double* zpart = (double*)c->d_zpart;
     int* cpart = (int*)(zpart + (size_t)X.np * c->lz_chunks);
-    hipLaunchKernelGGL(dxl_logz_part, dim3(c->lz_chunks, X.np), dim3(256), 0, c->s_dx, X, c->d_dxlin, zpart, cpart, c->lz_chunks);
-    hipLaunchKernelGGL(dxl_logz_final, dim3((X.np + 63) / 64), dim3(64), 0, c->s_dx, X, c->d_dxlin, (const double*)zpart, (const int*)cpart,
-                       c->lz_chunks, (double*)c->d_zbar, (double*)c->d_logz, (int*)c->d_dxbad);
-    hipLaunchKernelGGL(dxl_posterior, dim3((X.n1max + 31) / 32, (smax - 1 + 31) / 32, X.np), dim3(256), 0, c->s_dx, X, (const double*)c->d_zbar,
-                       (int*)c->d_dxbad);
+    hipLaunchKernelGGL(dxl_logz_part, dim3(c->lz_chunks, X.np), dim3(256), 0, c->s_dx, X, dm, zpart, cpart, c->lz_chunks);
+    hipLaunchKernelGGL(dxl_logz_final, dim3((X.np + 63) / 64), dim3(64), 0, c->s_dx, X, dm, (const double*)zpart, (const int*)cpart,
+                       c->lz_chunks, (double*)c->d_zbar, logz_out, bad);
+    hipLaunchKernelGGL(dxl_posterior, dim3((X.n1max + 31) / 32, (smax - 1 + 31) / 32, X.np), dim3(256), 0, c->s_dx, X, (const double*)c->d_zbar, bad);
+    return RH_OK;
+}
+template <int W>
+int launch_dx_lin(rh_ctx* c) { return launch_dx_lin_on<W>(c, c->dxl, c->d_dxlin, c->h_dxlin, (double*)c->d_logz, (int*)c->d_dxbad); }
+
+// ---- other scale exponents for the duplex sweeps before the log-space kernels (CONTRAfold model): the duplex counterpart of
+// retry_mc_lin_rungs.  IN~ = IN * exp(-s (a+b)) with s = 0.65 per unit of a+b (random ACGU: log Z grows by 0.6 per unit); a pair of
+// long complementary strands (1.0 - 1.5 per unit) leaves the double range.  The flagged pairs are recomputed as a compacted sub-batch on
+// the SAME linear kernels with s = 1.3, then 2.2 (overflow), then 0.3, then 0 (underflow), with their own tables (zero pad columns),
+// and only what no exponent holds goes to the log-space kernels.  An exponent costs dynamic range only, never accuracy.
+constexpr int kDxRungs = 4;
+constexpr double kDxRungS[kDxRungs] = {1.3, 2.2, 0.3, 0.0};
+
+int retry_dx_lin_rungs(rh_ctx* c, std::vector<int>* rest)
+{
+    if (!c->scale_ladder || rest->empty() || !c->h_score) return RH_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const DxBatch& D = c->dx;
+    int rc;
+    if (!c->d_dxlin_r[0]) {
+        for (int r = 0; r < kDxRungs; r++) {
+            build_dx_lin_model(*c->h_score, kDxRungS[r], &c->h_dxlin_r[r]);
+            HIP_TRY(c, hipMalloc((void**)&c->d_dxlin_r[r], sizeof(DxLinModel)));
+            HIP_TRY(c, hipMemcpy(c->d_dxlin_r[r], &c->h_dxlin_r[r], sizeof(DxLinModel), hipMemcpyHostToDevice));
+        }
+    }
+    std::vector<int> F = *rest;
+    for (int r = 0; r < kDxRungs && !F.empty(); r++) {
+        const int nsub = (int)F.size();
+        std::vector<uint8_t> codes((size_t)2 * nsub * D.lds);
+        std::vector<int> lens(2 * (size_t)nsub);
+        int n1max = 0, n2max = 0;
+        for (int k = 0; k < nsub; k++)
+            for (int h = 0; h < 2; h++) {
+                std::memcpy(codes.data() + (size_t)(2 * k + h) * D.lds, c->h_codes.data() + (size_t)(2 * F[k] + h) * D.lds, D.lds);
+                lens[2 * k + h] = c->n[2 * F[k] + h];
+                (h ? n2max : n1max) = std::max(h ? n2max : n1max, lens[2 * k + h]);
+            }
+        DxLinBatch X = c->dxl;   // lds, ldd, hp_stride as in the main batch: results scatter back row for row
+        X.np = nsub; X.n1max = n1max; X.n2max = n2max;
+        X.lda = (n1max + 2 + 2 * kDxPad + 1) & ~1;
+        const size_t rows = (size_t)n1max + n2max + 3;
+        X.tab_stride = rows * X.lda + 128;
+        X.pair_stride = X.tab_stride * (int)DL_COUNT;
+        const size_t tab_d = X.pair_stride * nsub, hp_d = D.tab_stride * nsub;
+        if ((rc = ensure(c, &c->d_subdseq, &c->cap_subdseq, codes.size(), false))) return rc;
+        if ((rc = ensure(c, &c->d_subdn, &c->cap_subdn, sizeof(int) * lens.size(), false))) return rc;
+        if ((rc = ensure(c, &c->d_subdx, &c->cap_subdx, sizeof(double) * (tab_d + hp_d + nsub + 1) + sizeof(int) * nsub, false))) return rc;
+        HIP_TRY(c, hipMemcpyAsync(c->d_subdseq, codes.data(), codes.size(), hipMemcpyHostToDevice, c->s_dx));
+        HIP_TRY(c, hipMemcpyAsync(c->d_subdn, lens.data(), sizeof(int) * lens.size(), hipMemcpyHostToDevice, c->s_dx));
+        double* sub_tab = (double*)c->d_subdx;
+        double* sub_hp = sub_tab + tab_d;
+        double* sub_logz = sub_hp + hp_d;
+        int* sub_bad = (int*)(sub_logz + nsub + 1);
+        HIP_TRY(c, hipMemsetAsync(c->d_subdx, 0, sizeof(double) * (tab_d + hp_d + nsub + 1) + sizeof(int) * nsub, c->s_dx));   // pad columns, row 0 / column 0 of hp
+        HIP_TRY(c, hipStreamSynchronize(c->s_dx));   // (codes / lens die with this iteration)
+        X.seq = (const uint8_t*)c->d_subdseq; X.n = (const int*)c->d_subdn; X.tab = sub_tab; X.hp = sub_hp;
+        const int saved_chunks = c->lz_chunks;
+        c->lz_chunks = (n1max + n2max - 1 + 15) / 16;   // (<= the main batch's: d_zpart / d_zbar are large enough)
+        rc = launch_dx_lin_on<4>(c, X, c->d_dxlin_r[r], c->h_dxlin_r[r], sub_logz, sub_bad);
+        c->lz_chunks = saved_chunks;
+        if (rc) return rc;
+        std::vector<int> bad(nsub);
+        HIP_TRY(c, hipMemcpyAsync(bad.data(), sub_bad, sizeof(int) * nsub, hipMemcpyDeviceToHost, c->s_dx));
+        HIP_TRY(c, hipStreamSynchronize(c->s_dx));
+        std::vector<int> still;
+        for (int k = 0; k < nsub; k++) {
+            if (bad[k]) { still.push_back(F[k]); continue; }
+            HIP_TRY(c, hipMemcpyAsync((double*)c->d_hp + (size_t)F[k] * D.tab_stride, sub_hp + (size_t)k * D.tab_stride, sizeof(double) * D.tab_stride,
+                                      hipMemcpyDeviceToDevice, c->s_dx));
+            HIP_TRY(c, hipMemcpyAsync((double*)c->d_logz + F[k], sub_logz + k, sizeof(double), hipMemcpyDeviceToDevice, c->s_dx));
+            c->rescaled_dx.push_back(F[k]);
+        }
+        HIP_TRY(c, hipStreamSynchronize(c->s_dx));   // the sub-batch buffers are reused by the next rung
+        F.swap(still);
+    }
+    std::sort(c->rescaled_dx.begin(), c->rescaled_dx.end());
+    *rest = F;
     return RH_OK;
 }
 // Vienna-BL pf_duplex, scaled linear space (duplex_vlin.hip)
@@ -1578,7 +1659,7 @@ int compute_once(rh_ctx* c)
     c->n_launch[0] = c->n_launch[1] = c->n_launch[2] = 0;
     c->n_far[0] = c->n_far[1] = c->n_far[2] = 0;
     c->last_path = 0;
-    c->fallback_mc.clear(); c->fallback_dx.clear(); c->rescaled_mc.clear();
+    c->fallback_mc.clear(); c->fallback_dx.clear(); c->rescaled_mc.clear(); c->rescaled_dx.clear();
     // sequence -> XCD affinity only when the batch spreads evenly over the 8 XCDs (speed only)
     const int pin = (c->has_mc && c->mc.ns % 8 == 0) ? 1 : 0;
     int rc;
@@ -1740,8 +1821,10 @@ int compute_once(rh_ctx* c)
             bool redo = false;
             for (int k = 0; k < c->dx.np; k++) if (bad[k]) { redo = true; c->fallback_dx.push_back(k); }
             if (redo && c->model != RH_MODEL_VIENNA_BL && 2 * c->fallback_dx.size() <= (size_t)c->dx.np) {
-                // only the flagged pairs, as a compacted sub-batch with its own tables
-                if ((rc = recompute_dx_subset_log(c, c->fallback_dx))) return rc;
+                // only the flagged pairs, as a compacted sub-batch with its own tables: another scale exponent on the linear kernels
+                // first (retry_dx_lin_rungs), the log-space kernels for what is left
+                if ((rc = retry_dx_lin_rungs(c, &c->fallback_dx))) return rc;
+                if (!c->fallback_dx.empty() && (rc = recompute_dx_subset_log(c, c->fallback_dx))) return rc;
                 HIP_TRY(c, hipEventRecord(c->ev[4], c->s_dx));
                 c->last_dx_path = 3;
             } else if (redo) {  // most pairs (or the Vienna-BL model): recompute the batch with the log-space kernels
@@ -2001,7 +2084,7 @@ void rh_destroy(rh_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    void* bufs[] = {c->d_seq, c->d_n, c->d_mctab, c->d_f5, c->d_bp, c->d_up, c->d_dxtab, c->d_hp, c->d_logz, c->d_scal, c->d_mclogz, c->d_bad, c->d_cnt, c->d_cand, c->d_dxbad, c->d_zbar, c->d_zpart, c->d_gaps, c->d_coseq, c->d_con, c->d_cotab, c->d_pk, c->d_copk, c->d_rowp, c->d_corowp, c->d_cof5, c->d_cobp, c->d_cobad, c->d_allow, c->d_coallow, c->d_vlin, c->d_vdxl, c->d_vdx, c->d_hplen, c->d_model, c->d_lin, c->d_dxlin, c->d_vienna, c->d_wT, c->d_subseq, c->d_subn, c->d_subbp, c->d_subup, c->d_subdseq, c->d_subdn, c->d_subdx};
+    void* bufs[] = {c->d_seq, c->d_n, c->d_mctab, c->d_f5, c->d_bp, c->d_up, c->d_dxtab, c->d_hp, c->d_logz, c->d_scal, c->d_mclogz, c->d_bad, c->d_cnt, c->d_cand, c->d_dxbad, c->d_zbar, c->d_zpart, c->d_gaps, c->d_coseq, c->d_con, c->d_cotab, c->d_pk, c->d_copk, c->d_rowp, c->d_corowp, c->d_cof5, c->d_cobp, c->d_cobad, c->d_allow, c->d_coallow, c->d_vlin, c->d_vdxl, c->d_vdx, c->d_hplen, c->d_model, c->d_lin, c->d_dxlin, c->d_vienna, c->d_wT, c->d_subseq, c->d_subn, c->d_subbp, c->d_subup, c->d_subdseq, c->d_subdn, c->d_subdx, c->d_dxlin_r[0], c->d_dxlin_r[1], c->d_dxlin_r[2], c->d_dxlin_r[3]};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (int r = 0; r < rh_ctx::kRungs; r++) { if (c->d_lin_r[r]) (void)hipFree(c->d_lin_r[r]); if (c->d_wT_r[r]) (void)hipFree(c->d_wT_r[r]); }
     for (GraphSlot* g : {&c->g_in, &c->g_out, &c->g_dx}) if (g->exec) (void)hipGraphExecDestroy(g->exec);
@@ -2349,9 +2432,9 @@ int rh_batch_kernels(rh_ctx* c, const char* fine[3], const char* far[3], int n_f
 
 int rh_batch_fallbacks(rh_ctx* c, int which, int* out, int cap)
 {
-    if (!c || which < 0 || which > 2) return RH_ERR_ARG;
+    if (!c || which < 0 || which > 3) return RH_ERR_ARG;
     if (!c->computed) return fail(c, RH_ERR_ARG, "no computed batch");
-    const std::vector<int>& F = which == 2 ? c->rescaled_mc : (which ? c->fallback_dx : c->fallback_mc);
+    const std::vector<int>& F = which == 3 ? c->rescaled_dx : (which == 2 ? c->rescaled_mc : (which ? c->fallback_dx : c->fallback_mc));
     if (cap > 0 && !out) return fail(c, RH_ERR_ARG, "rh_batch_fallbacks: out is NULL with cap > 0");
     for (int k = 0; k < (int)F.size() && k < cap; k++) out[k] = F[k];
     return (int)F.size();

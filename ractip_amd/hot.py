@@ -324,7 +324,7 @@ class Context:
 
     def batch_fallbacks(self, which=0):
         """Indices of the sequences (which=0) / pairs (which=1) the last compute recomputed in log space; which=2: the sequences it
-        recomputed on the linear kernels with another scale exponent."""
+        recomputed on the linear kernels with another scale exponent; which=3: the pairs whose duplex sweeps it recomputed that way."""
         buf = (ctypes.c_int * max(1, 2 * len(self._pairs)))()
         k = self._check(self.L.rh_batch_fallbacks(self.h, which, buf, len(buf)))
         return [buf[t] for t in range(min(k, len(buf)))]

@@ -212,8 +212,8 @@ def test_mixed_batch_only_the_flagged_problems_fall_back(ctx, oracle):
     mixed[3] = (helix, pairs[3][1])
     ctx.batch_upload(mixed)
     ctx.batch_compute()
-    # (the helix is held by the third scale exponent of the linear path, 1.5 per unit span, or else goes to the log-space kernels)
-    assert ctx.last_path() == 3 and sorted(ctx.batch_fallbacks(0) + ctx.batch_fallbacks(2)) == [6]
+    # WHICH mechanism: the helix is held by the third scale exponent of the linear path (1.5 per unit span), not by the log-space kernels
+    assert ctx.last_path() == 3 and ctx.batch_fallbacks(2) == [6] and ctx.batch_fallbacks(0) == []
     for p in range(len(pairs)):
         r = ctx.batch_results(p)
         if p != 3:   # untouched problems: bit for bit what the all-ordinary batch gave
@@ -226,16 +226,18 @@ def test_mixed_batch_only_the_flagged_problems_fall_back(ctx, oracle):
             assert np.array_equal(r["bp2"], base[3]["bp2"])         # its partner stayed on the linear path
             assert abs(r["logZ"][2] - od["logZ2"][0]) < 1e-7 * abs(od["logZ2"][0])
             assert_prob_close(r["hp"], od["post"], rel=REL, what="helix duplex")
-    # a duplex that overflows while its sequences do not: two complementary 400-mers (log Z of the duplex ~ 2 per pair)
-    a = "GC" * 200
-    b = "GC" * 200
+    # a duplex that overflows while its sequences do not: a random GC 600-mer and its reverse complement (log Z of the duplex ~ 3 per pair)
+    rng = np.random.RandomState(17)
+    a = "".join(rng.choice(list("GC"), 600))
+    b = "".join({"G": "C", "C": "G"}[ch] for ch in reversed(a))
     ctx.batch_upload(pairs[:3] + [(a, b)] + pairs[3:])
     ctx.batch_compute()
-    if ctx.batch_fallbacks(1):
-        assert ctx.batch_fallbacks(1) == [3] and ctx.last_hybrid_path() == 3
-        od = oracle.duplex(a, b)
-        assert_prob_close(ctx.batch_results(3)["hp"], od["post"], rel=REL, what="overflowing duplex via per-pair fallback")
-        assert np.array_equal(ctx.batch_results(0)["hp"], base[0]["hp"])
+    # WHICH mechanism: the duplex scale-exponent ladder (another exponent on the linear duplex kernels), not the log-space kernels
+    assert ctx.batch_fallbacks(3) == [3] and ctx.batch_fallbacks(1) == [] and ctx.last_hybrid_path() == 3
+    od = oracle.duplex(a, b)
+    assert abs(ctx.batch_results(3)["logZ"][2] - od["logZ2"][0]) < 1e-9 * abs(od["logZ2"][0])
+    assert_prob_close(ctx.batch_results(3)["hp"], od["post"], rel=REL, what="overflowing duplex via the per-pair ladder")
+    assert np.array_equal(ctx.batch_results(0)["hp"], base[0]["hp"])
 
 
 def test_scale_exponent_ladder(hotlib, monkeypatch):
@@ -282,6 +284,45 @@ def test_scale_exponent_ladder(hotlib, monkeypatch):
                 assert np.abs(r[up] - r0[up]).max() < 1e-9
             else:
                 assert np.array_equal(r[key], r0[key]) and np.array_equal(r[up], r0[up]) and r["logZ"][which] == r0["logZ"][which]
+
+
+def test_duplex_scale_exponent_ladder(hotlib, monkeypatch):
+    """Pairs of long complementary strands (log Z of the duplex ensemble 1.2 - 1.6 per unit of i + (L2+1-j), against the 0.65 the default
+    exponent assumes) leave the double range on the linear duplex kernels: they are recomputed there with another exponent
+    (rh_batch_fallbacks which = 3), NOT by the log-space kernels; results equal the log-space path's to 1e-9 and every other pair of the
+    batch keeps its bits."""
+    import ractip_amd
+    rng = np.random.default_rng(11)
+    comp = {"A": "U", "U": "A", "G": "C", "C": "G"}
+    rnd_ = lambda n, al="ACGU": "".join(rng.choice(list(al), size=n))
+    def compl(n):
+        a = rnd_(n, "GC")
+        return a, "".join(comp[ch] for ch in reversed(a))
+    pairs = [(rnd_(300), rnd_(280)), compl(600), (rnd_(120), rnd_(400)), compl(450), (rnd_(64), rnd_(64)), (rnd_(200), rnd_(210)), compl(700), (rnd_(90), rnd_(33))]
+
+    def run(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        c = ractip_amd.Context(device=0)
+        try:
+            c.batch_upload(pairs); c.batch_compute()
+            return c.last_path(), c.batch_fallbacks(1), c.batch_fallbacks(3), [c.batch_results(p) for p in range(len(pairs))], c.last_hybrid_path()
+        finally:
+            c.close()
+            for k in env:
+                monkeypatch.delenv(k)
+
+    _, logd0, resc0, ref, _ = run({"RH_SCALE_LADDER": "0"})
+    assert resc0 == [] and set(logd0) >= {1, 6} and set(logd0) <= {1, 3, 6}     # (the 450-mer pair stays inside the range on some exponent-free margin)
+    _, logd, resc, res, hpath = run({})
+    assert resc == logd0 and logd == [] and hpath == 3
+    for p, (r, r0) in enumerate(zip(res, ref)):
+        if p in logd0:
+            assert abs(r["logZ"][2] - r0["logZ"][2]) < 1e-9 * abs(r0["logZ"][2]) and r0["logZ"][2] > 400
+            assert_prob_close(r["hp"], r0["hp"], rel=REL, what="hp of the rescaled pair %d" % p)
+        else:
+            assert np.array_equal(r["hp"], r0["hp"]) and r["logZ"][2] == r0["logZ"][2]
+        assert np.array_equal(r["bp1"], r0["bp1"])
 
 
 def test_scale_exponent_is_remembered(hotlib):
