@@ -285,6 +285,16 @@ struct rh_ctx {
     VLinModel* d_vlin_m[kVRungs + 1] = {nullptr, nullptr, nullptr, nullptr};
     int vlin_cur = -1, vlin_primary = -1;      // model selected now / the one a batch starts with
     bool defer_log = false, deferred = false;  // compute_once: a flagged problem ends the attempt instead of starting the log-space kernels
+    // Vienna-BL, per-pair route of the ladder (round 3): when at most half of the pairs of a batch are flagged, only THOSE pairs are recomputed --
+    // on a helper context of the same model (its own tables, its own whole-batch ladder and log-space fallback) -- and their results are
+    // copied into this batch's result buffers; every other pair keeps the result of the first pass bit for bit
+    rh_ctx* helper = nullptr;
+    bool is_helper = false;
+    int pair_helper = 1;           // RH_PAIR_HELPER=0: the whole batch is run again (round-2 behaviour); 2: helper whenever at most half of the pairs are flagged
+    std::vector<int> flagged_pairs;            // pairs the deferred attempt flagged (folds, two-molecule sweeps or pf_duplex)
+    std::string p_param, p_defaults;           // creation arguments, for the helper
+    bool p_has_param = false, p_has_defaults = false;
+    int p_use_bl = 1, p_sem = 0;
     bool went_log = false;                     // compute_once (Vienna-BL): the batch was recomputed by the log-space kernels
     std::vector<int> flagged_mc;               // sequences the deferred attempts flagged
     VLinModel* d_vdxl = nullptr;   // the same tables at the duplex scale (duplex_vlin.hip)
@@ -390,6 +400,8 @@ struct rh_ctx {
     std::vector<hipEvent_t> tev;   // event pool of the timed class (pairs), tev_n used by the last compute
     size_t tev_n = 0;
 };
+
+rh_ctx* make_ctx_for_helper(int device, int model, const char* param_file, const char* defaults_file, int use_bl, int semantics);   // = create_ctx (below)
 
 namespace {
 
@@ -1741,7 +1753,7 @@ int compute_once(rh_ctx* c)
                 for (int b : bad) log_path |= (b != 0);
                 if (log_path) { c->last_path = 3; c->tables_dirty = true; co_seed_bad = co_seed; }
                 if (log_path && c->defer_log) {   // another exponent first (compute): this attempt ends here
-                    for (int k = 0; k < c->mc.ns; k++) if (bad[k]) c->flagged_mc.push_back(k);
+                    for (int k = 0; k < c->mc.ns; k++) if (bad[k]) { c->flagged_mc.push_back(k); if (c->has_dx) c->flagged_pairs.push_back(k / 2); }
                     c->deferred = true;
                     log_path = false;
                 }
@@ -1800,7 +1812,10 @@ int compute_once(rh_ctx* c)
         HIP_TRY(c, hipStreamSynchronize(c->s_dx));
         bool redo = co_seed_bad;   // a molecule left the double range on its own: what was copied from its fold is not usable
         for (int b : bad) redo |= (b != 0);
-        if (redo && c->defer_log) { c->tables_dirty = true; c->deferred = true; }
+        if (redo && c->defer_log) {
+            c->tables_dirty = true; c->deferred = true;
+            for (int k = 0; k < c->co.ns; k++) if (bad[k]) c->flagged_pairs.push_back(k);
+        }
         else if (redo) {   // some pair left the double range: recompute the two-molecule sweeps in log space
             c->went_log = true;
             c->tables_dirty = true;
@@ -1827,6 +1842,10 @@ int compute_once(rh_ctx* c)
                 if (!c->fallback_dx.empty() && (rc = recompute_dx_subset_log(c, c->fallback_dx))) return rc;
                 HIP_TRY(c, hipEventRecord(c->ev[4], c->s_dx));
                 c->last_dx_path = 3;
+            } else if (redo && c->model == RH_MODEL_VIENNA_BL && c->defer_log) {   // (compute: the flagged pairs go to the helper context)
+                c->tables_dirty = true; c->deferred = true;
+                c->flagged_pairs.insert(c->flagged_pairs.end(), c->fallback_dx.begin(), c->fallback_dx.end());
+                c->fallback_dx.clear();
             } else if (redo) {  // most pairs (or the Vienna-BL model): recompute the batch with the log-space kernels
                 c->n_launch[2] = 0;
                 HIP_TRY(c, hipEventRecord(c->ev[3], c->s_dx));
@@ -1882,6 +1901,72 @@ int select_vlin(rh_ctx* c, int model)
     return RH_OK;
 }
 
+int compute(rh_ctx* c);
+
+// The flagged pairs P of a Vienna-BL batch, recomputed on the helper context and copied into this batch's result buffers (bp, up, hp and
+// the three log partition functions of each pair); the layouts differ only in their strides.
+int recompute_pairs_on_helper(rh_ctx* c, const std::vector<int>& P)
+{
+    if (!c->helper) {
+        c->helper = make_ctx_for_helper(c->device, c->model, c->p_has_param ? c->p_param.c_str() : nullptr, c->p_has_defaults ? c->p_defaults.c_str() : nullptr,
+                               c->p_use_bl, c->p_sem);
+        if (!c->helper) return fail(c, RH_ERR_HIP, "helper context for the per-pair fallback could not be created");
+        c->helper->is_helper = true;
+    }
+    rh_ctx* h = c->helper;
+    h->max_w = c->max_w; h->hybrid = c->hybrid; h->mode = RH_MODE_AUTO; h->scale_ladder = c->scale_ladder; h->scale_memory = 0;
+    h->vlin_primary = c->vlin_primary < 0 ? 0 : -1;   // the exponent of the first pass is known to fail for these pairs: start on the next one
+    const int nsub = (int)P.size();
+    const int lds = c->mc.lds;
+    std::vector<std::string> text(2 * (size_t)nsub);
+    std::vector<const char*> ptr(2 * (size_t)nsub);
+    std::vector<int> lens(2 * (size_t)nsub);
+    for (int k = 0; k < nsub; k++)
+        for (int hh = 0; hh < 2; hh++) {
+            const int sq = 2 * P[k] + hh, n = c->n[sq];
+            std::string& t = text[2 * k + hh];
+            t.resize(n);
+            for (int i = 0; i < n; i++) t[i] = "NACGU"[c->h_codes[(size_t)sq * lds + 1 + i] <= 4 ? c->h_codes[(size_t)sq * lds + 1 + i] : 0];   // vienna_code^-1
+            ptr[2 * k + hh] = t.c_str(); lens[2 * k + hh] = n;
+        }
+    int rc;
+    if ((rc = stage(h, 2 * nsub, ptr.data(), lens.data(), true, true, nullptr, nullptr))) return fail(c, rc, "helper upload: %s", h->err.c_str());
+    if ((rc = compute(h))) return fail(c, rc, "helper compute: %s", h->err.c_str());
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->s_mc));
+    HIP_TRY(c, hipStreamSynchronize(c->s_dx));
+    const size_t up_c = (size_t)c->mc.ld * c->max_w, up_h = (size_t)h->mc.ld * h->max_w;
+    for (int k = 0; k < nsub; k++) {
+        for (int hh = 0; hh < 2; hh++) {
+            const int sq = 2 * P[k] + hh, sh = 2 * k + hh, n = c->n[sq];
+            HIP_TRY(c, hipMemcpyAsync((double*)c->d_bp + (size_t)sq * c->mc.tri_stride, (const double*)h->d_bp + (size_t)sh * h->mc.tri_stride,
+                                      sizeof(double) * tri_size(n), hipMemcpyDeviceToDevice, c->s_mc));
+            HIP_TRY(c, hipMemcpyAsync((double*)c->d_up + (size_t)sq * up_c, (const double*)h->d_up + (size_t)sh * up_h, sizeof(double) * (size_t)n * c->max_w,
+                                      hipMemcpyDeviceToDevice, c->s_mc));
+            HIP_TRY(c, hipMemcpyAsync((double*)c->d_mclogz + sq, (const double*)h->d_mclogz + sh, sizeof(double), hipMemcpyDeviceToDevice, c->s_mc));
+        }
+        const int n1 = c->n[2 * P[k]], n2 = c->n[2 * P[k] + 1];
+        HIP_TRY(c, hipMemcpy2DAsync((double*)c->d_hp + (size_t)P[k] * c->dx.tab_stride, sizeof(double) * c->dx.ldd,
+                                    (const double*)h->d_hp + (size_t)k * h->dx.tab_stride, sizeof(double) * h->dx.ldd,
+                                    sizeof(double) * (n2 + 1), (size_t)n1 + 1, hipMemcpyDeviceToDevice, c->s_mc));
+        HIP_TRY(c, hipMemcpyAsync((double*)c->d_logz + P[k], (const double*)h->d_logz + k, sizeof(double), hipMemcpyDeviceToDevice, c->s_mc));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->s_mc));
+    // what happened to them: held by another exponent on the helper's linear kernels (which = 2), or recomputed in log space (which = 0 / 1)
+    c->last_path = 3;
+    if (c->last_dx_path == 1 || c->last_dx_path == 0) c->last_dx_path = 3;
+    c->rescaled_mc.clear(); c->fallback_mc.clear(); c->fallback_dx.clear();
+    const bool h_log = h->went_log || h->last_path == 2 || (h->last_path == 3 && h->rescaled_mc.empty() && !h->fallback_mc.empty());
+    for (int k = 0; k < nsub; k++) {
+        if (h_log) { c->fallback_mc.push_back(2 * P[k]); c->fallback_mc.push_back(2 * P[k] + 1); c->fallback_dx.push_back(P[k]); }
+        else { c->rescaled_mc.push_back(2 * P[k]); c->rescaled_mc.push_back(2 * P[k] + 1); }
+    }
+    c->deferred = false;
+    c->tables_dirty = true;
+    c->computed = true;
+    return RH_OK;
+}
+
 int compute(rh_ctx* c)
 {
     c->defer_log = false;
@@ -1901,10 +1986,24 @@ int compute(rh_ctx* c)
         for (auto it = all.rbegin(); it != all.rend(); ++it) if (it->first < s0 - 1e-12) order.push_back(it->second);
     }
     int rc = RH_OK;
+    const bool per_pair = !c->is_helper && c->pair_helper && c->has_dx && c->np >= 4 && !c->mc.allow && !c->co.allow;
     for (size_t a = 0; a < order.size(); a++) {
         if ((rc = select_vlin(c, order[a]))) break;
         c->defer_log = a + 1 < order.size();
+        c->flagged_pairs.clear();
         if ((rc = compute_once(c))) break;
+        if (c->deferred && a == 0 && per_pair) {
+            std::sort(c->flagged_pairs.begin(), c->flagged_pairs.end());
+            c->flagged_pairs.erase(std::unique(c->flagged_pairs.begin(), c->flagged_pairs.end()), c->flagged_pairs.end());
+            // cost: the helper pays the launch latency of a few pairs (tens of ms per attempt at n = 500 - 1000, whatever the batch), a
+            // second pass over the batch pays its whole device time again: the helper wins when the flagged pairs are a small share
+            // (measured at n = 500: equal at 64 pairs and one flagged pair, 2 x at 256).  RH_PAIR_HELPER=2: whenever at most half are flagged
+            const size_t share = c->pair_helper >= 2 ? 2 : 16;
+            if (!c->flagged_pairs.empty() && share * c->flagged_pairs.size() <= (size_t)c->np) {
+                rc = recompute_pairs_on_helper(c, c->flagged_pairs);
+                break;
+            }
+        }
         if (!c->deferred) {
             if (a > 0) {   // held by another exponent
                 c->last_path = 3;
@@ -2029,6 +2128,10 @@ static rh_ctx* create_ctx(int device, int model, const char* param_file, const c
     if (const char* e = std::getenv("RH_CO_WINDOW")) c->co_window = std::atoi(e);
     if (const char* e = std::getenv("RH_SCALE_LADDER")) c->scale_ladder = std::atoi(e);
     if (const char* e = std::getenv("RH_SCALE_MEMORY")) c->scale_memory = std::atoi(e);
+    if (const char* e = std::getenv("RH_PAIR_HELPER")) c->pair_helper = std::atoi(e);
+    c->p_has_param = param_file != nullptr; if (param_file) c->p_param = param_file;
+    c->p_has_defaults = defaults_file != nullptr; if (defaults_file) c->p_defaults = defaults_file;
+    c->p_use_bl = use_bl; c->p_sem = semantics;
     if (const char* e = std::getenv("RH_CO_SEED")) c->co_seed = std::atoi(e);
     if (const char* e = std::getenv("RH_DX_W")) c->dx_w = std::atoi(e);
     if (const char* e = std::getenv("RH_DX_QUAD")) c->dx_quad = std::atoi(e) != 0;
@@ -2083,6 +2186,7 @@ static rh_ctx* create_ctx(int device, int model, const char* param_file, const c
 void rh_destroy(rh_ctx* c)
 {
     if (!c) return;
+    if (c->helper) { rh_destroy(c->helper); c->helper = nullptr; }
     (void)hipSetDevice(c->device);
     void* bufs[] = {c->d_seq, c->d_n, c->d_mctab, c->d_f5, c->d_bp, c->d_up, c->d_dxtab, c->d_hp, c->d_logz, c->d_scal, c->d_mclogz, c->d_bad, c->d_cnt, c->d_cand, c->d_dxbad, c->d_zbar, c->d_zpart, c->d_gaps, c->d_coseq, c->d_con, c->d_cotab, c->d_pk, c->d_copk, c->d_rowp, c->d_corowp, c->d_cof5, c->d_cobp, c->d_cobad, c->d_allow, c->d_coallow, c->d_vlin, c->d_vdxl, c->d_vdx, c->d_hplen, c->d_model, c->d_lin, c->d_dxlin, c->d_vienna, c->d_wT, c->d_subseq, c->d_subn, c->d_subbp, c->d_subup, c->d_subdseq, c->d_subdn, c->d_subdx, c->d_dxlin_r[0], c->d_dxlin_r[1], c->d_dxlin_r[2], c->d_dxlin_r[3]};
     for (void* b : bufs) if (b) (void)hipFree(b);
@@ -2508,3 +2612,9 @@ int rh_batch_device_views(rh_ctx* c, const double** bp, size_t* tri_stride, cons
 }
 
 }  // extern "C"
+
+// (file-scope alias of create_ctx for the per-pair helper context; C++ linkage, not part of the C ABI)
+rh_ctx* make_ctx_for_helper(int device, int model, const char* param_file, const char* defaults_file, int use_bl, int semantics)
+{
+    return create_ctx(device, model, param_file, defaults_file, use_bl, semantics);
+}

@@ -822,6 +822,55 @@ def test_vienna_bl_scale_exponent_ladder(hotlib, monkeypatch):
         assert_prob_close(r["up1"], r0["up1"], rel=REL, abs_floor=1e-11, what="up1 of pair %d" % p)
 
 
+def test_vienna_bl_flagged_pairs_are_recomputed_alone(hotlib, monkeypatch):
+    """Vienna-BL, per-pair route of the ladder: ONE chain of stable hairpins among seven ordinary pairs.  Only the pair that holds it is
+    recomputed (on a helper context: another exponent, or log space), every other pair keeps the bits of a batch without the chain, and
+    the chain's results equal the whole-batch route's (RH_PAIR_HELPER=0) to 1e-9."""
+    import ractip_amd
+    rng = np.random.default_rng(9)
+    comp = {"G": "C", "C": "G"}
+
+    def hairpins(n):
+        s = ""
+        while len(s) < n:
+            stem = "".join(rng.choice(list("GC"), size=10))
+            s += stem + "AAAA" + "".join(comp[ch] for ch in reversed(stem)) + "AA"
+        return s[:n]
+    rnd_ = lambda n: "".join(rng.choice(list("ACGU"), size=n))
+    plain = [(rnd_(300), rnd_(260)), (rnd_(150), rnd_(333)), (rnd_(64), rnd_(65)), (rnd_(400), rnd_(90)),
+             (rnd_(220), rnd_(210)), (rnd_(900), rnd_(190)), (rnd_(128), rnd_(127)), (rnd_(77), rnd_(300))]   # (the same longest length in both batches)
+    mixed = list(plain)
+    mixed[5] = (hairpins(900), plain[5][1])
+
+    def run(pairs, env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        c = ractip_amd.Context(device=0, model=ractip_amd.hot.RH_MODEL_VIENNA_BL)
+        try:
+            c.set_hybrid(True)
+            c.batch_upload(pairs); c.batch_compute()
+            return c.last_path(), c.batch_fallbacks(2), c.batch_fallbacks(0), [c.batch_results(p) for p in range(len(pairs))]
+        finally:
+            c.close()
+            for k in env:
+                monkeypatch.delenv(k)
+
+    path0, _, _, base = run(plain, {})
+    assert path0 == 1
+    path, resc, logd, res = run(mixed, {"RH_PAIR_HELPER": "2"})       # (2: the helper whenever at most half of the pairs are flagged; default: one in 16)
+    assert path == 3 and sorted(resc + logd) == [10, 11]            # the one pair, whichever mechanism held it on the helper
+    _, _, _, whole = run(mixed, {"RH_PAIR_HELPER": "0"})
+    for p in range(len(plain)):
+        if p != 5:
+            for k in ("bp1", "bp2", "up1", "up2", "hp", "logZ"):
+                assert np.array_equal(res[p][k], base[p][k]), (p, k)
+        else:
+            assert np.allclose(res[p]["logZ"], whole[p]["logZ"], rtol=1e-9, atol=0)
+            for k in ("bp1", "bp2", "hp"):
+                assert_prob_close(res[p][k], whole[p][k], rel=REL, what="%s of the recomputed pair" % k)
+            assert_prob_close(res[p]["up1"], whole[p]["up1"], rel=REL, abs_floor=1e-11, what="up1 of the recomputed pair")
+
+
 def test_vienna_bl_linear_path_falls_back_on_overflow(vctx):
     """A 1200-nt perfect GC helix has log Z ~ 2.5 per nucleotide: the scaled linear values leave the double range, the
     device flags it and the batch is recomputed in log space; results equal the log-space context's."""
