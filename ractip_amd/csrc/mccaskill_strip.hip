@@ -355,6 +355,7 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_inside_strip(McB
     if constexpr (FACT) fwv = wT[kStripFiltOffD + (threadIdx.x < 160 ? threadIdx.x : 159)];   // (with the staging loads: no round trip of its own)
     // the letters are first touched HERE, behind the staging loads (fence + pins: their wait must not move above those loads)
     __builtin_amdgcn_sched_barrier(0);
+    RH_STAMPI(9);    // (tuning build: every staging load is issued)
     asm volatile("" : "+v"(rb0)); asm volatile("" : "+v"(rb1)); asm volatile("" : "+v"(rb2));
 #pragma unroll
     for (int sl = 0; sl < NSL; sl++) { asm volatile("" : "+v"(r0[sl])); asm volatile("" : "+v"(r1[sl])); asm volatile("" : "+v"(r2[sl])); }
@@ -367,6 +368,7 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_inside_strip(McB
             s_j[sl] = v ? r0[sl] : 4; s_jp1[sl] = v ? r1[sl] : 4; s_jp2[sl] = v ? r2[sl] : 4;
         }
     }
+    RH_STAMPI(10);   // (tuning build: the letters have arrived)
     // ---- operands of this wavefront's chain steps, raw: issued behind the staging loads, consumed after the filter
     double r_tjb[NSL], r_tja[NSL], r_tst[NSL], r_bp[NSL], r_tjbd[NSL], r_tjad[NSL], r_b01[NSL], r_b10[NSL], r_11[NSL], p_far[NSL];
     double p_x01 = 0, p_x10 = 0, p_x11 = 0, p_fc = 0, p_fca = 0, p_fm1 = 0, p_fm = 0;   // only step k < 4 reads rows < d0 here
@@ -406,6 +408,7 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_inside_strip(McB
 #pragma unroll
     for (int q = 0; q < NR / 2; q++) { asm volatile("" : "+v"(vA1[q])); asm volatile("" : "+v"(vE1[q])); }
     asm volatile("" : "+v"(vD1));
+    RH_STAMPI(11);   // (tuning build: the staged values have arrived)
 #pragma unroll
     for (int q = 0; q < NR; q++) {   // 64-wide parts
         const int ra = w + W * q, e = 1 + w + W * q;
