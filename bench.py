@@ -240,6 +240,8 @@ def measure_roofline(ctx, pairs, model, n, batch, vienna, cofold, hp, resident_m
     sd = sweeps[dom]
     cls = {"inside": 0, "outside": 2, "duplex": 4}[dom]
     k_us, k_launches = ctx.kernel_class_times(cls, computes=2)
+    if not k_launches:   # (the two-molecule sweeps of the Vienna-BL model run under the McCaskill classes: the sweep's own event timing instead)
+        k_us, k_launches = sd["isolated_ms_per_step"] * 1e3 / sd["launches_per_step"], float(sd["launches_per_step"])
     far_us = far_launches = None
     if sd["of_which_block_product"] and dom != "duplex":   # (the two-molecule sweeps of the Vienna-BL model share classes 0-3 with the folds)
         far_us, far_launches = ctx.kernel_class_times(cls + 1, computes=2)
