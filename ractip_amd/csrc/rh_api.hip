@@ -1985,6 +1985,10 @@ int compute(rh_ctx* c)
         for (const auto& e : all) if (e.first > s0 + 1e-12) order.push_back(e.second);
         for (auto it = all.rbegin(); it != all.rend(); ++it) if (it->first < s0 - 1e-12) order.push_back(it->second);
     }
+    // (An attempt that failed leaves Inf / NaN in the tables of the flagged sequences; the next attempt runs over them without a clear.
+    //  That is sound because the vlin kernels mask every operand by SELECT (`ok ? x : 0.0`), never by a multiplication with 0, and
+    //  rewrite every interior cell they read before reading it -- the invariant `tests: test_vienna_bl_scale_exponent_ladder` and
+    //  tools/fuzz_ladder.py exercise: chains of hairpins that overflow the first exponent, results equal to the log-space path's.)
     int rc = RH_OK;
     const bool per_pair = !c->is_helper && c->pair_helper && c->has_dx && c->np >= 4 && !c->mc.allow && !c->co.allow;
     for (size_t a = 0; a < order.size(); a++) {
