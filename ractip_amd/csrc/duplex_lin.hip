@@ -484,6 +484,22 @@ __device__ __forceinline__ void win_pass8(const double* seg0, const double* __re
     }
 }
 
+#ifdef RH_DSTAMPS
+// tuning build only (tools/build_variant.py dstamps -DRH_DSTAMPS): per-phase cycle totals of dxl_strip8 (wavefront 0 of the workgroups that hold cells)
+__device__ unsigned long long g_dstamps[16];
+extern "C" int rh_debug_dstamps(unsigned long long* out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dstamps), sizeof(g_dstamps)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_dstamps), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#define RH_DSTAMP(k) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_dstamps[k], t_ - t_prev_); t_prev_ = t_; } } while (0)
+#define RH_DSTAMP_BEGIN() unsigned long long t_prev_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) atomicAdd(&g_dstamps[15], 1ull)
+#else
+#define RH_DSTAMP(k) do { } while (0)
+#define RH_DSTAMP_BEGIN() do { } while (0)
+#endif
+
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 8))) void dxl_strip8(DxLinBatch B, const DxLinModel* __restrict__ L, int step)
 {
     constexpr int KD = 8, GS = 58, PAD = 8, CS = 80;
@@ -527,6 +543,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
             return;
         }
     }
+    RH_DSTAMP_BEGIN();
     // ---- the 30 window rows: loads first, all of them in flight at once (unconditional, from clamped addresses: a load behind a
     // branch is waited for behind that branch, which made these eight one round trip each), then the cell operands, whose chain of
     // dependent loads (letters -> pair type -> table values) travels behind them; zeros where the padded row has no column
@@ -550,8 +567,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     bool pairable = false;
     const DxCellRaw craw = dx_cell_loads(lda, rawt, dect, s1, s2, outside, sdw, a, L1, L2, smax, (w < 2 ? 1 : 0) | (w < 3 ? 2 : 0) | (w < 4 ? 4 : 0));
     __builtin_amdgcn_sched_barrier(0);
+    RH_DSTAMP(0);   // loads issued
 #pragma unroll
     for (int q = 0; q < 4; q++) { asm volatile("" : "+v"(vl[q])); asm volatile("" : "+v"(vh[q])); }   // (keeps the loads where they were issued)
+    RH_DSTAMP(1);   // window rows arrived
 #pragma unroll
     for (int q = 0; q < 4; q++) {   // the window rows were requested first and arrive first: into LDS while the cell's own loads travel
         const int r = 1 + w + 8 * q;
@@ -561,7 +580,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         if (lane < 40) seg[w][q][64 + lane] = rv && okh ? vh[q] : 0.0;
     }
     __builtin_amdgcn_sched_barrier(0);
+    RH_DSTAMP(2);   // staged
     DxCellOps o = dx_cell_weights(L, craw, outside, &pairable);
+    RH_DSTAMP(3);   // cell operands arrived, weights computed
     for (int k = threadIdx.x; k < 2 * KD * CS; k += 512) (&srow[0][0][0])[k] = 0.0;
     double acc[KD];
 #pragma unroll
@@ -571,7 +592,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 #undef X
     }
+    RH_DSTAMP(4);   // window pass
     __syncthreads();
+    RH_DSTAMP(5);   // barrier
     // partial sums meet over the dead staging area, [8 wavefronts][4 diagonals][64] at a time: diagonals 0..3 (read by their owners,
     // wavefronts 0..3), then diagonals 4..7
     double* const part = &seg[0][0][0];
@@ -588,6 +611,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         }
         lds_barrier_dx();
     }
+    RH_DSTAMP(6);   // partial sums exchanged (two halves, four barriers)
     auto finish = [&](int k) {
         // own-row sources: row k' <= k-2 at columns a + dir*(1..t+1), t = k-2-k'
         double v = 0.0, vx = 0.0;
@@ -612,6 +636,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         if ((w >> 1) == sl) finish(w);
         lds_barrier_dx();
     }
+    RH_DSTAMP(7);   // chain (four slots)
     // ---- the 2 x 8 rows go to HBM: row (table, k) by wavefront; every column of the row is rewritten
     if (own && a >= 0 && a <= B.n1max + 1) {
 #pragma unroll
@@ -621,6 +646,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
                 tab[(tbl ? (outside ? DL_OUTX : DL_INX) : (outside ? DL_OUT : DL_IN)) * ts + (size_t)sd * lda + kDxPad + a] = srow[tbl][k][PAD + lane];
         }
     }
+    RH_DSTAMP(8);   // stores issued
 }
 
 // Z~ = sum IN~[a,b] * close~(a,b)                                                (DuplexEngine.ipp:1066-1073)

@@ -207,13 +207,15 @@ struct InStripPlan {
     static constexpr int RA = NM + KD, CA = 96;   // FM rows d0-31 .. d0-1, columns i0+1 .. +95; KD zero rows behind them
     static constexpr int RE = 32, CE = 96;        // FCX rows d0-1-rho, rho = 0..31, columns i0+1 .. +95
     static constexpr int OFF_DUMMY = RD * CD + RA * CA + RE * CE;   // one row that is never read: the sink of the staging slots that hold no row
-    static constexpr int SZ = OFF_DUMMY + CA;
     // after the pre-phase everything behind the first KD rows of the fixed FM rows is dead and is reused:
     static constexpr int CS = 72;                 // row pitch of the strip's own rows
     static constexpr int TS = 4;                  // term sets: wavefront w accumulates term set w % TS for diagonals (w / TS) * KD*TS/W ..
-    static constexpr int OFF_PART = KD * CD;      // [TS][KD][2][64] partial sums
-    static constexpr int OFF_S = OFF_PART + TS * KD * 2 * 64;   // [5][KD][CS] rows FM, FM1, FCX, FC, FCA of this strip
-    static_assert(OFF_S + 5 * KD * CS <= SZ, "overlay does not fit");
+    static constexpr bool SPLIT = W == 8 && KD == 8;   // the FM2 sums are split by END between the wavefront halves (see the kernel)
+    static constexpr int PS = SPLIT ? 3 : 2;      // PART slots: FM2 partial sum (SPLIT: low end), filter, (SPLIT: high end)
+    static constexpr int OFF_PART = KD * CD;      // [TS][KD][PS][64] partial sums
+    static constexpr int OFF_S = OFF_PART + TS * KD * PS * 64;   // [5][KD][CS] rows FM, FM1, FCX, FC, FCA of this strip
+    static constexpr int OFF_F1S = OFF_S + 5 * KD * CS;          // [KD-1][64] FM1[m][i], m < KD, handed from the pre-phase to the chain
+    static constexpr int SZ = OFF_DUMMY + CA > OFF_F1S + (KD - 1) * 64 ? OFF_DUMMY + CA : OFF_F1S + (KD - 1) * 64;
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -342,14 +344,26 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_inside_strip(McB
         }
         vD1 = fm[(unsigned)((eD <= NM ? eD : NM) * ld) + (unsigned)(cD1 > 0 ? cD1 : 0)];
     }
+    // SPLIT (8 wavefronts): wavefronts 0..3 take the low-end sums of ALL eight diagonals and load only FM1[m][i], wavefronts 4..7 the high-end
+    // sums and only FM1[d0-m][i] -- half the loads of the (term set, diagonal half) split, in which the wavefronts w and w+4 fetched the same
+    // sixteen row segments; the two halves land in PART slots 0 and 2 and are added by the chain.
+    constexpr bool SPLIT = P::SPLIT;
+    const bool hi_role = SPLIT && w >= TS;
 #pragma unroll
     for (int q = 0; q < NT; q++) {   // this term set's FM1 values: rows m = 1+wt+TS*q (low end) and d0-m (high end), column i.  Slot m = 32 is
         // no term: it is paired with zero rows below.  Per-lane validity is a select; the wave-uniform condition of the high end
         // (m <= d0-32) is a 0/1 factor applied at use -- a uniform select on a load becomes a branch with a full drain behind it.
         const int m = 1 + wt + TS * q, R = d0 - m;
-        const double v = fm1[(unsigned)(m * ld) + (unsigned)i], u = fm1[(unsigned)(R * ld) + (unsigned)i];
-        a_lo[q] = i <= n - 1 - m ? v : 0.0;
-        a_hi[q] = i <= n - 1 - R ? u : 0.0;
+        if constexpr (SPLIT) {   // one load per term: the row is selected by the wavefront's role (no branch)
+            const int row = hi_role ? R : m;
+            const double x = fm1[(unsigned)(row * ld) + (unsigned)i];
+            a_lo[q] = i <= n - 1 - row ? x : 0.0;
+            a_hi[q] = 0.0;
+        } else {
+            const double v = fm1[(unsigned)(m * ld) + (unsigned)i], u = fm1[(unsigned)(R * ld) + (unsigned)i];
+            a_lo[q] = i <= n - 1 - m ? v : 0.0;
+            a_hi[q] = i <= n - 1 - R ? u : 0.0;
+        }
     }
     double fwv = 0.0;
     if constexpr (FACT) fwv = wT[kStripFiltOffD + (threadIdx.x < 160 ? threadIdx.x : 159)];   // (with the staging loads: no round trip of its own)
@@ -391,9 +405,20 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_inside_strip(McB
         const bool v = i <= n - 1 - d;
         {
             const unsigned c1 = (unsigned)(i + 1), c2 = (unsigned)(i + 2);
-            const double x01 = fcx[(unsigned)((d - 3) * ld) + c1], x10 = fcx[(unsigned)((d - 3) * ld) + c2], x11 = fcx[(unsigned)((d - 4) * ld) + c2];
-            const double fc = tab[S_FC * ts + (unsigned)((d - 2) * ld) + c1], fca = tab[S_FCA * ts + (unsigned)((d - 2) * ld) + c1];
-            const double xm1 = fm1[(unsigned)((d - 1) * ld) + c1], xm = fm[(unsigned)((d - 1) * ld) + (unsigned)i];
+            // Only the wavefronts that finish steps 0..3 read rows below d0: a wave-uniform nest, behind every other load of the batch (the
+            // wait that follows is for the staged rows, which are older).  Staging time follows the number of distinct 128-byte lines a
+            // workgroup pulls through its CU's L1 (profiles/r03_strip_timeline.txt), and these were 35 lines per wavefront
+            double x01 = 0.0, x10 = 0.0, x11 = 0.0, fc = 0.0, fca = 0.0, xm1 = 0.0, xm = 0.0;
+            if (k0 < 4) {
+                x11 = fcx[(unsigned)((d - 4) * ld) + c2];
+                if (k0 < 3) {
+                    x01 = fcx[(unsigned)((d - 3) * ld) + c1]; x10 = fcx[(unsigned)((d - 3) * ld) + c2];
+                    if (k0 < 2) {
+                        fc = tab[S_FC * ts + (unsigned)((d - 2) * ld) + c1]; fca = tab[S_FCA * ts + (unsigned)((d - 2) * ld) + c1];
+                        if (k0 < 1) { xm1 = fm1[(unsigned)((d - 1) * ld) + c1]; xm = fm[(unsigned)((d - 1) * ld) + (unsigned)i]; }
+                    }
+                }
+            }
             p_x01 = (v & (k0 < 3)) ? x01 : 0.0; p_x10 = (v & (k0 < 3)) ? x10 : 0.0;
             p_x11 = (v & (k0 < 4)) ? x11 : 0.0;
             p_fc = (v & (k0 < 2)) ? fc : 0.0; p_fca = (v & (k0 < 2)) ? fca : 0.0;
@@ -441,7 +466,54 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_inside_strip(McB
     double acc2[KH], accg[KH];
 #pragma unroll
     for (int k = 0; k < KH; k++) { acc2[k] = 0.0; accg[k] = 0.0; }
-    {
+    double acc8[SPLIT ? KD : 1];   // SPLIT: this wavefront's end of the FM2 sum, all eight diagonals
+    if constexpr (SPLIT) {
+#pragma unroll
+        for (int k = 0; k < KD; k++) acc8[k] = 0.0;
+        const lds_vp vLA = (lds_vp)LA;
+        const lds_vp vLD = (lds_vp)LDm;
+        double vx[KD], nx[KD];
+        // (software-pipelined by hand and pinned, volatile ds_read_b64: see the unsplit form below)
+        if (!hi_role) {   // low end: FM1[m][i] * FM[d-m][i+m]; FM row d0+k-m sits in staged row 31+k-m (rows >= 31 are zero; slot m = 32 reads zero rows)
+            auto issue = [&](int q, double* r) {
+                const int m = 1 + wt + TS * q;
+                const lds_vp pa = vLA + (m <= NM ? NM - m : NM) * CA + lane + (m <= NM ? m : NM) - 1;
+#pragma unroll
+                for (int k = 0; k < KD; k++) r[k] = pa[k * CA];
+            };
+            issue(0, vx);
+#pragma unroll
+            for (int q = 0; q < NT; q++) {
+                if (q + 1 < NT) issue(q + 1, nx);
+                const double a = a_lo[q];
+#pragma unroll
+                for (int k = 0; k < KD; k++) acc8[k] = fma(a, vx[k], acc8[k]);
+#pragma unroll
+                for (int k = 0; k < KD; k++) asm volatile("" : "+v"(acc8[k]));
+#pragma unroll
+                for (int k = 0; k < KD; k++) vx[k] = nx[k];
+            }
+        } else {          // high end: FM1[d0-x][i] * FM[e][i+d0-x], e = k+x, staged row e-1 at column index lane+k (rows e > 31 are zero)
+            auto issue = [&](int q, double* r) {
+                const int x = 1 + wt + TS * q;
+                const lds_vp pd = vLD + (x - 1) * CD + lane;
+#pragma unroll
+                for (int k = 0; k < KD; k++) r[k] = pd[k * (CD + 1)];
+            };
+            issue(0, vx);
+#pragma unroll
+            for (int q = 0; q < NT; q++) {
+                if (q + 1 < NT) issue(q + 1, nx);
+                const double b = a_lo[q] * ((1 + wt + TS * q) <= d0 - 32 ? 1.0 : 0.0);   // e = k+x <= d-32: rows m' = d-e >= 32 only
+#pragma unroll
+                for (int k = 0; k < KD; k++) acc8[k] = fma(b, vx[k], acc8[k]);
+#pragma unroll
+                for (int k = 0; k < KD; k++) asm volatile("" : "+v"(acc8[k]));
+#pragma unroll
+                for (int k = 0; k < KD; k++) vx[k] = nx[k];
+            }
+        }
+    } else {
         // two LDS operands per term and diagonal; software-pipelined by hand (the reads of term q+1 are issued before the
         // FMAs of term q) and pinned, because left alone the scheduler hoists every read of this block and spills.  The
         // volatile pointer keeps the reads as ds_read_b64: merged into ds_read2_b64 they run at half the LDS rate on CDNA4.
@@ -473,9 +545,9 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_inside_strip(McB
         }
     }
     RH_STAMPI(2);
-    double f1[KD - 1];   // FM1[m][i], m = 1..KD-1: low-end operands of the chain's own-row terms (latency hides behind the filter)
-#pragma unroll
-    for (int m = 1; m < KD; m++) { const double v = fm1[(unsigned)(m * ld) + (unsigned)i]; f1[m - 1] = i <= n - 1 - m ? v : 0.0; }
+    // FM1[m][i], m = 1..KD-1 (low-end operands of the chain's own-row terms) are a_lo[0], a_lo[1] of the wavefronts with kb == 0: m = 1+wt
+    // and 5+wt.  They are handed to every wavefront through LDS behind the filter (F1S), instead of seven more loads per wavefront.
+    const double f1keep0 = a_lo[0], f1keep1 = a_lo[1];
     RH_STAMPI(3);
     // single-branch filter: staged row rho is table row d0-1-rho = d-2-t with t = rho-1+k for diagonal d0+k; tap l1 reads column
     // i+1+l1 of it.  One LDS read feeds all KD diagonals.  The weight of (row rho, diagonal k, tap l1) is wT[l1][rho+k] (zero where
@@ -540,17 +612,30 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_inside_strip(McB
     double* const SFCX = SFM1 + KD * CS;
     double* const SFC = SFCX + KD * CS;
     double* const SFCA = SFC + KD * CS;
+    double* const F1S = lds + P::OFF_F1S;   // [KD-1][64]: behind the strip's own rows (staged filter rows, dead now)
+    constexpr int PS = P::PS;
+    if (kb == 0) {
+        F1S[wt * 64 + lane] = f1keep0;                              // m = 1 + wt
+        if (4 + wt < KD - 1) F1S[(4 + wt) * 64 + lane] = f1keep1;   // m = 5 + wt <= 7
+    }
+    if constexpr (SPLIT) {
+#pragma unroll
+        for (int k = 0; k < KD; k++) PART[((wt * KD + k) * PS + (hi_role ? 2 : 0)) * 64 + lane] = acc8[k];
+    }
 #pragma unroll
     for (int k = 0; k < KH; k++) {
-        PART[((wt * KD + kb + k) * 2 + 0) * 64 + lane] = acc2[k];
+        if constexpr (!SPLIT) PART[((wt * KD + kb + k) * PS + 0) * 64 + lane] = acc2[k];
         if constexpr (FACT) {   // accg[k]: diagonal k0+2k of column i-k (k0 = w / TS); lanes < k hold cells of the group to the left
-            if (lane >= k) PART[((wt * KD + w / TS + 2 * k) * 2 + 1) * 64 + lane - k] = accg[k];
+            if (lane >= k) PART[((wt * KD + w / TS + 2 * k) * PS + 1) * 64 + lane - k] = accg[k];
         } else {
-            PART[((wt * KD + kb + k) * 2 + 1) * 64 + lane] = accg[k];
+            PART[((wt * KD + kb + k) * PS + 1) * 64 + lane] = accg[k];
         }
     }
     __syncthreads();
 
+    double f1[KD - 1];
+#pragma unroll
+    for (int m = 1; m < KD; m++) f1[m - 1] = F1S[(m - 1) * 64 + lane];
     // ---- chain: step K finishes diagonal d0+K on wavefront K % W.  Only the terms that touch row K-1 (and the epilogue) are on the
     // critical path: in time slot T wavefront T % W finishes step T (fin) while the next wavefront gathers, for step T+1, the
     // partial sums and every term of rows <= T-1 (pre).
@@ -563,7 +648,11 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_inside_strip(McB
         const int K = w + W * sl;
         double fm2 = p_far[sl], g = 0.0;
 #pragma unroll
-        for (int q = 0; q < TS; q++) { fm2 += PART[((q * KD + K) * 2 + 0) * 64 + lane]; g += PART[((q * KD + K) * 2 + 1) * 64 + lane]; }
+        for (int q = 0; q < TS; q++) {
+            fm2 += PART[((q * KD + K) * PS + 0) * 64 + lane];
+            if constexpr (SPLIT) fm2 += PART[((q * KD + K) * PS + 2) * 64 + lane];
+            g += PART[((q * KD + K) * PS + 1) * 64 + lane];
+        }
         fm2s[sl] = fm2; gs[sl] = g;
     }
     // the terms of step K that touch the strip's own row R <= K-2 (FM2: m = K-R at both ends; filter: t = K-2-R)
@@ -817,15 +906,28 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_outside_strip(Mc
         vE1[p2] = fcox[(unsigned)((d0 + 1 + ra + lhalf * W) * ld + cE1)];
     }
     vD1 = fm[(unsigned)((eD <= NM ? eD : NM) * ld + cD1)];
+    // SPLIT (8 wavefronts): wavefronts 0..3 take the FMo sums of ALL eight diagonals and load only FM1[e][i-e], wavefronts 4..7 the FM1o sums and
+    // only FM2o[d0+e][i] -- half the loads of the (term set, diagonal half) split, in which the wavefronts w and w+4 fetched the same sixteen row
+    // segments at the same time; the partial sums land in the same PART slots.  One load per term, base and mask selected by role (no branch)
+    constexpr bool SPLIT = W == 8 && KD == 8;
+    const bool hi_role = SPLIT && w >= TS;
 #pragma unroll
     for (int q = 0; q < NT; q++) {   // this term set's own-column values: FM1[e][i-e] (FMo terms), FM2o[d0+e][i] (FM1o terms), e = 1+wt+TS*q.
         // Slot e = 32 is no term: it is paired with zero rows below.
         const int e = 1 + wt + TS * q, R = d0 + e;
         // (eager '&': with '&&' the compiler turns the select into a branch, sinks the load into it and waits for it there --
         //  one exposed round trip per value)
-        const double v = fm1[(unsigned)(e * ld + i - e)], u = fm2o[(unsigned)(R * ld + i)];
-        a_lo[q] = ((i - e >= 1) & (i <= n - 1)) ? v : 0.0;       // cell (i-e, i)
-        a_hi[q] = ((i >= 1) & (i <= n - 1 - R)) ? u : 0.0;       // cell (i, i+R)
+        if constexpr (SPLIT) {
+            const double* __restrict__ base = hi_role ? fm2o : fm1;
+            const double x = base[(unsigned)(hi_role ? R * ld + i : e * ld + i - e)];
+            const bool ok = hi_role ? ((i >= 1) & (i <= n - 1 - R)) : ((i - e >= 1) & (i <= n - 1));
+            a_lo[q] = ok ? x : 0.0;      // (one array: the role's operand)
+            a_hi[q] = 0.0;
+        } else {
+            const double v = fm1[(unsigned)(e * ld + i - e)], u = fm2o[(unsigned)(R * ld + i)];
+            a_lo[q] = ((i - e >= 1) & (i <= n - 1)) ? v : 0.0;       // cell (i-e, i)
+            a_hi[q] = ((i >= 1) & (i <= n - 1 - R)) ? u : 0.0;       // cell (i, i+R)
+        }
     }
     double fwv = 0.0;
     if constexpr (FACT) fwv = wT[kStripFiltOffD + (threadIdx.x < 160 ? threadIdx.x : 159)];   // (with the staging loads: no round trip of its own)
@@ -913,7 +1015,53 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_outside_strip(Mc
     double accm[KH], acc1[KH], accg[KH];
 #pragma unroll
     for (int k = 0; k < KH; k++) { accm[k] = 0.0; acc1[k] = 0.0; accg[k] = 0.0; }
-    {
+    double acc8[SPLIT ? KD : 1];   // SPLIT: this wavefront's sum (FMo or FM1o) of all eight diagonals
+    if constexpr (SPLIT) {
+#pragma unroll
+        for (int k = 0; k < KD; k++) acc8[k] = 0.0;
+        const lds_vp vLA = (lds_vp)LA;
+        const lds_vp vLD = (lds_vp)LDm;
+        double vx[KD], nx[KD];
+        if (!hi_role) {   // FMo: FM1[e][i-e] * FM2o[d0-k+e][i-e]: staged row KD + e-k-1, column index lane-e+31 (slot e = 32 reads zero rows only)
+            auto issue = [&](int q, double* r) {
+                const int e = 1 + wt + TS * q;
+                const lds_vp pa = vLA + (e <= NM ? KD + e - 1 : KD - 1) * CA + lane - (e <= NM ? e : NM) + 31;
+#pragma unroll
+                for (int k = 0; k < KD; k++) r[k] = pa[-k * CA];
+            };
+            issue(0, vx);
+#pragma unroll
+            for (int q = 0; q < NT; q++) {
+                if (q + 1 < NT) issue(q + 1, nx);
+                const double a = a_lo[q];
+#pragma unroll
+                for (int k = 0; k < KD; k++) acc8[k] = fma(a, vx[k], acc8[k]);
+#pragma unroll
+                for (int k = 0; k < KD; k++) asm volatile("" : "+v"(acc8[k]));
+#pragma unroll
+                for (int k = 0; k < KD; k++) vx[k] = nx[k];
+            }
+        } else {          // FM1o: FM2o[d0+x][i] * FM[x+k][i+d0-k]: staged row x+k-1 (rows e > 31 are zero), column index lane + (KD-1) - k
+            auto issue = [&](int q, double* r) {
+                const int x = 1 + wt + TS * q;
+                const lds_vp pd = vLD + (x - 1) * CD + lane + (KD - 1);
+#pragma unroll
+                for (int k = 0; k < KD; k++) r[k] = pd[k * (CD - 1)];
+            };
+            issue(0, vx);
+#pragma unroll
+            for (int q = 0; q < NT; q++) {
+                if (q + 1 < NT) issue(q + 1, nx);
+                const double b = a_lo[q];
+#pragma unroll
+                for (int k = 0; k < KD; k++) acc8[k] = fma(b, vx[k], acc8[k]);
+#pragma unroll
+                for (int k = 0; k < KD; k++) asm volatile("" : "+v"(acc8[k]));
+#pragma unroll
+                for (int k = 0; k < KD; k++) vx[k] = nx[k];
+            }
+        }
+    } else {
         const lds_vp vLA = (lds_vp)LA;
         const lds_vp vLD = (lds_vp)LDm;
         double va[KH], vb[KH], na[KH], nb[KH];
@@ -942,9 +1090,9 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_outside_strip(Mc
         }
     }
     RH_STAMPO(2);
-    double f1e[KD - 1];   // FM1[e][i-e], e = 1..KD-1: operands of the chain's own-row FMo terms
-#pragma unroll
-    for (int e = 1; e < KD; e++) { const double v = fm1[(unsigned)(e * ld + i - e)]; f1e[e - 1] = ((i - e >= 1) & (i <= n - 1)) ? v : 0.0; }
+    // FM1[e][i-e], e = 1..KD-1 (operands of the chain's own-row FMo terms) are a_lo[0], a_lo[1] of the wavefronts with kb == 0 (e = 1+wt, 5+wt):
+    // handed to every wavefront through LDS behind the filter (F1S) instead of seven more loads per wavefront
+    const double f1keep0 = a_lo[0], f1keep1 = a_lo[1];
     {   // (loaded here, behind the pre-phase, rather than with the other gathers: seven values fewer in registers while the staged rows
         //  are in flight -- the kernel is at 128 VGPRs, and a spilled gather is waited for where it is spilled)
         // the first of its steps may still need rows > d0 (unconditional loads, selected afterwards)
@@ -952,9 +1100,18 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_outside_strip(Mc
         const bool v = i >= 1 && i <= n - 1 - d;
         const bool right_ok = v && j + 1 <= n - 1, left_ok = v && i - 1 >= 1;
         const unsigned a1 = (unsigned)((d + 1) * ld + ic), a2 = (unsigned)((d + 2) * ld + ic), a3 = (unsigned)((d + 3) * ld + ic), a4 = (unsigned)((d + 4) * ld + ic);
-        const double l_fmo = tab[S_FMO * ts + a1], l_fm1o = tab[S_FM1O * ts + a1 - 1];                    // FMo[d+1][i], FM1o[d+1][i-1]   ipp:3806, 3833
-        const double l_fm1o_up = tab[S_FM1O * ts + a2 - 1], l_fco_up = tab[S_FCO * ts + a2 - 1];          // ipp:3828
-        const double l_x01 = fcox[a3 - 1], l_x10 = fcox[a3 - 2], l_x11 = fcox[a4 - 2];
+        // (only the wavefronts that finish steps 0..3 read rows above d0: a wave-uniform nest, see the inside strip)
+        double l_fmo = 0.0, l_fm1o = 0.0, l_fm1o_up = 0.0, l_fco_up = 0.0, l_x01 = 0.0, l_x10 = 0.0, l_x11 = 0.0;
+        if (k0 < 4) {
+            l_x11 = fcox[a4 - 2];
+            if (k0 < 3) {
+                l_x01 = fcox[a3 - 1]; l_x10 = fcox[a3 - 2];
+                if (k0 < 2) {
+                    l_fm1o_up = tab[S_FM1O * ts + a2 - 1]; l_fco_up = tab[S_FCO * ts + a2 - 1];          // ipp:3828
+                    if (k0 < 1) { l_fmo = tab[S_FMO * ts + a1]; l_fm1o = tab[S_FM1O * ts + a1 - 1]; }    // FMo[d+1][i], FM1o[d+1][i-1]   ipp:3806, 3833
+                }
+            }
+        }
         p_fmo = (right_ok & (k0 < 1)) ? l_fmo : 0.0;
         p_fm1o = (left_ok & (k0 < 1)) ? l_fm1o : 0.0;
         const bool up_ok = left_ok && right_ok;                                                          // the cell (i-1, j+1) is interior
@@ -1023,15 +1180,27 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_outside_strip(Mc
     double* const SFM1O = SFMO + KD * CS;
     double* const SFCO = SFM1O + KD * CS;
     double* const SFCOX = SFCO + KD * CS;
+    if constexpr (SPLIT) {
+#pragma unroll
+        for (int k = 0; k < KD; k++) PART[((wt * KD + k) * 3 + (hi_role ? 1 : 0)) * 64 + lane] = acc8[k];
+    }
 #pragma unroll
     for (int k = 0; k < KH; k++) {
-        PART[((wt * KD + kb + k) * 3 + 0) * 64 + lane] = accm[k];
-        PART[((wt * KD + kb + k) * 3 + 1) * 64 + lane] = acc1[k];
+        if constexpr (!SPLIT) {
+            PART[((wt * KD + kb + k) * 3 + 0) * 64 + lane] = accm[k];
+            PART[((wt * KD + kb + k) * 3 + 1) * 64 + lane] = acc1[k];
+        }
         if constexpr (FACT) {   // accg[k]: diagonal d0-(k0+2k) of column i+k; lanes > 63-k hold cells of the group to the right
             if (lane + k <= 63) PART[((wt * KD + w / TS + 2 * k) * 3 + 2) * 64 + lane + k] = accg[k];
         } else {
             PART[((wt * KD + kb + k) * 3 + 2) * 64 + lane] = accg[k];
         }
+    }
+    double* const F1S = lds + P::OFF_S + 5 * KD * CS;   // [KD-1][64]: behind the strip's own rows
+    static_assert(P::OFF_S + 5 * KD * CS + (KD - 1) * 64 <= P::SZ, "F1S does not fit");
+    if (kb == 0) {
+        F1S[wt * 64 + lane] = f1keep0;                              // e = 1 + wt
+        if (4 + wt < KD - 1) F1S[(4 + wt) * 64 + lane] = f1keep1;   // e = 5 + wt <= 7
     }
     for (int k = threadIdx.x; k < 5 * KD; k += 64 * W) {   // the left pad of the strip rows (read by lanes < 8 only)
 #pragma unroll
@@ -1039,6 +1208,9 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_outside_strip(Mc
     }
     __syncthreads();
 
+    double f1e[KD - 1];
+#pragma unroll
+    for (int e = 1; e < KD; e++) f1e[e - 1] = F1S[(e - 1) * 64 + lane];
     // ---- chain (see the inside strip): time slot T: wavefront T % W finishes diagonal d0-T, the next wavefront gathers for d0-T-1
     const double w_mu = L->w_mu, w_mp2 = L->w_mp2, w_ep2 = L->w_ep2;
     double sms[NSL], s1s[NSL], gs[NSL];

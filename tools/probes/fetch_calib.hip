@@ -92,6 +92,10 @@ int main()
     hipLaunchKernelGGL(calib_read<f4>, dim3(grid), dim3(256), 0, 0, (const f4*)buf, bytes / 16, sink);
     CHECK(hipDeviceSynchronize());
     printf("calib_read<f4> bytes_read=%zu\n", bytes);
+    // the same 16 B/lane streaming read from a base that is only 8-byte aligned (are unaligned dwordx4 loads served at the aligned rate?)
+    hipLaunchKernelGGL(calib_read<f4>, dim3(grid), dim3(256), 0, 0, (const f4*)((const char*)buf + 8), bytes / 16 - 1, sink);
+    CHECK(hipDeviceSynchronize());
+    printf("calib_read<f4>+8 bytes_read=%zu\n", bytes - 16);
     {
         const int ld = 513, rows = 32, gpb = 8;   // a band = 32 rows of 513 doubles, read by 8 overlapping 96-column windows
         const size_t band_doubles = (size_t)rows * ld;
