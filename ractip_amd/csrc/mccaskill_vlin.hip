@@ -221,6 +221,18 @@ __device__ __forceinline__ bool gap_ok_vl(int cut, int g) { return g != cut; }
 
 // the seven tabulated loop shapes: outer pair type t1, inner pair type t2 (0: the letters do not pair), letters si1/sj1
 // next to the outer pair inside the loop, sp1/sq1 next to the inner pair
+// the address small_w reads (l1, l2 wave-uniform: the branches hold no load)
+__device__ __forceinline__ const double* small_w_ptr(const VLinModel* L, int l1, int l2, int t1, int t2, int si1, int sj1, int sp1, int sq1)
+{
+    const int r2 = vienna_rtype(t2);
+    const int tt = t1 * 8 + r2;
+    if (l1 == 0 && l2 == 0) return &L->E_stack[tt];
+    if (l1 + l2 == 1) return &L->E_bulge1[tt];
+    if (l1 == 1 && l2 == 1) return &L->E_int11[tt * 25 + si1 * 5 + sj1];
+    if (l1 == 1 && l2 == 2) return &L->E_int21[tt * 125 + (si1 * 5 + sq1) * 5 + sj1];
+    if (l1 == 2 && l2 == 1) return &L->E_int21[(r2 * 8 + t1) * 125 + (sq1 * 5 + si1) * 5 + sp1];
+    return &L->E_int22[tt * 625 + ((si1 * 5 + sp1) * 5 + sq1) * 5 + sj1];
+}
 __device__ __forceinline__ double small_w(const VLinModel* L, int l1, int l2, int t1, int t2, int si1, int sj1, int sp1, int sq1)
 {
     const int r2 = vienna_rtype(t2);
@@ -409,6 +421,51 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) __attribute__((amdgpu_wave
     const int idd = 25 * (5 * s_jp1 + (GAPOK(j + 1) ? s_jp2 : 0)) + 5 * s_i + (GAPOK(i - 1) ? s_im1 : 0);
     const int idx_raw = 25 * (5 * s_jp1 + s_jp2) + 5 * s_i + s_im1;
     RH_VPIN(type); RH_VSTAMP(0);   // letters and pair type
+    // ---- MODE 1: the epilogue's operands are gathered HERE, by all W wavefronts (three or four loads each), and travel while the term
+    // loops run; they meet in LDS at the barrier that collects the partial sums.  Loaded by wavefront 0 alone behind that barrier (two
+    // dependent round trips: letters, then the tables) they were a third of a workgroup's life, spent with seven wavefronts gone and the
+    // group's LDS still held.  Wavefront 0: FCA, FM1, FMS of the neighbour cells; wavefront k+1: value and weight of tabulated shape k plus
+    // one of TXO TMC TMH TXI TSA tau TNC; wavefronts 1, 2 (two-molecule form): XS, XP.  One address per slot, selected by role -- no branch
+    // around a load.  Every value reaches the epilogue unchanged, so the results are bit-identical to the other launch organisations.
+    constexpr bool DIST = MODE == 1 && W == 8;
+    double opA = 0.0, opB = 0.0, opC = 0.0, opD = 0.0;
+    int b_ip2 = 0, b_ip3 = 0, b_jm1 = 0, b_jm2 = 0;
+    if constexpr (DIST) {
+        if (valid) {
+            b_ip2 = s[i + 2 <= n + 1 ? i + 2 : n + 1]; b_ip3 = s[i + 3 <= n + 1 ? i + 3 : n + 1];     // letters i+2, i+3, j-1, j-2
+            b_jm1 = s[j - 1 >= 0 ? j - 1 : 0]; b_jm2 = s[j - 2 >= 0 ? j - 2 : 0];
+        }
+        const int iv = valid ? i : 1;
+        const int k = w - 1;   // tabulated shape of this wavefront (w >= 1)
+        const int l1 = (k == 2 || k == 3 || k == 4) ? 1 : (k >= 5 ? 2 : 0);
+        const int l2 = (k == 1 || k == 3 || k == 5) ? 1 : ((k == 4 || k == 6) ? 2 : 0);
+        const int t = l1 + l2;
+        const bool sokk = pairable & (d - 2 - t >= 0) & (l1 <= l1max) & (l2 <= l2max);
+        const int sp = l1 == 0 ? s_ip1 : (l1 == 1 ? b_ip2 : b_ip3), spm = l1 == 0 ? s_i : (l1 == 1 ? s_ip1 : b_ip2);
+        const int sq_ = l2 == 0 ? s_j : (l2 == 1 ? b_jm1 : b_jm2), sqp = l2 == 0 ? s_jp1 : (l2 == 1 ? s_j : b_jm1);
+        const int t2 = vienna_ptype(sp, sq_);
+        const unsigned dm1 = (unsigned)((d >= 1 ? d - 1 : 0) * ld + iv), dm2 = (unsigned)((d >= 2 ? d - 2 : 0) * ld + iv);
+        const double* __restrict__ Lt = (const double*)L;
+        constexpr size_t oTXO = offsetof(VLinModel, TXO) / 8, oTMC = offsetof(VLinModel, TMC) / 8, oTMH = offsetof(VLinModel, TMH) / 8,
+                         oTXI = offsetof(VLinModel, TXI) / 8, oTSA = offsetof(VLinModel, TSA) / 8, oTNC = offsetof(VLinModel, TNC) / 8,
+                         oTAU = offsetof(VLinModel, E_tau) / 8;
+        // slot A: a table cell
+        const size_t offA = w == 0 ? VL_FCA * ts + dm2 + 1 : VL_FC * ts + (unsigned)((sokk ? d - 2 - t : 0) * ld + iv + 1 + l1);
+        // slot B: FM1 of the neighbour cell / the shape's weight
+        const double* __restrict__ pB = w == 0 ? tab + (VL_FM1 * ts + dm1 + 1) : small_w_ptr(L, l1, l2, type, t2, s_ip1, s_j, spm, sqp);
+        // slot C: FMS of the neighbour cell / one letter-indexed table
+        const int tnc = 25 * (5 * s_i + (GAPOK(i) ? s_ip1 : 0)) + 5 * s_jp1 + (GAPOK(j) ? s_j : 0);
+        const size_t offC = w == 1 ? oTXO + idx : w == 2 ? oTMC + idx : w == 3 ? oTMH + idx : w == 4 ? oTXI + idx_raw : w == 5 ? oTSA + idd
+                          : w == 6 ? oTAU + type : oTNC + (CUT ? tnc : 0);
+        const double* __restrict__ pC = w == 0 ? tab + (VL_FMS * ts + dm1) : Lt + offC;
+        opA = tab[offA]; opB = *pB; opC = *pC;
+        if constexpr (CUT) {
+            const bool nk = nick_in & pairable & (d >= kMinHairpin);
+            const size_t o = (size_t)sq * ld;
+            const double* __restrict__ pD = w == 2 ? B.xp + (o + (nk ? j : 1)) : B.xs + (o + ((nk & (w == 1)) ? i + 1 : 1));
+            opD = *pD;
+        }
+    }
     // ---- FM2[i,d] = sum_{m=1}^{d-1} FM1[m][i] * FM[d-m][i+m]: near terms here, far blocks from FM2F
     double acc2 = 0.0, acc2n = 0.0;
     {
@@ -585,6 +642,10 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) __attribute__((amdgpu_wave
     }
 
     RH_VPIN(accc); RH_VPIN(acccn); RH_VSTAMP(3);   // filters
+    if constexpr (DIST) {   // this wavefront's staging rows are dead: its epilogue operands go there
+        gbuf[w][0][lane] = opA; gbuf[w][1][lane] = opB; gbuf[w][2][lane] = opC;
+        if constexpr (CUT) gbuf[w][3][lane] = opD;
+    }
     if constexpr (MODE != 2) {
         part[0][w][lane] = acc2;
         part[1][w][lane] = accc;
@@ -607,23 +668,38 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) __attribute__((amdgpu_wave
     {   // epilogue operands: loaded here, after the term loops, so that they do not occupy registers during them -- and ALL AT ONCE:
         // every index below follows from letters that arrived long ago (pair types are arithmetic, vienna_ptype), every load is
         // unconditional from a clamped address and selected afterwards.  Behind per-lane `if`s these were ~20 dependent round trips.
-        const int b_ip2 = s[i + 2 <= n + 1 ? i + 2 : n + 1], b_ip3 = s[i + 3 <= n + 1 ? i + 3 : n + 1];     // letters i+2, i+3, j-1, j-2
-        const int b_jm1 = s[j - 1 >= 0 ? j - 1 : 0], b_jm2 = s[j - 2 >= 0 ? j - 2 : 0];
-        const double l_txo = L->TXO[idx], l_tmc = L->TMC[idx], l_tmh = L->TMH[idx], l_txi = L->TXI[idx_raw], l_tsa = L->TSA[idd], l_tau = L->E_tau[type];
-        const unsigned dm1 = (unsigned)((d >= 1 ? d - 1 : 0) * ld + i), dm2 = (unsigned)((d >= 2 ? d - 2 : 0) * ld + i);
-        const double l_fca = tab[VL_FCA * ts + dm2 + 1], l_fm1 = tab[VL_FM1 * ts + dm1 + 1], l_fms = tab[VL_FMS * ts + dm1];
+        if constexpr (!DIST) {
+            b_ip2 = s[i + 2 <= n + 1 ? i + 2 : n + 1]; b_ip3 = s[i + 3 <= n + 1 ? i + 3 : n + 1];     // letters i+2, i+3, j-1, j-2
+            b_jm1 = s[j - 1 >= 0 ? j - 1 : 0]; b_jm2 = s[j - 2 >= 0 ? j - 2 : 0];
+        }
+        double l_txo, l_tmc, l_tmh, l_txi, l_tsa, l_tau, l_fca, l_fm1, l_fms;
         double l_nick = 0.0;
-        if constexpr (CUT) {
-            const bool nk = nick_in & pairable & (d >= kMinHairpin);
-            const size_t o = (size_t)sq * ld;
-            const double xs = B.xs[o + (nk ? i + 1 : 1)], xp = B.xp[o + (nk ? j : 1)];
-            const double tn = L->TNC[25 * (5 * s_i + (GAPOK(i) ? s_ip1 : 0)) + 5 * s_jp1 + (GAPOK(j) ? s_j : 0)];
-            l_nick = nk ? xs * xp * tn : 0.0;
+        if constexpr (DIST) {   // gathered at the head of the kernel by the wavefront named in the row index
+            l_fca = gbuf[0][0][lane]; l_fm1 = gbuf[0][1][lane]; l_fms = gbuf[0][2][lane];
+            l_txo = gbuf[1][2][lane]; l_tmc = gbuf[2][2][lane]; l_tmh = gbuf[3][2][lane]; l_txi = gbuf[4][2][lane]; l_tsa = gbuf[5][2][lane];
+            l_tau = gbuf[6][2][lane];
+            if constexpr (CUT) {
+                const bool nk = nick_in & pairable & (d >= kMinHairpin);
+                const double xs = gbuf[1][3][lane], xp = gbuf[2][3][lane], tn = gbuf[7][2][lane];
+                l_nick = nk ? xs * xp * tn : 0.0;
+            }
+        } else {
+            l_txo = L->TXO[idx]; l_tmc = L->TMC[idx]; l_tmh = L->TMH[idx]; l_txi = L->TXI[idx_raw]; l_tsa = L->TSA[idd]; l_tau = L->E_tau[type];
+            const unsigned dm1 = (unsigned)((d >= 1 ? d - 1 : 0) * ld + i), dm2 = (unsigned)((d >= 2 ? d - 2 : 0) * ld + i);
+            l_fca = tab[VL_FCA * ts + dm2 + 1]; l_fm1 = tab[VL_FM1 * ts + dm1 + 1]; l_fms = tab[VL_FMS * ts + dm1];
+            if constexpr (CUT) {
+                const bool nk = nick_in & pairable & (d >= kMinHairpin);
+                const size_t o = (size_t)sq * ld;
+                const double xs = B.xs[o + (nk ? i + 1 : 1)], xp = B.xp[o + (nk ? j : 1)];
+                const double tn = L->TNC[25 * (5 * s_i + (GAPOK(i) ? s_ip1 : 0)) + 5 * s_jp1 + (GAPOK(j) ? s_j : 0)];
+                l_nick = nk ? xs * xp * tn : 0.0;
+            }
         }
         // tetraloop bonus (d = 4: the letters i .. i+5 are s_i, s_ip1, i+2, i+3, s_j, s_jp1)
         const bool tet_ok = (d == 4) & pairable & (s_i != 0) & (s_ip1 != 0) & (b_ip2 != 0) & (b_ip3 != 0) & (s_j != 0) & (s_jp1 != 0);
         const int tet_code = tet_ok ? ((((( (s_i - 1) * 4 + (s_ip1 - 1)) * 4 + (b_ip2 - 1)) * 4 + (b_ip3 - 1)) * 4 + (s_j - 1)) * 4 + (s_jp1 - 1)) : 0;
-        const double l_tet = L->E_tetra[tet_code];
+        double l_tet = 1.0;
+        if (!DIST || d == 4) l_tet = L->E_tetra[tet_code];   // (wave-uniform)
         // the seven tabulated shapes: inner pair letters (p, q) = (i+1+l1, j-l2), raw table cell (p, q-1)
         const double* __restrict__ fc = tab + VL_FC * ts;
         double sv[7], sw[7];
@@ -638,8 +714,11 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) __attribute__((amdgpu_wave
             const int sp = l1 == 0 ? s_ip1 : (l1 == 1 ? b_ip2 : b_ip3), spm = l1 == 0 ? s_i : (l1 == 1 ? s_ip1 : b_ip2);
             const int sq_ = l2 == 0 ? s_j : (l2 == 1 ? b_jm1 : b_jm2), sqp = l2 == 0 ? s_jp1 : (l2 == 1 ? s_j : b_jm1);
             const int t2 = vienna_ptype(sp, sq_);
-            sv[k] = fc[(unsigned)((sok[k] ? d - 2 - t : 0) * ld + i + 1 + l1)];
-            sw[k] = small_w(L, l1, l2, type, t2, s_ip1, s_j, spm, sqp);
+            if constexpr (DIST) { sv[k] = gbuf[k + 1][0][lane]; sw[k] = gbuf[k + 1][1][lane]; }
+            else {
+                sv[k] = fc[(unsigned)((sok[k] ? d - 2 - t : 0) * ld + i + 1 + l1)];
+                sw[k] = small_w(L, l1, l2, type, t2, s_ip1, s_j, spm, sqp);
+            }
         }
         e_txo = l_txo; e_tmc = l_tmc; e_tmh = l_tmh; e_txi = l_txi; e_tsa = l_tsa; e_tau = l_tau;
         nick = l_nick;
@@ -833,6 +912,47 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) __attribute__((amdgpu_wave
     const int idx_raw = 25 * (5 * s_jp1 + s_jp2) + 5 * s_i + s_im1;
     double accm = 0.0, acc1 = 0.0, accc = 0.0, accb = 0.0;
     double accmn = 0.0, acc1n = 0.0, acccn = 0.0, accbn = 0.0;   // MODE 1: diagonal d-1 without its e = 1 terms
+    // ---- MODE 1: the epilogue's operands are gathered here by all W wavefronts, four loads each, and meet in LDS at the barrier that
+    // collects the partial sums (see vlin_inside_diag).  Wavefront 0: FMSo, FM1o (two cells), FC; wavefront k+1: value and weight of
+    // tabulated shape k plus one of TXO TMC TXI TSA tau F5o F5i; the fourth slot: Z, and the two factors of the exterior-half stem.
+    constexpr bool DIST = MODE == 1 && W == 8;
+    double opA = 0.0, opB = 0.0, opC = 0.0, opD = 0.0;
+    int b_im2 = 0, b_im3 = 0, b_jp3 = 0, b_jp4 = 0;
+    if constexpr (DIST) {
+        if (valid) {
+            b_im2 = s[i - 2 >= 0 ? i - 2 : 0]; b_im3 = s[i - 3 >= 0 ? i - 3 : 0];
+            b_jp3 = s[j + 3 <= n + 1 ? j + 3 : n + 1]; b_jp4 = s[j + 4 <= n + 1 ? j + 4 : n + 1];
+        }
+        const int iv = valid ? i : 1, jv = iv + d;
+        const int k = w - 1;   // tabulated shape of this wavefront (w >= 1)
+        const int l1 = (k == 2 || k == 3 || k == 4) ? 1 : (k >= 5 ? 2 : 0);
+        const int l2 = (k == 1 || k == 3 || k == 5) ? 1 : ((k == 4 || k == 6) ? 2 : 0);
+        const int io = iv - 1 - l1, jo = jv + 1 + l2;
+        const bool sokk = pairable & (io >= 1) & (jo <= n - 1) & (l1 <= l1max) & (l2 <= l2max);
+        const int s_io = l1 == 0 ? s_im1 : (l1 == 1 ? b_im2 : b_im3), s_io1 = l1 == 0 ? s_i : (l1 == 1 ? s_im1 : b_im2);
+        const int s_jo = l2 == 0 ? s_jp1 : (l2 == 1 ? s_jp2 : b_jp3), s_jo1 = l2 == 0 ? s_jp2 : (l2 == 1 ? b_jp3 : b_jp4);
+        const int to = vienna_ptype(s_io, s_jo1);
+        const bool ok_so = valid & guard_m & (j + 1 <= n - 1) & GAPOK(j) & GAPOK(j + 1), ok_1o = valid & guard_m & (i - 1 >= 1) & GAPOK(i - 1) & GAPOK(i);
+        const bool ok_up = valid & up_ok & GAPOK(i - 1) & GAPOK(j + 1);
+        const double* __restrict__ Lt = (const double*)L;
+        constexpr size_t oTXO = offsetof(VLinModel, TXO) / 8, oTMC = offsetof(VLinModel, TMC) / 8, oTXI = offsetof(VLinModel, TXI) / 8,
+                         oTSA = offsetof(VLinModel, TSA) / 8, oTAU = offsetof(VLinModel, E_tau) / 8;
+        const size_t offA = w == 0 ? VL_FMSO * ts + (unsigned)((ok_so ? d + 1 : d) * ld + iv)
+                                   : VL_FCO * ts + (unsigned)(sokk ? (jo - io) * ld + io : d * ld + iv);
+        const double* __restrict__ pB = w == 0 ? tab + (VL_FM1O * ts + (unsigned)((ok_1o ? d + 1 : d) * ld + (ok_1o ? iv - 1 : iv)))
+                                               : small_w_ptr(L, l1, l2, to, type, s_io1, s_jo, s_im1, s_jp2);
+        const size_t offC = w == 1 ? oTXO + idx : w == 2 ? oTMC + idx : w == 3 ? oTXI + idx_raw : w == 4 ? oTSA + idd : oTAU + type;
+        const double* __restrict__ pC = w == 0 ? tab + (VL_FM1O * ts + (unsigned)((ok_up ? d + 2 : d) * ld + (ok_up ? iv - 1 : iv)))
+                                      : w == 6 ? f5o + (jv + 1) : w == 7 ? f5i + (iv - 1) : Lt + offC;
+        const double* __restrict__ pD = w == 0 ? tab + (VL_FC * ts + (unsigned)(d * ld + iv)) : f5i + n;
+        if constexpr (CUT) {
+            const size_t o = (size_t)sq * ld;
+            const bool right = valid & (i > cut), left = valid & (j + 1 <= cut);
+            if (w == 2) pD = (right ? B.xpo : B.xso) + (o + (right ? j + 1 : iv));
+            if (w == 3) pD = (right ? B.xp : B.xs) + (o + (right ? i - 1 : (left ? j + 2 : 1)));
+        }
+        opA = tab[offA]; opB = *pB; opC = *pC; opD = *pD;
+    }
     if constexpr (MODE == 2) {
         // the look-ahead sums of the previous launch + the e = 1 terms (row d+1) + the block products: ten loads, requested together
         // (rows d+1 and 1 exist for every d this launch sees; columns of a lane past the diagonal lie in the table) and selected afterwards
@@ -1025,6 +1145,7 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) __attribute__((amdgpu_wave
         }
     }
     }
+    if constexpr (DIST) { gbuf[w][0][lane] = opA; gbuf[w][1][lane] = opB; gbuf[w][2][lane] = opC; gbuf[w][3][lane] = opD; }   // (its staging rows are dead)
     if constexpr (MODE != 2) {
         part[0][w][lane] = accm;
         part[1][w][lane] = acc1;
@@ -1046,21 +1167,33 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) __attribute__((amdgpu_wave
     double o_fmso = 0, o_fm1o = 0, o_f5o = 0, o_f5i = 0, o_fm1o_up = 0, o_fc = 0, o_z = 1, sm7 = 0.0, o_x = 0.0;
     {   // epilogue operands: loaded after the term loops so that they do not occupy registers during them, all at once and without a
         // branch in front of any load (see vlin_inside_diag): the indices follow from letters, the letters were requested at the start
-        const int b_im2 = s[i - 2 >= 0 ? i - 2 : 0], b_im3 = s[i - 3 >= 0 ? i - 3 : 0];
-        const int b_jp3 = s[j + 3 <= n + 1 ? j + 3 : n + 1], b_jp4 = s[j + 4 <= n + 1 ? j + 4 : n + 1];
-        const double l_txo = L->TXO[idx], l_tmc = L->TMC[idx], l_txi = L->TXI[idx_raw], l_tsa = L->TSA[idd], l_tau = L->E_tau[type];
         const bool ok_so = guard_m & (j + 1 <= n - 1) & GAPOK(j) & GAPOK(j + 1), ok_1o = guard_m & (i - 1 >= 1) & GAPOK(i - 1) & GAPOK(i);
         const bool ok_up = up_ok & GAPOK(i - 1) & GAPOK(j + 1);
-        const double l_fmso = tab[VL_FMSO * ts + (unsigned)((ok_so ? d + 1 : d) * ld + i)];
-        const double l_fm1o = tab[VL_FM1O * ts + (unsigned)((ok_1o ? d + 1 : d) * ld + (ok_1o ? i - 1 : i))];
-        const double l_up = tab[VL_FM1O * ts + (unsigned)((ok_up ? d + 2 : d) * ld + (ok_up ? i - 1 : i))];
-        const double l_f5o = f5o[j + 1], l_f5i = f5i[i - 1], l_z = f5i[n], l_fc = tab[VL_FC * ts + at];
+        double l_txo, l_tmc, l_txi, l_tsa, l_tau, l_fmso, l_fm1o, l_up, l_f5o, l_f5i, l_z, l_fc;
         double l_x = 0.0;
-        if constexpr (CUT) {   // stem of one of the exterior halves of the loop around the missing gap
-            const size_t o = (size_t)sq * ld;
-            const bool right = i > cut, left = j + 1 <= cut;
-            const double a1 = (right ? B.xpo : B.xso)[o + (right ? j + 1 : i)], a2 = (right ? B.xp : B.xs)[o + (right ? i - 1 : (left ? j + 2 : 1))];
-            l_x = (right | left) ? a1 * a2 : 0.0;
+        if constexpr (DIST) {   // gathered at the head of the kernel by the wavefront named in the row index
+            l_fmso = gbuf[0][0][lane]; l_fm1o = gbuf[0][1][lane]; l_up = gbuf[0][2][lane]; l_fc = gbuf[0][3][lane];
+            l_txo = gbuf[1][2][lane]; l_tmc = gbuf[2][2][lane]; l_txi = gbuf[3][2][lane]; l_tsa = gbuf[4][2][lane]; l_tau = gbuf[5][2][lane];
+            l_f5o = gbuf[6][2][lane]; l_f5i = gbuf[7][2][lane]; l_z = gbuf[1][3][lane];
+            if constexpr (CUT) {
+                const bool right = i > cut, left = j + 1 <= cut;
+                const double a1 = gbuf[2][3][lane], a2 = gbuf[3][3][lane];
+                l_x = (right | left) ? a1 * a2 : 0.0;
+            }
+        } else {
+            b_im2 = s[i - 2 >= 0 ? i - 2 : 0]; b_im3 = s[i - 3 >= 0 ? i - 3 : 0];
+            b_jp3 = s[j + 3 <= n + 1 ? j + 3 : n + 1]; b_jp4 = s[j + 4 <= n + 1 ? j + 4 : n + 1];
+            l_txo = L->TXO[idx]; l_tmc = L->TMC[idx]; l_txi = L->TXI[idx_raw]; l_tsa = L->TSA[idd]; l_tau = L->E_tau[type];
+            l_fmso = tab[VL_FMSO * ts + (unsigned)((ok_so ? d + 1 : d) * ld + i)];
+            l_fm1o = tab[VL_FM1O * ts + (unsigned)((ok_1o ? d + 1 : d) * ld + (ok_1o ? i - 1 : i))];
+            l_up = tab[VL_FM1O * ts + (unsigned)((ok_up ? d + 2 : d) * ld + (ok_up ? i - 1 : i))];
+            l_f5o = f5o[j + 1]; l_f5i = f5i[i - 1]; l_z = f5i[n]; l_fc = tab[VL_FC * ts + at];
+            if constexpr (CUT) {   // stem of one of the exterior halves of the loop around the missing gap
+                const size_t o = (size_t)sq * ld;
+                const bool right = i > cut, left = j + 1 <= cut;
+                const double a1 = (right ? B.xpo : B.xso)[o + (right ? j + 1 : i)], a2 = (right ? B.xp : B.xs)[o + (right ? i - 1 : (left ? j + 2 : 1))];
+                l_x = (right | left) ? a1 * a2 : 0.0;
+            }
         }
         // the seven tabulated shapes: outer pair letters (io, jo+1) = (i-1-l1, j+2+l2), raw outside cell (io, jo)
         const double* __restrict__ fco = tab + VL_FCO * ts;
@@ -1076,8 +1209,11 @@ __global__ __launch_bounds__(MODE == 2 ? 64 : 64 * W) __attribute__((amdgpu_wave
             const int s_io = l1 == 0 ? s_im1 : (l1 == 1 ? b_im2 : b_im3), s_io1 = l1 == 0 ? s_i : (l1 == 1 ? s_im1 : b_im2);
             const int s_jo = l2 == 0 ? s_jp1 : (l2 == 1 ? s_jp2 : b_jp3), s_jo1 = l2 == 0 ? s_jp2 : (l2 == 1 ? b_jp3 : b_jp4);
             const int to = vienna_ptype(s_io, s_jo1);
-            sv[k] = fco[(unsigned)(sok[k] ? (jo - io) * ld + io : d * ld + i)];
-            sw[k] = small_w(L, l1, l2, to, type, s_io1, s_jo, s_im1, s_jp2);
+            if constexpr (DIST) { sv[k] = gbuf[k + 1][0][lane]; sw[k] = gbuf[k + 1][1][lane]; (void)to; (void)s_io1; (void)s_jo; (void)fco; }
+            else {
+                sv[k] = fco[(unsigned)(sok[k] ? (jo - io) * ld + io : d * ld + i)];
+                sw[k] = small_w(L, l1, l2, to, type, s_io1, s_jo, s_im1, s_jp2);
+            }
         }
         e_txo = l_txo; e_tmc = l_tmc; e_txi = l_txi; e_tsa = l_tsa; e_tau = l_tau;
         o_fmso = ok_so ? l_fmso : 0.0; o_fm1o = ok_1o ? l_fm1o : 0.0; o_fm1o_up = ok_up ? l_up : 0.0;

@@ -5,7 +5,7 @@ average ticks per cell workgroup between consecutive RH_VSTAMP sites (mccaskill_
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["RACTIP_HOT_LIB"] = os.path.join(ROOT, "ractip_amd", "libractip_hot_vstamps.so")
+os.environ["RACTIP_HOT_LIB"] = os.environ.get("RH_STAMPS_LIB") or os.path.join(ROOT, "ractip_amd", "libractip_hot_vstamps.so")
 import ractip_amd
 from ractip_amd.seqgen import random_pairs
 lib = ctypes.CDLL(os.environ["RACTIP_HOT_LIB"])
