@@ -13,7 +13,7 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
-HOT_SOURCES = ["rh_api.hip", "mccaskill.hip", "mccaskill_lin.hip", "mccaskill_far.hip", "mccaskill_strip.hip", "duplex.hip", "duplex_lin.hip", "duplex_vienna.hip", "duplex_vlin.hip", "mccaskill_vienna.hip", "mccaskill_vlin.hip", "param_loader.cpp", "vienna_loader.cpp"]
+HOT_SOURCES = ["rh_api.hip", "mccaskill.hip", "mccaskill_lin.hip", "mccaskill_far.hip", "mccaskill_strip.hip", "mccaskill_small.hip", "duplex.hip", "duplex_lin.hip", "duplex_vienna.hip", "duplex_vlin.hip", "mccaskill_vienna.hip", "mccaskill_vlin.hip", "param_loader.cpp", "vienna_loader.cpp"]
 HOT_LIB = os.path.join(PKG, "libractip_hot.so")
 LAST_BUILD = {"compiled": [], "reused": [], "linked": False}   # what the last build_hot() did (reported by __graft_entry__.build)
 

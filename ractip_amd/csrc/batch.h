@@ -71,6 +71,11 @@ struct McBatch {
     int seeded;
 };
 constexpr int kPkCopies = 6;
+// sequences of kSmallMin .. kSmallMax letters are folded by mccaskill_small.hip (one workgroup each, tables in LDS); the upper bound is
+// what three triangles of doubles plus the partial-sum buffers leave of 160 KB
+constexpr int kSmallMin = 8, kSmallMax = 109;
+// layout of rh_ctx::d_wT: transposed weights of the strip kernels [31][40], their factored tables, zero-padded rows [31][32] for mccaskill_small.hip
+constexpr int kStripFiltOff = 31 * 40, kStripFiltLen = 232, kSmallWLen = 31 * 32;
 
 enum DxTable {
     D_IN = 0,  // inside[i][j]

@@ -43,6 +43,7 @@ template <int SWEEP> __global__ void lin_pack_tiles(McBatch B, int Dblk, int out
 template <int KD, int W, int FILT> __global__ void lin_inside_strip(McBatch B, const LinModel* __restrict__ L, const double* __restrict__ wT, int d0, int f5_lo, double lam_d0, int pin);
 template <int KD, int W, int FILT> __global__ void lin_outside_strip(McBatch B, const LinModel* __restrict__ L, const double* __restrict__ wT, int d0, int f5_hi, int f5_lo, int pin, int* __restrict__ bad);
 __global__ void lin_f5i_tail(McBatch B, const LinModel* __restrict__ L, int jlo);
+void launch_lin_small(const McBatch& B, const LinModel* L, const double* wpad, const int* list, int nlist, int* bad, hipStream_t stream);   // mccaskill_small.hip
 __global__ void lin_f5o_head(McBatch B, const LinModel* __restrict__ L, int khi, int klo);
 __global__ void lin_far_inside_pk(McBatch B, int D, int l2);
 __global__ void lin_far_outside_pk(McBatch B, int D, int l2);
@@ -320,6 +321,14 @@ struct rh_ctx {
     int far2 = -1;                 // two-level block products: -1 = by size (sequences of n >= 384), 0 / 1 forced (RH_FAR2)
     int far2_next = -1;            // launch-sequence state of far_outside_step
     int strip_w = 8;               // wavefronts per strip workgroup (RH_STRIP_W = 4 | 8)
+    // short sequences (kSmallMin <= n <= kSmallMax, CONTRAfold model, scaled linear path): one workgroup per sequence, one launch
+    // (mccaskill_small.hip); chosen per sequence by its length alone, so a result does not depend on the rest of the batch.  The sweeps
+    // see these sequences with length 0 (d_n_sweep).  Opt-in (RH_SMALL=1): measured slower than the sweeps (6.1 against 4.9 ms per 1000 pairs of 109 + 53 letters).
+    int small_on = 0;
+    std::vector<int> small_list;
+    void* d_small_list = nullptr; size_t cap_small_list = 0;
+    void* d_n_sweep = nullptr; size_t cap_n_sweep = 0;
+    int nmax_sweep = 0;
     int strip_filt = 1;            // single-branch filter of the strip kernels: 1 = factored (A(t) B(|l1-l2|) + sparse residual), 0 = dense (RH_STRIP_FILT)
     bool strip_filt_ok = false;    // the model's weights have the factored form (strip_weights verifies it entry by entry)
     int co_cut_min = 0, co_cut_max = 0;   // smallest / largest cut (length of s1) of the two-molecule batch: bounds of the groups its sweeps launch
@@ -553,6 +562,25 @@ int stage(rh_ctx* c, int ns, const char* const* seqs, const int* lens, bool with
     c->h_codes = codes;
     HIP_TRY(c, hipMemcpyAsync(c->d_seq, codes.data(), codes.size(), hipMemcpyHostToDevice, c->s_mc));
     HIP_TRY(c, hipMemcpyAsync(c->d_n, lens, sizeof(int) * ns, hipMemcpyHostToDevice, c->s_mc));
+    c->small_list.clear();
+    c->nmax_sweep = nmax;
+    if (with_mc && !vienna && c->small_on && !cons) {
+        std::vector<int> nsw(lens, lens + ns);
+        c->nmax_sweep = 0;
+        for (int k = 0; k < ns; k++) {
+            if (lens[k] >= kSmallMin && lens[k] <= kSmallMax) { c->small_list.push_back(k); nsw[k] = 0; }
+            else c->nmax_sweep = std::max(c->nmax_sweep, lens[k]);
+        }
+        if (!c->small_list.empty()) {
+            // longest first: one workgroup occupies a CU, and workgroups of alternating cost land on alternating CUs
+            std::stable_sort(c->small_list.begin(), c->small_list.end(), [&](int a, int b) { return lens[a] > lens[b]; });
+            if ((rc = ensure(c, &c->d_small_list, &c->cap_small_list, sizeof(int) * ns, false))) return rc;
+            if ((rc = ensure(c, &c->d_n_sweep, &c->cap_n_sweep, sizeof(int) * ns, false))) return rc;
+            HIP_TRY(c, hipMemcpyAsync(c->d_small_list, c->small_list.data(), sizeof(int) * c->small_list.size(), hipMemcpyHostToDevice, c->s_mc));
+            HIP_TRY(c, hipMemcpyAsync(c->d_n_sweep, nsw.data(), sizeof(int) * ns, hipMemcpyHostToDevice, c->s_mc));
+            HIP_TRY(c, hipStreamSynchronize(c->s_mc));   // (nsw dies with this scope)
+        }
+    }
     HIP_TRY(c, hipStreamSynchronize(c->s_mc));  // host staging buffers die with this scope
 
     if (with_mc) {
@@ -972,11 +1000,25 @@ static bool strip_outside(const rh_ctx* c, const McBatch& B) { return (c->strip 
 template <int W, int BS>
 int launch_mc_lin(rh_ctx* c, int pin, int phase)
 {
-    const McBatch& B = c->mc;
+    const McBatch& BR = c->mc;   // the batch as uploaded
+    McBatch B = c->mc;           // the batch the sweeps see: short sequences have length 0 there (mccaskill_small.hip computes them)
     int* bad = (int*)c->d_bad;
+    const bool small_here = c->small_on && !c->small_list.empty() && (const void*)BR.n == c->d_n;   // (not for the sub-batches of the ladder)
+    if (small_here) { B.n = (const int*)c->d_n_sweep; B.nmax = c->nmax_sweep; }
+    if (small_here && phase == 0) {
+        hipLaunchKernelGGL(lin_init, dim3((BR.ns + 63) / 64), dim3(64), 0, c->s_mc, BR, c->d_lin, bad);
+        launch_lin_small(BR, c->d_lin, c->d_wT + kStripFiltOff + kStripFiltLen, (const int*)c->d_small_list, (int)c->small_list.size(), bad, c->s_mc);
+        c->n_launch[0]++;
+        if (B.nmax == 0) return RH_OK;
+    }
+    if (small_here && phase == 1 && B.nmax == 0) {
+        hipLaunchKernelGGL(lin_finish, dim3((BR.ns + 63) / 64), dim3(64), 0, c->s_mc, BR, c->d_lin, (double*)c->d_mclogz, bad);
+        hipLaunchKernelGGL(mc_unpaired, dim3((BR.nmax + 63) / 64, BR.ns), dim3(256), 0, c->s_mc, BR);
+        return RH_OK;
+    }
     const int last_block = BS > 0 ? (B.nmax - 1) / BS : 0;
     if (phase == 0) {
-    hipLaunchKernelGGL(lin_init, dim3((B.ns + 63) / 64), dim3(64), 0, c->s_mc, B, c->d_lin, bad);
+    if (!small_here) hipLaunchKernelGGL(lin_init, dim3((B.ns + 63) / 64), dim3(64), 0, c->s_mc, B, c->d_lin, bad);
     if constexpr (W == 4 && BS == 16) {
         if (strip_inside(c, B)) {
             // diagonals 0..31 by pairs (every row is "near" there), then strips of kStripKD diagonals (mccaskill_strip.hip)
@@ -1079,8 +1121,8 @@ int launch_mc_lin(rh_ctx* c, int pin, int phase)
                             d0 - 6, d0 - 13, (pin && c->strip_xcd) ? 2 : pin, bad);
                 c->n_launch[1]++;
             }
-            hipLaunchKernelGGL(lin_finish, dim3((B.ns + 63) / 64), dim3(64), 0, c->s_mc, B, c->d_lin, (double*)c->d_mclogz, bad);
-            hipLaunchKernelGGL(mc_unpaired, dim3((B.nmax + 63) / 64, B.ns), dim3(256), 0, c->s_mc, B);
+            hipLaunchKernelGGL(lin_finish, dim3((BR.ns + 63) / 64), dim3(64), 0, c->s_mc, BR, c->d_lin, (double*)c->d_mclogz, bad);
+            hipLaunchKernelGGL(mc_unpaired, dim3((BR.nmax + 63) / 64, BR.ns), dim3(256), 0, c->s_mc, BR);
             return RH_OK;
         }
     }
@@ -1109,8 +1151,8 @@ int launch_mc_lin(rh_ctx* c, int pin, int phase)
                         d, pin, bad);
                 c->n_launch[1]++;
             }
-            hipLaunchKernelGGL(lin_finish, dim3((B.ns + 63) / 64), dim3(64), 0, c->s_mc, B, c->d_lin, (double*)c->d_mclogz, bad);
-            hipLaunchKernelGGL(mc_unpaired, dim3((B.nmax + 63) / 64, B.ns), dim3(256), 0, c->s_mc, B);
+            hipLaunchKernelGGL(lin_finish, dim3((BR.ns + 63) / 64), dim3(64), 0, c->s_mc, BR, c->d_lin, (double*)c->d_mclogz, bad);
+            hipLaunchKernelGGL(mc_unpaired, dim3((BR.nmax + 63) / 64, BR.ns), dim3(256), 0, c->s_mc, BR);
             return RH_OK;
         }
     }
@@ -1131,8 +1173,8 @@ int launch_mc_lin(rh_ctx* c, int pin, int phase)
                            c->d_lin, d, pin, bad);
         c->n_launch[1]++;
     }
-    hipLaunchKernelGGL(lin_finish, dim3((B.ns + 63) / 64), dim3(64), 0, c->s_mc, B, c->d_lin, (double*)c->d_mclogz, bad);
-    hipLaunchKernelGGL(mc_unpaired, dim3((B.nmax + 63) / 64, B.ns), dim3(256), 0, c->s_mc, B);
+    hipLaunchKernelGGL(lin_finish, dim3((BR.ns + 63) / 64), dim3(64), 0, c->s_mc, BR, c->d_lin, (double*)c->d_mclogz, bad);
+    hipLaunchKernelGGL(mc_unpaired, dim3((BR.nmax + 63) / 64, BR.ns), dim3(256), 0, c->s_mc, BR);
     return RH_OK;
 }
 
@@ -1257,10 +1299,11 @@ int recompute_mc_subset_log(rh_ctx* c, const std::vector<int>& F)
 //   F[0..159]   W4[t+1][4] = {A(t), bulge weight wb(t), Bstep(t), centre residual Rc(t)}, t = -1..38 (zero outside 0..30)
 //   F[160..191] Bp[parity][j] = B(parity + 2j)
 //   F[192..231] Rx[t][l1-1], t = 0..9, l1 = 1..4: residuals of the shapes with 1 <= l1 <= 4 that are neither bulge end nor centre
-constexpr int kStripFiltOff = 31 * 40, kStripFiltLen = 232;
 std::vector<double> strip_weights(const LinModel& L, bool* ok_out = nullptr)
 {
-    std::vector<double> wT(kStripFiltOff + kStripFiltLen, 0.0);
+    std::vector<double> wT(kStripFiltOff + kStripFiltLen + kSmallWLen, 0.0);
+    for (int t = 0; t <= kMaxSingle; t++)   // zero-padded rows for mccaskill_small.hip
+        for (int l1 = 0; l1 <= t; l1++) wT[kStripFiltOff + kStripFiltLen + t * 32 + l1] = L.shape_w[t * (t + 1) / 2 + l1];
     double W[31][31] = {};
     for (int t = 0; t <= kMaxSingle; t++)
         for (int l1 = 0; l1 <= t; l1++) { W[t][l1] = L.shape_w[t * (t + 1) / 2 + l1]; wT[(size_t)l1 * 40 + t + 1] = W[t][l1]; }
@@ -1651,7 +1694,8 @@ size_t shape_key(const rh_ctx* c, int which)
         for (size_t v : {(size_t)B.ns, (size_t)B.nmax, (size_t)B.ld, (size_t)B.lds, (size_t)B.tab, (size_t)B.seq, (size_t)B.n,
                          (size_t)B.f5i, (size_t)B.bp, (size_t)B.up, (size_t)c->d_bad, (size_t)c->d_mclogz, (size_t)c->lin_w, (size_t)c->lin_w_in,
                          (size_t)c->lin_bs, (size_t)B.tri_stride, (size_t)c->far_mfma, (size_t)c->max_w, (size_t)c->d_gaps,
-                         (size_t)c->d_hplen, (size_t)B.allow, (size_t)B.pk, (size_t)c->far_pk, (size_t)B.rowp, (size_t)c->lookahead, (size_t)c->strip, (size_t)c->d_wT, (size_t)c->strip_w, (size_t)(c->strip_filt && c->strip_filt_ok), (size_t)c->strip_xcd, (size_t)(c->far2 + 2), (size_t)c->acc_wide, (size_t)c->acc_final_t, (size_t)c->d_vlin})
+                         (size_t)c->d_hplen, (size_t)B.allow, (size_t)B.pk, (size_t)c->far_pk, (size_t)B.rowp, (size_t)c->lookahead, (size_t)c->strip, (size_t)c->d_wT, (size_t)c->strip_w, (size_t)(c->strip_filt && c->strip_filt_ok), (size_t)c->strip_xcd, (size_t)(c->far2 + 2), (size_t)c->acc_wide, (size_t)c->acc_final_t, (size_t)c->d_vlin,
+                         (size_t)c->small_on, c->small_list.size(), (size_t)c->nmax_sweep, (size_t)c->d_small_list, (size_t)c->d_n_sweep})
             h = mix(h, v);
     } else {
         const DxLinBatch& X = c->dxl;
@@ -2125,6 +2169,7 @@ static rh_ctx* create_ctx(int device, int model, const char* param_file, const c
     if (const char* e = std::getenv("RH_STRIP")) c->strip = std::atoi(e);
     if (const char* e = std::getenv("RH_STRIP_W")) c->strip_w = std::atoi(e) == 4 ? 4 : 8;
     if (const char* e = std::getenv("RH_STRIP_FILT")) c->strip_filt = std::atoi(e) != 0;
+    if (const char* e = std::getenv("RH_SMALL")) c->small_on = std::atoi(e) != 0;
     if (const char* e = std::getenv("RH_FAR2")) c->far2 = std::atoi(e);
     if (const char* e = std::getenv("RH_STRIP_XCD")) c->strip_xcd = std::atoi(e);
     if (const char* e = std::getenv("RH_ACC_WIDE")) c->acc_wide = std::atoi(e);
@@ -2192,7 +2237,7 @@ void rh_destroy(rh_ctx* c)
     if (!c) return;
     if (c->helper) { rh_destroy(c->helper); c->helper = nullptr; }
     (void)hipSetDevice(c->device);
-    void* bufs[] = {c->d_seq, c->d_n, c->d_mctab, c->d_f5, c->d_bp, c->d_up, c->d_dxtab, c->d_hp, c->d_logz, c->d_scal, c->d_mclogz, c->d_bad, c->d_cnt, c->d_cand, c->d_dxbad, c->d_zbar, c->d_zpart, c->d_gaps, c->d_coseq, c->d_con, c->d_cotab, c->d_pk, c->d_copk, c->d_rowp, c->d_corowp, c->d_cof5, c->d_cobp, c->d_cobad, c->d_allow, c->d_coallow, c->d_vlin, c->d_vdxl, c->d_vdx, c->d_hplen, c->d_model, c->d_lin, c->d_dxlin, c->d_vienna, c->d_wT, c->d_subseq, c->d_subn, c->d_subbp, c->d_subup, c->d_subdseq, c->d_subdn, c->d_subdx, c->d_dxlin_r[0], c->d_dxlin_r[1], c->d_dxlin_r[2], c->d_dxlin_r[3]};
+    void* bufs[] = {c->d_seq, c->d_n, c->d_mctab, c->d_f5, c->d_bp, c->d_up, c->d_dxtab, c->d_hp, c->d_logz, c->d_scal, c->d_mclogz, c->d_bad, c->d_cnt, c->d_cand, c->d_dxbad, c->d_zbar, c->d_zpart, c->d_gaps, c->d_coseq, c->d_con, c->d_cotab, c->d_pk, c->d_copk, c->d_rowp, c->d_corowp, c->d_cof5, c->d_cobp, c->d_cobad, c->d_allow, c->d_coallow, c->d_vlin, c->d_vdxl, c->d_vdx, c->d_hplen, c->d_model, c->d_lin, c->d_dxlin, c->d_vienna, c->d_wT, c->d_subseq, c->d_subn, c->d_subbp, c->d_subup, c->d_subdseq, c->d_subdn, c->d_subdx, c->d_small_list, c->d_n_sweep, c->d_dxlin_r[0], c->d_dxlin_r[1], c->d_dxlin_r[2], c->d_dxlin_r[3]};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (int r = 0; r < rh_ctx::kRungs; r++) { if (c->d_lin_r[r]) (void)hipFree(c->d_lin_r[r]); if (c->d_wT_r[r]) (void)hipFree(c->d_wT_r[r]); }
     for (GraphSlot* g : {&c->g_in, &c->g_out, &c->g_dx}) if (g->exec) (void)hipGraphExecDestroy(g->exec);

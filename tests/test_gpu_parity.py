@@ -1033,7 +1033,9 @@ def test_sweep_organisations_agree(hotlib, oracle, monkeypatch):
     # (RH_STRIP_FILT=0: the dense single-branch filter instead of the factored one, A(t) B(|l1-l2|) + sparse residual)
     for env in ({"RH_STRIP_FILT": "0"}, {"RH_STRIP": "0"}, {"RH_STRIP": "1"}, {"RH_STRIP": "2"}, {"RH_STRIP_W": "4"}, {"RH_STRIP_XCD": "0"}, {"RH_FAR2": "1"},
                 {"RH_STRIP": "0", "RH_FAR2": "1"}, {"RH_STRIP": "0", "RH_LOOKAHEAD": "1"}, {"RH_STRIP": "0", "RH_LOOKAHEAD": "0"}, {"RH_FAR_PK": "0"},
-                {"RH_STRIP": "0", "RH_LOOKAHEAD": "0", "RH_LIN_W": "8"}, {"RH_STRIP": "0", "RH_LIN_W": "8"}, {"RH_DX_W": "8"}, {"RH_DX_QUAD": "0"}):
+                {"RH_STRIP": "0", "RH_LOOKAHEAD": "0", "RH_LIN_W": "8"}, {"RH_STRIP": "0", "RH_LIN_W": "8"}, {"RH_DX_W": "8"}, {"RH_DX_QUAD": "0"},
+                # (RH_SMALL=1: sequences of 8..109 letters by the one-workgroup-per-sequence kernel, the others of the same batch by the sweeps)
+                {"RH_SMALL": "1"}):
         got, got_pairs = run(env)
         for (bp, z), (bp0, z0), s in zip(got, base, seqs):
             assert abs(z - z0) < 1e-10, (env, len(s))
@@ -1042,3 +1044,42 @@ def test_sweep_organisations_agree(hotlib, oracle, monkeypatch):
             assert_prob_close(r["hp"], r0["hp"], rel=1e-10, what="%r hp" % (env,))
             assert_prob_close(r["bp1"], r0["bp1"], rel=1e-10, what="%r bp1" % (env,))
             assert np.allclose(r["logZ"], r0["logZ"], rtol=0, atol=1e-10)
+
+
+def test_short_sequences_one_workgroup_each(hotlib, oracle, monkeypatch):
+    """RH_SMALL=1 (mccaskill_small.hip): every sequence of 8..109 letters is folded by one workgroup with its tables in LDS, whatever
+    else the batch holds.  Lengths around the limits (7/8, 64/65/66 = one or two column groups, 109/110), a ragged batch with long
+    sequences in it, unpairable and unknown letters: bp / up / log Z against the CPU oracle, and bit-identical alone / inside the batch."""
+    import ractip_amd
+    monkeypatch.setenv("RH_SMALL", "1")
+    rng = np.random.RandomState(77)
+    lens = [7, 8, 9, 31, 33, 53, 64, 65, 66, 67, 100, 108, 109, 110, 150]
+    seqs = [rnd(rng, n) for n in lens] + ["A" * 40, "GGGGNNNNCCCCNNNNGGGGAAAACCCC", "GC" * 30]
+    c = ractip_amd.Context(device=0)
+    try:
+        alone = [c.bpp(s) for s in seqs]
+        for (bp, z), s in zip(alone, seqs):
+            o = oracle.inference(s)
+            assert abs(z - o["logZ"]) < 1e-9, len(s)
+            assert_prob_close(bp, o["post"], rel=REL, what="short n=%d" % len(s))
+        pairs = [(seqs[k], seqs[(k + 5) % len(seqs)]) for k in range(len(seqs))] + [(rnd(rng, 300), seqs[5])]
+        c.batch_upload(pairs)
+        c.batch_compute()
+        assert c.batch_fallbacks(0) == [] and c.batch_fallbacks(2) == []
+        for p, (s1, s2) in enumerate(pairs[:-1]):
+            r = c.batch_results(p)
+            k1, k2 = seqs.index(s1), seqs.index(s2)
+            for key, kz, k, sq in (("bp1", 0, k1, s1), ("bp2", 1, k2, s2)):
+                if 8 <= len(sq) <= 109:   # folded by its own workgroup: the batch cannot matter
+                    assert np.array_equal(r[key], alone[k][0]) and r["logZ"][kz] == alone[k][1], (p, len(sq))
+                else:                     # (the sweeps choose their launch organisation by the longest sequence of the batch)
+                    assert abs(r["logZ"][kz] - alone[k][1]) < 1e-10
+                    assert_prob_close(r[key], alone[k][0], rel=1e-10, what="n=%d in the mixed batch" % len(sq))
+            ref = oracle.up_float(len(s1), r["bp1"].astype(np.float32))   # ractip.cpp:213-222 in float
+            assert np.abs(r["up1"].astype(np.float32) - ref).max() < 2e-6
+        r = c.batch_results(len(pairs) - 1)
+        o = oracle.inference(pairs[-1][0])
+        assert abs(r["logZ"][0] - o["logZ"]) < 1e-9
+        assert_prob_close(r["bp1"], o["post"], rel=REL, what="the long sequence of the mixed batch")
+    finally:
+        c.close()
