@@ -61,8 +61,13 @@ typedef const volatile __attribute__((address_space(3))) double* lds_vp;
 #ifdef RH_STAMPS
 // tuning build only (tools/build_variant.py stamps -DRH_STAMPS): per-phase cycle totals of the strip kernels, summed over workgroups
 __device__ unsigned long long g_stamps[16];
-#define RH_STAMP(k) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_stamps[k], t_ - t_prev_); t_prev_ = t_; } } while (0)
-#define RH_STAMP_BEGIN() unsigned long long t_prev_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) atomicAdd(&g_stamps[15], 1ull)
+// The intervals are kept in registers and added to the global totals ONCE, at the last stamp (8): an atomic (or a store) issued in
+// front of the staging loads sits in the same in-order memory queue, and the wait for those loads then includes its round trip to a
+// contended address -- the first form of these macros inflated the staging phase it was meant to measure (found on mccaskill_small.hip,
+// where one atomic per stamp and diagonal doubled the kernel's duration).
+#define RH_STAMP(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc_[k] += t_ - t_prev_; t_prev_ = t_; \
+        if ((k) == 8 && threadIdx.x == 0) { for (int k_ = 0; k_ < 15; k_++) if (st_acc_[k_]) atomicAdd(&g_stamps[k_], st_acc_[k_]); atomicAdd(&g_stamps[15], 1ull); } } while (0)
+#define RH_STAMP_BEGIN() unsigned long long st_acc_[15] = {}; unsigned long long t_prev_ = __builtin_amdgcn_s_memtime()
 extern "C" int rh_debug_stamps(unsigned long long* out, int reset)
 {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(g_stamps)) != hipSuccess) return -1;
@@ -325,7 +330,34 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_inside_strip(McB
     const int ca0 = i0 + 1 + lane, ca1 = i0 + 65 + lsub;            // columns of the 64-wide part / of the tail
     const int dsel = lane >> 3, dsub = lane & 7;                     // D tails: row = dsel (< NR), 8 columns each
     const int eD = 1 + w + W * dsel, cD1 = i0 + d0 - eD + 64 + dsub;
-    {
+    // A group whose 96-column windows lie inside every staged row (all but the last two groups of a diagonal) needs no masks: its rows
+    // go from HBM straight into LDS (global_load_lds_dwordx4, 16 bytes per lane: the three regions are contiguous row-major, so one
+    // instruction fills 1024 consecutive LDS bytes from per-lane addresses) -- 9 instead of 17 loads per wavefront, no registers, no
+    // LDS-write phase.  RH_STRIP_DMA=0 (tuning build) keeps the register path for every group.
+#ifndef RH_STRIP_DMA
+#define RH_STRIP_DMA 1
+#endif
+    const bool full = RH_STRIP_DMA && W == 8 && i0 + 96 <= n - d0;   // (workgroup-uniform)
+    if (full) {
+        typedef const __attribute__((address_space(1))) void* gptr_t;
+        typedef __attribute__((address_space(3))) void* lptr_t;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int blk = k * W + w, chunk = blk * 64 + lane;   // 16-byte chunk of the region
+            if (chunk < NM * (CA / 2)) {                           // A: rows d0-31+row, columns i0+1 ..
+                const int row = chunk / (CA / 2), within = chunk - row * (CA / 2);
+                __builtin_amdgcn_global_load_lds((gptr_t)(fm + (unsigned)((d0 - NM + row) * ld) + (unsigned)(i0 + 1 + 2 * within)), (lptr_t)(LA + blk * 128), 16, 0, 0);
+            }
+            {                                                      // E: rows d0-1-rho, columns i0+1 ..  (32 x 48 chunks = 3 x 512)
+                const int row = chunk / (CE / 2), within = chunk - row * (CE / 2);
+                __builtin_amdgcn_global_load_lds((gptr_t)(fcx + (unsigned)((d0 - 1 - row) * ld) + (unsigned)(i0 + 1 + 2 * within)), (lptr_t)(LE + blk * 128), 16, 0, 0);
+            }
+            if (chunk < NM * (CD / 2)) {                           // D: rows e = 1 + row, columns i0+d0-e ..
+                const int row = chunk / (CD / 2), within = chunk - row * (CD / 2), e = row + 1;
+                __builtin_amdgcn_global_load_lds((gptr_t)(fm + (unsigned)(e * ld) + (unsigned)(i0 + d0 - e + 2 * within)), (lptr_t)(LDm + blk * 128), 16, 0, 0);
+            }
+        }
+    } else {
         const unsigned oA0 = (unsigned)ca0, oA1 = (unsigned)(ca1 + lhalf * W * ld);
         const unsigned oD0 = (unsigned)(i0 + d0 + lane);
 #pragma unroll
@@ -428,6 +460,7 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_inside_strip(McB
     // Every staged value is stored unconditionally (slots that hold no row go to a dummy row) and pinned here: otherwise the
     // compiler sinks a LOAD into the (branchy) select at its store and waits for it there, one round trip per row.
     double* const LX = lds + P::OFF_DUMMY;
+    if (!full) {
 #pragma unroll
     for (int q = 0; q < NR; q++) { asm volatile("" : "+v"(vA0[q])); asm volatile("" : "+v"(vE0[q])); asm volatile("" : "+v"(vD0[q])); }
 #pragma unroll
@@ -453,6 +486,7 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_inside_strip(McB
     {
         double* const dD = (dsel < NR && eD <= NM) ? LDm + (eD - 1) * CD : LX;
         dD[64 + dsub] = cD1 <= n - 1 - eD ? vD1 : 0.0;
+    }
     }
     for (int k = threadIdx.x; k < (P::RA - NM) * CA; k += 64 * W) LA[NM * CA + k] = 0.0;
     for (int k = threadIdx.x; k < (P::RD - NM) * CD; k += 64 * W) LDm[NM * CD + k] = 0.0;
@@ -891,6 +925,28 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_outside_strip(Mc
     const int cD0 = i0 + d0 - (KD - 1) + lane;                        // D: columns i0+d0-(KD-1) ..
     const int dsel = lane >> 3, dsub = lane & 7;                      // D tails: row = dsel (< NR), 8 columns each
     const int eD = 1 + w + W * dsel, cD1 = i0 + d0 - (KD - 1) + 64 + dsub;
+    // a group whose windows lie inside every staged row goes from HBM straight into LDS (see the inside strip)
+    const bool full = RH_STRIP_DMA && W == 8 && i0 >= 33 && i0 + 96 <= n - d0 && i0 + d0 - (KD - 1) >= 1;   // (workgroup-uniform)
+    if (full) {
+        typedef const __attribute__((address_space(1))) void* gptr_t;
+        typedef __attribute__((address_space(3))) void* lptr_t;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int blk = k * W + w, chunk = blk * 64 + lane;   // 16-byte chunk of the region
+            if (chunk < NM * (CA / 2)) {                           // A: rows d0+1+row behind the KD zero rows, columns i0-31 ..
+                const int row = chunk / (CA / 2), within = chunk - row * (CA / 2);
+                __builtin_amdgcn_global_load_lds((gptr_t)(fm2o + (unsigned)((d0 + 1 + row) * ld + i0 - 31 + 2 * within)), (lptr_t)(LA + KD * CA + blk * 128), 16, 0, 0);
+            }
+            {                                                      // E: rows d0+1+rho, columns i0-32 ..  (32 x 48 chunks = 3 x 512)
+                const int row = chunk / (CE / 2), within = chunk - row * (CE / 2);
+                __builtin_amdgcn_global_load_lds((gptr_t)(fcox + (unsigned)((d0 + 1 + row) * ld + i0 - 32 + 2 * within)), (lptr_t)(LE + blk * 128), 16, 0, 0);
+            }
+            if (chunk < NM * (CD / 2)) {                           // D: rows e = 1 + row, columns i0+d0-(KD-1) ..
+                const int row = chunk / (CD / 2), within = chunk - row * (CD / 2), e = row + 1;
+                __builtin_amdgcn_global_load_lds((gptr_t)(fm + (unsigned)(e * ld + i0 + d0 - (KD - 1) + 2 * within)), (lptr_t)(LDm + blk * 128), 16, 0, 0);
+            }
+        }
+    } else {
 #pragma unroll
     for (int q = 0; q < NR; q++) {
         const int ra = w + W * q;                                     // A row d0+1+ra (slot 31: no row), E row d0+1+rho, rho = ra
@@ -906,6 +962,7 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_outside_strip(Mc
         vE1[p2] = fcox[(unsigned)((d0 + 1 + ra + lhalf * W) * ld + cE1)];
     }
     vD1 = fm[(unsigned)((eD <= NM ? eD : NM) * ld + cD1)];
+    }
     // SPLIT (8 wavefronts): wavefronts 0..3 take the FMo sums of ALL eight diagonals and load only FM1[e][i-e], wavefronts 4..7 the FM1o sums and
     // only FM2o[d0+e][i] -- half the loads of the (term set, diagonal half) split, in which the wavefronts w and w+4 fetched the same sixteen row
     // segments at the same time; the partial sums land in the same PART slots.  One load per term, base and mask selected by role (no branch)
@@ -979,6 +1036,7 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_outside_strip(Mc
     }
     // ---- staged rows -> LDS (cells outside the interior of their row are staged as 0); unconditional stores, pinned values
     double* const LX = lds + P::OFF_DUMMY;
+    if (!full) {
 #pragma unroll
     for (int q = 0; q < NR; q++) { asm volatile("" : "+v"(vA0[q])); asm volatile("" : "+v"(vE0[q])); asm volatile("" : "+v"(vD0[q])); }
 #pragma unroll
@@ -1003,6 +1061,7 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_outside_strip(Mc
     {
         double* const dD = (dsel < NR && eD <= NM) ? LDm + (eD - 1) * CD : LX;
         dD[64 + dsub] = ((cD1 >= 1) & (cD1 <= n - 1 - eD)) ? vD1 : 0.0;
+    }
     }
     for (int k = threadIdx.x; k < KD * CA; k += 64 * W) LA[k] = 0.0;
     for (int k = threadIdx.x; k < (P::RD - NM) * CD; k += 64 * W) LDm[NM * CD + k] = 0.0;
