@@ -493,8 +493,10 @@ extern "C" int rh_debug_dstamps(unsigned long long* out, int reset)
     if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_dstamps), z, sizeof(z)) != hipSuccess) return -1; }
     return 0;
 }
-#define RH_DSTAMP(k) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_dstamps[k], t_ - t_prev_); t_prev_ = t_; } } while (0)
-#define RH_DSTAMP_BEGIN() unsigned long long t_prev_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) atomicAdd(&g_dstamps[15], 1ull)
+// (intervals in registers, added to the totals once at the last stamp (8): an atomic per stamp sits in front of the loads it is timing)
+#define RH_DSTAMP(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); dst_acc_[k] += t_ - t_prev_; t_prev_ = t_; \
+        if ((k) == 8 && threadIdx.x == 0) { for (int k_ = 0; k_ < 9; k_++) atomicAdd(&g_dstamps[k_], dst_acc_[k_]); atomicAdd(&g_dstamps[15], 1ull); } } while (0)
+#define RH_DSTAMP_BEGIN() unsigned long long dst_acc_[9] = {}; unsigned long long t_prev_ = __builtin_amdgcn_s_memtime()
 #else
 #define RH_DSTAMP(k) do { } while (0)
 #define RH_DSTAMP_BEGIN() do { } while (0)
