@@ -975,16 +975,11 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_outside_strip(Mc
         // (eager '&': with '&&' the compiler turns the select into a branch, sinks the load into it and waits for it there --
         //  one exposed round trip per value)
         if constexpr (SPLIT) {
-            // wavefronts 4..7: FM2o[d0+e][i] is column i of staged row d0+e (A region, masked alike) -- read from LDS behind the staging
-            // barrier instead of eight more loads of lines the staging fetches anyway.  (A wave-uniform branch: nothing in it is awaited
-            // before that barrier.)
-            a_lo[q] = 0.0;
-            if (!hi_role) {
-                const double x = fm1[(unsigned)(e * ld + i - e)];
-                a_lo[q] = ((i - e >= 1) & (i <= n - 1)) ? x : 0.0;
-            }
+            const double* __restrict__ base = hi_role ? fm2o : fm1;
+            const double x = base[(unsigned)(hi_role ? R * ld + i : e * ld + i - e)];
+            const bool ok = hi_role ? ((i >= 1) & (i <= n - 1 - R)) : ((i - e >= 1) & (i <= n - 1));
+            a_lo[q] = ok ? x : 0.0;      // (one array: the role's operand)
             a_hi[q] = 0.0;
-            (void)R;
         } else {
             const double v = fm1[(unsigned)(e * ld + i - e)], u = fm2o[(unsigned)(R * ld + i)];
             a_lo[q] = ((i - e >= 1) & (i <= n - 1)) ? v : 0.0;       // cell (i-e, i)
@@ -1116,8 +1111,7 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_outside_strip(Mc
 #pragma unroll
             for (int q = 0; q < NT; q++) {
                 if (q + 1 < NT) issue(q + 1, nx);
-                const int x = 1 + wt + TS * q;
-                const double b = x <= NM ? vLA[(KD + x - 1) * CA + lane + 31] : 0.0;   // FM2o[d0+x][i], staged (0 outside its row)
+                const double b = a_lo[q];
 #pragma unroll
                 for (int k = 0; k < KD; k++) acc8[k] = fma(b, vx[k], acc8[k]);
 #pragma unroll
