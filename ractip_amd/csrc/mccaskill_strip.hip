@@ -975,6 +975,9 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_outside_strip(Mc
         // (eager '&': with '&&' the compiler turns the select into a branch, sinks the load into it and waits for it there --
         //  one exposed round trip per value)
         if constexpr (SPLIT) {
+            // (FM2o[d0+e][i] is also column i of staged row d0+e, and wavefronts 4..7 could take it from LDS behind the staging barrier --
+            //  but then wavefronts 0..3 load under a condition, and whether that is a wave-uniform branch or an exec mask, the outside
+            //  sweep ran 5 - 10 % LONGER (20.7 -> 21.7 - 22.8 ms): the loads behind it are awaited where the branches join.  Measured twice.)
             const double* __restrict__ base = hi_role ? fm2o : fm1;
             const double x = base[(unsigned)(hi_role ? R * ld + i : e * ld + i - e)];
             const bool ok = hi_role ? ((i >= 1) & (i <= n - 1 - R)) : ((i - e >= 1) & (i <= n - 1));
