@@ -975,14 +975,7 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_outside_strip(Mc
         // (eager '&': with '&&' the compiler turns the select into a branch, sinks the load into it and waits for it there --
         //  one exposed round trip per value)
         if constexpr (SPLIT) {
-            // (FM2o[d0+e][i] is also column i of staged row d0+e, and wavefronts 4..7 could take it from LDS behind the staging barrier --
-            //  but then wavefronts 0..3 load under a condition, and whether that is a wave-uniform branch or an exec mask, the outside
-            //  sweep ran 5 - 10 % LONGER (20.7 -> 21.7 - 22.8 ms): the loads behind it are awaited where the branches join.  Measured twice.)
-            const double* __restrict__ base = hi_role ? fm2o : fm1;
-            const double x = base[(unsigned)(hi_role ? R * ld + i : e * ld + i - e)];
-            const bool ok = hi_role ? ((i >= 1) & (i <= n - 1 - R)) : ((i - e >= 1) & (i <= n - 1));
-            a_lo[q] = ok ? x : 0.0;      // (one array: the role's operand)
-            a_hi[q] = 0.0;
+            a_lo[q] = 0.0; a_hi[q] = 0.0; (void)R;   // (loaded further down, as the LAST loads in front of the LDS-write phase)
         } else {
             const double v = fm1[(unsigned)(e * ld + i - e)], u = fm2o[(unsigned)(R * ld + i)];
             a_lo[q] = ((i - e >= 1) & (i <= n - 1)) ? v : 0.0;       // cell (i-e, i)
@@ -1035,6 +1028,20 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_outside_strip(Mc
             p_far_1[sl] = v ? fm1of : 0.0;
             p_fc[sl] = v ? fcv : 0.0;
             p_f5o[sl] = v ? f5ov : 0.0;
+        }
+    }
+    // SPLIT: the FMo sums' own-column operands FM1[e][i-e] of wavefronts 0..3.  Wavefronts 4..7 need FM2o[d0+e][i], which is column i of
+    // staged row d0+e: they read it from LDS behind the staging barrier.  These loads therefore sit under a wave-uniform condition, and
+    // a conditional load is awaited where the branches join: placed among the other loads that cost 5 - 10 % of the sweep (the loads
+    // behind it went out late); placed HERE, with nothing behind it but the wait for the staged rows, it costs nothing.
+    if constexpr (SPLIT) {
+        if (!hi_role) {
+#pragma unroll
+            for (int q = 0; q < NT; q++) {
+                const int e = 1 + wt + TS * q;
+                const double x = fm1[(unsigned)(e * ld + i - e)];
+                a_lo[q] = ((i - e >= 1) & (i <= n - 1)) ? x : 0.0;
+            }
         }
     }
     // ---- staged rows -> LDS (cells outside the interior of their row are staged as 0); unconditional stores, pinned values
@@ -1114,7 +1121,8 @@ __global__ __launch_bounds__(64 * W, (W >= 8 ? 4 : 2)) void lin_outside_strip(Mc
 #pragma unroll
             for (int q = 0; q < NT; q++) {
                 if (q + 1 < NT) issue(q + 1, nx);
-                const double b = a_lo[q];
+                const int x = 1 + wt + TS * q;
+                const double b = x <= NM ? vLA[(KD + x - 1) * CA + lane + 31] : 0.0;   // FM2o[d0+x][i], staged (0 outside its row)
 #pragma unroll
                 for (int k = 0; k < KD; k++) acc8[k] = fma(b, vx[k], acc8[k]);
 #pragma unroll
