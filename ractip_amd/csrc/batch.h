@@ -74,6 +74,9 @@ constexpr int kPkCopies = 6;
 // sequences of kSmallMin .. kSmallMax letters are folded by mccaskill_small.hip (one workgroup each, tables in LDS); the upper bound is
 // what three triangles of doubles plus the partial-sum buffers leave of 160 KB
 constexpr int kSmallMin = 8, kSmallMax = 109;
+// the strip kernels (mccaskill_strip.hip) run when the longest sequence the sweeps see has at least this many letters (one strip behind the
+// 32 bootstrap diagonals); shorter sequences of such a batch get a pass of their own (rh_api.hip: launch_mc_lin)
+constexpr int kStripMinN = 40;
 // layout of rh_ctx::d_wT: transposed weights of the strip kernels [31][40], their factored tables, zero-padded rows [31][32] for mccaskill_small.hip
 constexpr int kStripFiltOff = 31 * 40, kStripFiltLen = 232, kSmallWLen = 31 * 32;
 

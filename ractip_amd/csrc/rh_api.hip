@@ -329,6 +329,11 @@ struct rh_ctx {
     void* d_small_list = nullptr; size_t cap_small_list = 0;
     void* d_n_sweep = nullptr; size_t cap_n_sweep = 0;
     int nmax_sweep = 0;
+    // sequences shorter than 40 letters next to longer ones: the sweeps choose their launch organisation by the longest sequence they
+    // see (strips of eight diagonals from 40 letters on), so these get a pass of their own with the organisation they would get alone
+    // (d_n_short: their lengths, 0 for everyone else) -- a result then does not depend on what else is in the batch
+    void* d_n_short = nullptr; size_t cap_n_short = 0;
+    int n_short = 0, nmax_short = 0;
     int strip_filt = 1;            // single-branch filter of the strip kernels: 1 = factored (A(t) B(|l1-l2|) + sparse residual), 0 = dense (RH_STRIP_FILT)
     bool strip_filt_ok = false;    // the model's weights have the factored form (strip_weights verifies it entry by entry)
     int co_cut_min = 0, co_cut_max = 0;   // smallest / largest cut (length of s1) of the two-molecule batch: bounds of the groups its sweeps launch
@@ -564,21 +569,30 @@ int stage(rh_ctx* c, int ns, const char* const* seqs, const int* lens, bool with
     HIP_TRY(c, hipMemcpyAsync(c->d_n, lens, sizeof(int) * ns, hipMemcpyHostToDevice, c->s_mc));
     c->small_list.clear();
     c->nmax_sweep = nmax;
-    if (with_mc && !vienna && c->small_on && !cons) {
-        std::vector<int> nsw(lens, lens + ns);
-        c->nmax_sweep = 0;
+    c->n_short = 0; c->nmax_short = 0;
+    if (with_mc && !vienna && !cons) {
+        std::vector<int> nsw(lens, lens + ns), nsh(ns, 0);
+        int nmax_rest = 0;
         for (int k = 0; k < ns; k++) {
-            if (lens[k] >= kSmallMin && lens[k] <= kSmallMax) { c->small_list.push_back(k); nsw[k] = 0; }
-            else c->nmax_sweep = std::max(c->nmax_sweep, lens[k]);
+            if (c->small_on && lens[k] >= kSmallMin && lens[k] <= kSmallMax) { c->small_list.push_back(k); nsw[k] = 0; }
+            else nmax_rest = std::max(nmax_rest, lens[k]);
         }
-        if (!c->small_list.empty()) {
+        if (nmax_rest >= kStripMinN)   // some sequence runs in strips: the ones below that length get their own pass
+            for (int k = 0; k < ns; k++)
+                if (nsw[k] > 0 && nsw[k] < kStripMinN) { nsh[k] = nsw[k]; nsw[k] = 0; c->n_short++; c->nmax_short = std::max(c->nmax_short, nsh[k]); }
+        c->nmax_sweep = 0;
+        for (int k = 0; k < ns; k++) c->nmax_sweep = std::max(c->nmax_sweep, nsw[k]);
+        if (!c->small_list.empty() || c->n_short) {
             // longest first: one workgroup occupies a CU, and workgroups of alternating cost land on alternating CUs
             std::stable_sort(c->small_list.begin(), c->small_list.end(), [&](int a, int b) { return lens[a] > lens[b]; });
             if ((rc = ensure(c, &c->d_small_list, &c->cap_small_list, sizeof(int) * ns, false))) return rc;
             if ((rc = ensure(c, &c->d_n_sweep, &c->cap_n_sweep, sizeof(int) * ns, false))) return rc;
-            HIP_TRY(c, hipMemcpyAsync(c->d_small_list, c->small_list.data(), sizeof(int) * c->small_list.size(), hipMemcpyHostToDevice, c->s_mc));
+            if ((rc = ensure(c, &c->d_n_short, &c->cap_n_short, sizeof(int) * ns, false))) return rc;
+            if (!c->small_list.empty())
+                HIP_TRY(c, hipMemcpyAsync(c->d_small_list, c->small_list.data(), sizeof(int) * c->small_list.size(), hipMemcpyHostToDevice, c->s_mc));
             HIP_TRY(c, hipMemcpyAsync(c->d_n_sweep, nsw.data(), sizeof(int) * ns, hipMemcpyHostToDevice, c->s_mc));
-            HIP_TRY(c, hipStreamSynchronize(c->s_mc));   // (nsw dies with this scope)
+            HIP_TRY(c, hipMemcpyAsync(c->d_n_short, nsh.data(), sizeof(int) * ns, hipMemcpyHostToDevice, c->s_mc));
+            HIP_TRY(c, hipStreamSynchronize(c->s_mc));   // (the staging vectors die with this scope)
         }
     }
     HIP_TRY(c, hipStreamSynchronize(c->s_mc));  // host staging buffers die with this scope
@@ -994,31 +1008,18 @@ int launch_cofold(rh_ctx* c)
 //   inside : far(D) right after fine diagonal (D-1)*BS-1  (its operands are final, tile (I,I+D) starts at (D-1)*BS+1)
 //   outside: far(D) right before fine diagonal (D+1)*BS-1 (operands: spans >= (D+1)*BS+1, already final)
 // the strip kernels need the packed block products (masked tiles) and at least one strip behind the 32 bootstrap diagonals
-static bool strip_inside(const rh_ctx* c, const McBatch& B) { return (c->strip & 1) && c->far_pk && c->far_mfma && c->lin_bs == 16 && B.nmax >= 40; }
-static bool strip_outside(const rh_ctx* c, const McBatch& B) { return (c->strip & 2) && c->far_pk && c->far_mfma && c->lin_bs == 16 && B.nmax >= 40; }
+static bool strip_inside(const rh_ctx* c, const McBatch& B) { return (c->strip & 1) && c->far_pk && c->far_mfma && c->lin_bs == 16 && B.nmax >= kStripMinN; }
+static bool strip_outside(const rh_ctx* c, const McBatch& B) { return (c->strip & 2) && c->far_pk && c->far_mfma && c->lin_bs == 16 && B.nmax >= kStripMinN; }
 
+// the sweeps of one phase over the sequences B shows (lengths 0 hide a sequence); BR: the batch as uploaded (lin_init / lin_finish /
+// mc_unpaired see every sequence)
 template <int W, int BS>
-int launch_mc_lin(rh_ctx* c, int pin, int phase)
+int launch_mc_lin_body(rh_ctx* c, int pin, int phase, const McBatch& B, const McBatch& BR, bool init, bool finish)
 {
-    const McBatch& BR = c->mc;   // the batch as uploaded
-    McBatch B = c->mc;           // the batch the sweeps see: short sequences have length 0 there (mccaskill_small.hip computes them)
     int* bad = (int*)c->d_bad;
-    const bool small_here = c->small_on && !c->small_list.empty() && (const void*)BR.n == c->d_n;   // (not for the sub-batches of the ladder)
-    if (small_here) { B.n = (const int*)c->d_n_sweep; B.nmax = c->nmax_sweep; }
-    if (small_here && phase == 0) {
-        hipLaunchKernelGGL(lin_init, dim3((BR.ns + 63) / 64), dim3(64), 0, c->s_mc, BR, c->d_lin, bad);
-        launch_lin_small(BR, c->d_lin, c->d_wT + kStripFiltOff + kStripFiltLen, (const int*)c->d_small_list, (int)c->small_list.size(), bad, c->s_mc);
-        c->n_launch[0]++;
-        if (B.nmax == 0) return RH_OK;
-    }
-    if (small_here && phase == 1 && B.nmax == 0) {
-        hipLaunchKernelGGL(lin_finish, dim3((BR.ns + 63) / 64), dim3(64), 0, c->s_mc, BR, c->d_lin, (double*)c->d_mclogz, bad);
-        hipLaunchKernelGGL(mc_unpaired, dim3((BR.nmax + 63) / 64, BR.ns), dim3(256), 0, c->s_mc, BR);
-        return RH_OK;
-    }
     const int last_block = BS > 0 ? (B.nmax - 1) / BS : 0;
     if (phase == 0) {
-    if (!small_here) hipLaunchKernelGGL(lin_init, dim3((B.ns + 63) / 64), dim3(64), 0, c->s_mc, B, c->d_lin, bad);
+    if (init) hipLaunchKernelGGL(lin_init, dim3((BR.ns + 63) / 64), dim3(64), 0, c->s_mc, BR, c->d_lin, bad);
     if constexpr (W == 4 && BS == 16) {
         if (strip_inside(c, B)) {
             // diagonals 0..31 by pairs (every row is "near" there), then strips of kStripKD diagonals (mccaskill_strip.hip)
@@ -1121,8 +1122,8 @@ int launch_mc_lin(rh_ctx* c, int pin, int phase)
                             d0 - 6, d0 - 13, (pin && c->strip_xcd) ? 2 : pin, bad);
                 c->n_launch[1]++;
             }
-            hipLaunchKernelGGL(lin_finish, dim3((BR.ns + 63) / 64), dim3(64), 0, c->s_mc, BR, c->d_lin, (double*)c->d_mclogz, bad);
-            hipLaunchKernelGGL(mc_unpaired, dim3((BR.nmax + 63) / 64, BR.ns), dim3(256), 0, c->s_mc, BR);
+            if (finish) hipLaunchKernelGGL(lin_finish, dim3((BR.ns + 63) / 64), dim3(64), 0, c->s_mc, BR, c->d_lin, (double*)c->d_mclogz, bad);
+            if (finish) hipLaunchKernelGGL(mc_unpaired, dim3((BR.nmax + 63) / 64, BR.ns), dim3(256), 0, c->s_mc, BR);
             return RH_OK;
         }
     }
@@ -1151,8 +1152,8 @@ int launch_mc_lin(rh_ctx* c, int pin, int phase)
                         d, pin, bad);
                 c->n_launch[1]++;
             }
-            hipLaunchKernelGGL(lin_finish, dim3((BR.ns + 63) / 64), dim3(64), 0, c->s_mc, BR, c->d_lin, (double*)c->d_mclogz, bad);
-            hipLaunchKernelGGL(mc_unpaired, dim3((BR.nmax + 63) / 64, BR.ns), dim3(256), 0, c->s_mc, BR);
+            if (finish) hipLaunchKernelGGL(lin_finish, dim3((BR.ns + 63) / 64), dim3(64), 0, c->s_mc, BR, c->d_lin, (double*)c->d_mclogz, bad);
+            if (finish) hipLaunchKernelGGL(mc_unpaired, dim3((BR.nmax + 63) / 64, BR.ns), dim3(256), 0, c->s_mc, BR);
             return RH_OK;
         }
     }
@@ -1173,6 +1174,38 @@ int launch_mc_lin(rh_ctx* c, int pin, int phase)
                            c->d_lin, d, pin, bad);
         c->n_launch[1]++;
     }
+    if (finish) hipLaunchKernelGGL(lin_finish, dim3((BR.ns + 63) / 64), dim3(64), 0, c->s_mc, BR, c->d_lin, (double*)c->d_mclogz, bad);
+    if (finish) hipLaunchKernelGGL(mc_unpaired, dim3((BR.nmax + 63) / 64, BR.ns), dim3(256), 0, c->s_mc, BR);
+    return RH_OK;
+}
+
+
+// Which sequences run where is decided per sequence, by its length alone: 8..109 letters by their own workgroup when RH_SMALL=1
+// (mccaskill_small.hip), fewer than kStripMinN letters next to longer ones in a pass of their own (the organisation they would get
+// alone), everyone else in the sweeps.  Sub-batches of the scale ladder (c->mc.n is not the upload's length array) run as they are.
+template <int W, int BS>
+int launch_mc_lin(rh_ctx* c, int pin, int phase)
+{
+    const McBatch BR = c->mc;
+    const bool routed = (const void*)BR.n == c->d_n && (!c->small_list.empty() || c->n_short > 0);
+    if (!routed) return launch_mc_lin_body<W, BS>(c, pin, phase, BR, BR, true, true);
+    int* bad = (int*)c->d_bad;
+    McBatch BL = BR, BSH = BR;
+    BL.n = (const int*)c->d_n_sweep; BL.nmax = c->nmax_sweep;
+    BSH.n = (const int*)c->d_n_short; BSH.nmax = c->nmax_short;
+    int rc;
+    if (phase == 0) {
+        hipLaunchKernelGGL(lin_init, dim3((BR.ns + 63) / 64), dim3(64), 0, c->s_mc, BR, c->d_lin, bad);
+        if (!c->small_list.empty()) {
+            launch_lin_small(BR, c->d_lin, c->d_wT + kStripFiltOff + kStripFiltLen, (const int*)c->d_small_list, (int)c->small_list.size(), bad, c->s_mc);
+            c->n_launch[0]++;
+        }
+        if (BL.nmax > 0 && (rc = launch_mc_lin_body<W, BS>(c, pin, 0, BL, BR, false, false))) return rc;
+        if (c->n_short > 0 && (rc = launch_mc_lin_body<W, BS>(c, pin, 0, BSH, BR, false, false))) return rc;
+        return RH_OK;
+    }
+    if (BL.nmax > 0 && (rc = launch_mc_lin_body<W, BS>(c, pin, 1, BL, BR, false, false))) return rc;
+    if (c->n_short > 0 && (rc = launch_mc_lin_body<W, BS>(c, pin, 1, BSH, BR, false, false))) return rc;
     hipLaunchKernelGGL(lin_finish, dim3((BR.ns + 63) / 64), dim3(64), 0, c->s_mc, BR, c->d_lin, (double*)c->d_mclogz, bad);
     hipLaunchKernelGGL(mc_unpaired, dim3((BR.nmax + 63) / 64, BR.ns), dim3(256), 0, c->s_mc, BR);
     return RH_OK;
@@ -1695,7 +1728,8 @@ size_t shape_key(const rh_ctx* c, int which)
                          (size_t)B.f5i, (size_t)B.bp, (size_t)B.up, (size_t)c->d_bad, (size_t)c->d_mclogz, (size_t)c->lin_w, (size_t)c->lin_w_in,
                          (size_t)c->lin_bs, (size_t)B.tri_stride, (size_t)c->far_mfma, (size_t)c->max_w, (size_t)c->d_gaps,
                          (size_t)c->d_hplen, (size_t)B.allow, (size_t)B.pk, (size_t)c->far_pk, (size_t)B.rowp, (size_t)c->lookahead, (size_t)c->strip, (size_t)c->d_wT, (size_t)c->strip_w, (size_t)(c->strip_filt && c->strip_filt_ok), (size_t)c->strip_xcd, (size_t)(c->far2 + 2), (size_t)c->acc_wide, (size_t)c->acc_final_t, (size_t)c->d_vlin,
-                         (size_t)c->small_on, c->small_list.size(), (size_t)c->nmax_sweep, (size_t)c->d_small_list, (size_t)c->d_n_sweep})
+                         (size_t)c->small_on, c->small_list.size(), (size_t)c->nmax_sweep, (size_t)c->d_small_list, (size_t)c->d_n_sweep,
+                         (size_t)c->n_short, (size_t)c->nmax_short, (size_t)c->d_n_short})
             h = mix(h, v);
     } else {
         const DxLinBatch& X = c->dxl;
@@ -2237,7 +2271,7 @@ void rh_destroy(rh_ctx* c)
     if (!c) return;
     if (c->helper) { rh_destroy(c->helper); c->helper = nullptr; }
     (void)hipSetDevice(c->device);
-    void* bufs[] = {c->d_seq, c->d_n, c->d_mctab, c->d_f5, c->d_bp, c->d_up, c->d_dxtab, c->d_hp, c->d_logz, c->d_scal, c->d_mclogz, c->d_bad, c->d_cnt, c->d_cand, c->d_dxbad, c->d_zbar, c->d_zpart, c->d_gaps, c->d_coseq, c->d_con, c->d_cotab, c->d_pk, c->d_copk, c->d_rowp, c->d_corowp, c->d_cof5, c->d_cobp, c->d_cobad, c->d_allow, c->d_coallow, c->d_vlin, c->d_vdxl, c->d_vdx, c->d_hplen, c->d_model, c->d_lin, c->d_dxlin, c->d_vienna, c->d_wT, c->d_subseq, c->d_subn, c->d_subbp, c->d_subup, c->d_subdseq, c->d_subdn, c->d_subdx, c->d_small_list, c->d_n_sweep, c->d_dxlin_r[0], c->d_dxlin_r[1], c->d_dxlin_r[2], c->d_dxlin_r[3]};
+    void* bufs[] = {c->d_seq, c->d_n, c->d_mctab, c->d_f5, c->d_bp, c->d_up, c->d_dxtab, c->d_hp, c->d_logz, c->d_scal, c->d_mclogz, c->d_bad, c->d_cnt, c->d_cand, c->d_dxbad, c->d_zbar, c->d_zpart, c->d_gaps, c->d_coseq, c->d_con, c->d_cotab, c->d_pk, c->d_copk, c->d_rowp, c->d_corowp, c->d_cof5, c->d_cobp, c->d_cobad, c->d_allow, c->d_coallow, c->d_vlin, c->d_vdxl, c->d_vdx, c->d_hplen, c->d_model, c->d_lin, c->d_dxlin, c->d_vienna, c->d_wT, c->d_subseq, c->d_subn, c->d_subbp, c->d_subup, c->d_subdseq, c->d_subdn, c->d_subdx, c->d_small_list, c->d_n_sweep, c->d_n_short, c->d_dxlin_r[0], c->d_dxlin_r[1], c->d_dxlin_r[2], c->d_dxlin_r[3]};
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (int r = 0; r < rh_ctx::kRungs; r++) { if (c->d_lin_r[r]) (void)hipFree(c->d_lin_r[r]); if (c->d_wT_r[r]) (void)hipFree(c->d_wT_r[r]); }
     for (GraphSlot* g : {&c->g_in, &c->g_out, &c->g_dx}) if (g->exec) (void)hipGraphExecDestroy(g->exec);
